@@ -1,0 +1,56 @@
+"""Particle swarm optimisation (Kennedy & Eberhart 1995).
+
+Reference behaviour: ``src/evox/algorithms/so/pso_variants/pso.py:18-108`` — ``ask`` hands out
+the current swarm, ``tell`` updates personal/global bests and moves the swarm.
+"""
+from __future__ import annotations
+
+import torch
+
+from ....core import random as rnd
+from ....core.algorithm import Algorithm
+from ....core.state import State
+from ....ops import swarm as _swarm
+
+
+class PSO(Algorithm):
+    def __init__(self, lb, ub, pop_size, inertia_weight=0.6, cognitive_coefficient=2.5, social_coefficient=0.8,
+                 mean=None, stdev=None):
+        super().__init__()
+        self.lb = torch.as_tensor(lb, dtype=torch.float32)
+        self.ub = torch.as_tensor(ub, dtype=torch.float32).to(self.lb.device)
+        self.dim = self.lb.shape[0]
+        self.pop_size = pop_size
+        self.w = inertia_weight
+        self.phi_p = cognitive_coefficient
+        self.phi_g = social_coefficient
+        self.mean = mean
+        self.stdev = stdev
+
+    def setup(self, key):
+        dev = self.lb.device
+        key = key.to(dev)
+        state_key, k_pop, k_vel = rnd.split(key, 3)
+        shape = (self.pop_size, self.dim)
+        if self.mean is not None and self.stdev is not None:
+            population = torch.clamp(self.stdev * rnd.normal(k_pop, shape) + self.mean, self.lb, self.ub)
+            velocity = self.stdev * rnd.normal(k_vel, shape)
+        else:
+            length = self.ub - self.lb
+            population = rnd.uniform(k_pop, shape) * length + self.lb
+            velocity = (rnd.uniform(k_vel, shape) * 2 - 1) * length
+        inf = torch.full((self.pop_size,), float("inf"), device=dev)
+        return State(population=population, velocity=velocity, local_best_location=population,
+                     local_best_fitness=inf, global_best_location=population[0],
+                     global_best_fitness=torch.full((1,), float("inf"), device=dev), key=state_key)
+
+    def ask(self, state):
+        return state.population, state
+
+    def tell(self, state, fitness):
+        key, k_move = rnd.split(state.key)
+        pop, vel, pbest, pbest_fit, gbest, gbest_fit = _swarm.pso_step(
+            k_move, state.population, state.velocity, fitness, state.local_best_location, state.local_best_fitness,
+            state.global_best_location, state.global_best_fitness, self.lb, self.ub, self.w, self.phi_p, self.phi_g)
+        return state.replace(population=pop, velocity=vel, local_best_location=pbest, local_best_fitness=pbest_fit,
+                             global_best_location=gbest, global_best_fitness=gbest_fit, key=key)

@@ -1,0 +1,162 @@
+"""Process-level distributed primitives.
+
+One process drives one GPU; processes talk through ``torch.distributed`` (backend ``nccl`` is
+RCCL over xGMI on ROCm, ``gloo`` on CPU).  These helpers are the single place the rest of the
+framework touches the communicator, and every one of them degrades to the identity in a
+single-process run, which is how the reference's ``all_gather(axis_name=None)`` behaves
+(reference: ``src/evox/core/distributed.py:17-87``).
+"""
+from __future__ import annotations
+
+import enum
+import os
+from typing import Optional, Sequence
+
+import torch
+
+POP_AXIS_NAME = "POP"
+
+
+class ShardingType(enum.Enum):
+    """Placement of a state field across the ranks of a job."""
+
+    SHARED_FIRST_DIM = "shard_dim0"
+    REPLICATED = "replicated"
+
+    def get_sharding(self, devices=None):
+        """Placement descriptor ``(kind, world_size)`` for ``devices`` (default: the job)."""
+        n = len(devices) if devices is not None else get_world_size()
+        return (self.value, n)
+
+    def shard(self, x: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+        if self is ShardingType.REPLICATED or world_size == 1:
+            return x
+        n = x.shape[0]
+        if n % world_size:
+            raise ValueError(f"dim0={n} not divisible by world_size={world_size}")
+        s = n // world_size
+        return x[rank * s:(rank + 1) * s]
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def is_dist_initialized() -> bool:
+    d = _dist()
+    return d.is_available() and d.is_initialized()
+
+
+def get_process_id() -> int:
+    return _dist().get_rank() if is_dist_initialized() else 0
+
+
+get_rank = get_process_id
+
+
+def get_world_size() -> int:
+    return _dist().get_world_size() if is_dist_initialized() else 1
+
+
+def init_process_group(backend: Optional[str] = None, device: Optional[torch.device] = None, **kw):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
+
+    Picks ``nccl`` (RCCL) when a GPU is visible, else ``gloo``; binds this process to
+    ``cuda:LOCAL_RANK``.  Safe to call when already initialised.
+    """
+    d = _dist()
+    if d.is_initialized():
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local if device is None else device)
+        kw.setdefault("device_id", torch.device("cuda", torch.cuda.current_device()))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    d.init_process_group(backend=backend, **kw)
+
+
+def _via_host(x: torch.Tensor) -> bool:
+    # gloo collectives are given CPU tensors only; device data is staged through host memory
+    return x.is_cuda and _dist().get_backend() == "gloo"
+
+
+def all_gather(x: torch.Tensor, axis_name: Optional[str] = POP_AXIS_NAME, axis: int = 0, tiled: bool = True,
+               group=None) -> torch.Tensor:
+    """Concatenate (``tiled``) or stack every rank's ``x`` along ``axis``.
+
+    Identity when ``axis_name`` is None or the job has one process.
+    """
+    if axis_name is None or not is_dist_initialized() or get_world_size() == 1:
+        return x if tiled else x.unsqueeze(axis)
+    d = _dist()
+    w = d.get_world_size(group)
+    src = x.contiguous()
+    stage = _via_host(src)
+    if stage:
+        src = src.cpu()
+    if axis == 0:
+        out = src.new_empty((w * src.shape[0],) + tuple(src.shape[1:])) if src.dim() else src.new_empty((w,))
+        d.all_gather_into_tensor(out, src.reshape(-1) if src.dim() == 0 else src, group=group)
+        parts = out if tiled and src.dim() else out.reshape((w,) + tuple(src.shape))
+        res = parts
+    else:
+        bufs = [torch.empty_like(src) for _ in range(w)]
+        d.all_gather(bufs, src, group=group)
+        res = torch.cat(bufs, dim=axis) if tiled else torch.stack(bufs, dim=axis)
+    return res.to(x.device) if stage else res
+
+
+def all_reduce(x: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
+    """Out-of-place all-reduce (sum / max / min / mean); identity in a single-process job."""
+    if not is_dist_initialized() or get_world_size() == 1:
+        return x
+    d = _dist()
+    ops = {"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN, "mean": d.ReduceOp.SUM}
+    y = x.detach().clone().contiguous()
+    stage = _via_host(y)
+    if stage:
+        y = y.cpu()
+    d.all_reduce(y, op=ops[op], group=group)
+    if op == "mean":
+        y = y / d.get_world_size(group)
+    return y.to(x.device) if stage else y
+
+
+def broadcast(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if not is_dist_initialized() or get_world_size() == 1:
+        return x
+    y = x.detach().clone().contiguous()
+    stage = _via_host(y)
+    if stage:
+        y = y.cpu()
+    _dist().broadcast(y, src=src, group=group)
+    return y.to(x.device) if stage else y
+
+
+def barrier(group=None) -> None:
+    if is_dist_initialized() and get_world_size() > 1:
+        _dist().barrier(group=group)
+
+
+def tree_all_gather(tree, axis_name: Optional[str] = POP_AXIS_NAME, **kwargs):
+    from .tree import tree_map
+
+    return tree_map(lambda t: all_gather(t, axis_name, **kwargs), tree)
+
+
+def unpmap(x, axis_name: Optional[str] = None):
+    """Replica 0 of a value that carries a leading replica axis (no-op otherwise).
+
+    Kept for API parity: in this framework every process holds its own un-batched replica, so
+    states never grow a device axis.
+    """
+    return x
+
+
+def tree_unpmap(tree, axis_name: Optional[str] = None):
+    return tree

@@ -1,0 +1,214 @@
+"""The standard ask → evaluate → tell driver.
+
+One ``step`` = monitor hooks, ``algorithm.ask`` (``init_ask`` on the first step), optional
+population slicing when several ranks share the evaluation, candidate transforms,
+``problem.evaluate``, fitness all-gather, fitness transforms, ``algorithm.tell`` and an
+optional migration.  There is no tracing compiler: the step is ordinary Python that launches
+fused kernels; ``graph_step=True`` records the steady-state step into a HIP graph and replays
+it (``evox_amd.utils.graph``).
+
+Multi-GPU: one process per GPU.  After ``enable_multi_devices`` every rank runs the same
+algorithm on replicated state (identical keys ⇒ identical populations), evaluates rows
+``[rank·n/W, (rank+1)·n/W)`` and all-gathers the fitness over RCCL — the data-parallel mode
+of the reference (``src/evox/workflows/std_workflow.py:33-313``).
+"""
+from __future__ import annotations
+
+from collections.abc import Callable, Sequence
+from typing import Optional, Union
+
+import torch
+
+from ..core import tree as _tree
+from ..core.algorithm import Algorithm, has_init_ask, has_init_tell
+from ..core.distributed import (POP_AXIS_NAME, all_gather, get_process_id, get_world_size, is_dist_initialized)
+from ..core.module import use_state
+from ..core.monitor import HOOK_NAMES, Monitor
+from ..core.problem import Problem
+from ..core.state import State
+from ..core.struct import dataclass, pytree_field
+from ..core.workflow import Workflow
+from ..utils.common import parse_opt_direction
+
+
+@dataclass
+class StdWorkflowState:
+    generation: int
+    first_step: bool = pytree_field(static=True)
+    rank: int = pytree_field(static=True)
+    world_size: int = pytree_field(static=True)
+
+
+class StdWorkflow(Workflow):
+    def __init__(
+        self,
+        algorithm: Algorithm,
+        problem: Problem,
+        monitors: Sequence[Monitor] = (),
+        opt_direction: Union[str, Sequence[str]] = "min",
+        candidate_transforms: Sequence[Callable] = (),
+        fitness_transforms: Sequence[Callable] = (),
+        jit_step: bool = True,
+        external_problem: bool = False,
+        num_objectives: Optional[int] = None,
+        migrate_helper=None,
+        graph_step: bool = False,
+    ):
+        """
+        algorithm, problem      the two halves of the loop.
+        monitors                called in list order at the hooks they declare.
+        opt_direction           "min" / "max", or one per objective; fitness is multiplied by
+                                ±1 so that algorithms always minimise.
+        candidate_transforms    applied in order to the candidates before evaluation
+                                (e.g. vector → parameter tree).
+        fitness_transforms      applied in order to the fitness before ``tell``.
+        jit_step                accepted for source compatibility; ignored.
+        external_problem        the problem runs on the host (simulator, numpy): candidates are
+                                copied to host memory, the fitness is copied back.  Requires
+                                ``num_objectives``.
+        migrate_helper          object with ``migrate_from_human() -> (do, pop, fit)``; when
+                                ``do`` is true ``algorithm.migrate(state, pop, fit)`` is called.
+        graph_step              replay the steady-state step from a HIP graph (GPU only).
+        """
+        super().__init__()
+        self.algorithm = algorithm
+        self.problem = problem
+        self.monitors = list(monitors)
+        self.registered_hooks = {name: [] for name in HOOK_NAMES}
+        for m in self.monitors:
+            for h in m.hooks():
+                if h not in self.registered_hooks:
+                    raise ValueError(f"unknown monitor hook {h!r}")
+                self.registered_hooks[h].append(m)
+        self.opt_direction = parse_opt_direction(opt_direction)
+        for m in self.monitors:
+            m.set_opt_direction(self.opt_direction)
+        self.candidate_transforms = list(candidate_transforms)
+        self.fitness_transforms = list(fitness_transforms)
+        self.jit_step = jit_step
+        self.external_problem = external_problem
+        self.num_objectives = num_objectives
+        self.migrate_helper = migrate_helper
+        self.graph_step = graph_step
+        if external_problem and num_objectives is None:
+            raise ValueError("Using external problem, but num_objectives isn't set")
+        self.pmap_axis_name = None
+        self._graphed = None
+
+    # ------------------------------------------------------------------------------------
+    def setup(self, key):
+        return State(StdWorkflowState(generation=0, first_step=True, rank=0, world_size=1))
+
+    def _ask(self, state):
+        first = has_init_ask(self.algorithm) and state.first_step
+        ask = self.algorithm.init_ask if first else self.algorithm.ask
+        return use_state(ask)(state)
+
+    def _evaluate(self, state, cands):
+        if not self.external_problem:
+            fitness, state = use_state(self.problem.evaluate)(state, cands)
+        else:
+            leaves = _tree.tree_leaves(cands)
+            dev = leaves[0].device
+            host_cands = _tree.tree_map(lambda t: t.detach().cpu() if isinstance(t, torch.Tensor) else t, cands)
+            fitness, state = use_state(self.problem.evaluate)(state, host_cands)
+            fitness = torch.as_tensor(fitness, dtype=torch.float32)
+            n = leaves[0].shape[0]
+            want = (n,) if self.num_objectives == 1 else (n, self.num_objectives)
+            if tuple(fitness.shape) != want:
+                raise ValueError(f"external problem returned fitness of shape {tuple(fitness.shape)}, expected {want}")
+            fitness = fitness.to(dev)
+        fitness = all_gather(fitness, self.pmap_axis_name, axis=0, tiled=True)
+        d = self.opt_direction
+        if isinstance(d, torch.Tensor):
+            fitness = fitness * d.to(fitness.device)
+        elif d != 1:
+            fitness = fitness * d
+        return fitness, state
+
+    def _tell(self, state, fitness):
+        first = has_init_tell(self.algorithm) and state.first_step
+        tell = self.algorithm.init_tell if first else self.algorithm.tell
+        return use_state(tell)(state, fitness)
+
+    def _step(self, state):
+        hooks = self.registered_hooks
+        for m in hooks["pre_step"]:
+            m.pre_step(state)
+        for m in hooks["pre_ask"]:
+            m.pre_ask(state)
+
+        cands, state = self._ask(state)
+
+        for m in hooks["post_ask"]:
+            m.post_ask(state, cands)
+
+        world = state.world_size
+        if world > 1:
+            n = _tree.tree_leaves(cands)[0].shape[0]
+            if n % world:
+                raise ValueError(f"#Candidates ({n}) should be divisible by the number of devices ({world})")
+            s = n // world
+            lo = state.rank * s
+            cands = _tree.tree_map(lambda x: x[lo:lo + s], cands)
+
+        tcands = cands
+        for t in self.candidate_transforms:
+            tcands = t(tcands)
+
+        for m in hooks["pre_eval"]:
+            m.pre_eval(state, cands, tcands)
+
+        fitness, state = self._evaluate(state, tcands)
+
+        for m in hooks["post_eval"]:
+            m.post_eval(state, cands, tcands, fitness)
+
+        tfitness = fitness
+        for t in self.fitness_transforms:
+            tfitness = t(tfitness)
+
+        for m in hooks["pre_tell"]:
+            m.pre_tell(state, cands, tcands, fitness, tfitness)
+
+        state = self._tell(state, tfitness)
+
+        for m in hooks["post_tell"]:
+            m.post_tell(state)
+
+        if self.migrate_helper is not None:
+            do_migrate, foreign_pop, foreign_fit = self.migrate_helper.migrate_from_human()
+            if bool(do_migrate):
+                state = use_state(self.algorithm.migrate)(state, foreign_pop, foreign_fit)
+
+        if state.first_step:
+            state = state.replace(generation=state.generation + 1, first_step=False)
+        else:
+            state = state.replace(generation=state.generation + 1)
+
+        for m in hooks["post_step"]:
+            m.post_step(state)
+        return state
+
+    def step(self, state):
+        if self.graph_step and not state.first_step:
+            if self._graphed is None:
+                from ..utils.graph import GraphedStep
+
+                self._graphed = GraphedStep(self._step)
+            return self._graphed(state)
+        return self._step(state)
+
+    # ------------------------------------------------------------------------------------
+    def enable_multi_devices(self, state: State, pmap_axis_name=POP_AXIS_NAME) -> State:
+        """Switch to population-sharded evaluation over all ranks of the job.
+
+        Call after ``init`` on every rank (same key everywhere).  Requires an initialised
+        process group when the job has more than one process."""
+        self.pmap_axis_name = pmap_axis_name
+        own = state.find_path_to(self._node_id, None)
+        world, rank = get_world_size(), get_process_id()
+        if own is None:
+            return state.replace(rank=rank, world_size=world)
+        path, node = own
+        return state.replace_by_path(path, node.replace(rank=rank, world_size=world))

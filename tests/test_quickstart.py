@@ -1,0 +1,35 @@
+"""README quick-start of the reference (PSO pop=100 on 2-D Ackley through StdWorkflow)."""
+import pytest
+import torch
+
+import evox_amd as ex
+from evox_amd import algorithms, monitors, problems, workflows
+
+
+def run(device, steps=100):
+    pso = algorithms.PSO(lb=torch.full((2,), -32.0, device=device), ub=torch.full((2,), 32.0, device=device),
+                         pop_size=100)
+    monitor = monitors.EvalMonitor()
+    wf = workflows.StdWorkflow(pso, problems.numerical.Ackley(), monitors=[monitor])
+    state = wf.init(ex.PRNGKey(42))
+    for _ in range(steps):
+        state = wf.step(state)
+    return monitor, state
+
+
+def test_quickstart_cpu():
+    monitor, state = run(torch.device("cpu"))
+    assert float(monitor.get_best_fitness()) < 1e-2
+    assert state.generation == 100
+    assert len(monitor.get_history()) == 100
+
+
+@pytest.mark.gpu
+def test_quickstart_gpu_matches_cpu_trajectory(cuda):
+    m_gpu, s_gpu = run(cuda, steps=20)
+    m_cpu, s_cpu = run(torch.device("cpu"), steps=20)
+    assert float(m_gpu.get_best_fitness()) < 1.0
+    a = s_gpu.get_child_state("algorithm")
+    b = s_cpu.get_child_state("algorithm")
+    # same Philox stream on both sides: trajectories agree up to transcendental rounding
+    assert torch.allclose(a.population.cpu(), b.population, atol=1e-2, rtol=1e-2)
