@@ -1,1 +1,2 @@
+from .es_variants import *
 from .pso_variants import *

@@ -1,0 +1,239 @@
+"""CMA-ES family: CMAES, SepCMAES, IPOPCMAES, BIPOPCMAES.
+
+Follows Hansen, "The CMA Evolution Strategy: A Tutorial" with the parameter settings of the
+reference (``src/evox/algorithms/so/es_variants/cma_es.py:32-388``).  The three heavy steps
+(sampling GEMM, rank-μ covariance update, eigendecomposition) are ``evox_amd.ops.cma``; the
+O(n) path/step-size algebra is a few small tensor ops.
+
+State layout equals the reference's: ``pc, ps, B, D, C, count_eigen, count_iter, invsqrtC,
+mean, sigma, key, population``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from ....core import random as rnd
+from ....core.algorithm import Algorithm
+from ....core.state import State
+from ....ops import cma as _cma
+from ....ops import sort as _sort
+
+
+class CMAES(Algorithm):
+    def __init__(self, center_init, init_stdev, pop_size: Optional[int] = None, recombination_weights=None, cm=1,
+                 decomp_per_iter: Optional[int] = None, precision: str = "fp32", eigh_method: Optional[str] = None,
+                 decomposition: str = "eigh"):
+        """
+        center_init            initial mean, shape (dim,); its device is where the run lives.
+        init_stdev             initial step size σ > 0.
+        pop_size               λ (default 4 + ⌊3 ln dim⌋).
+        recombination_weights  positive, non-increasing, summing to 1 (default log weights).
+        decomp_per_iter        eigendecompose every this many generations (default: the
+                               tutorial's max(⌊1/((c₁+cμ)·dim·10)⌋, 1)).
+        precision              "fp32" or "bf16" inputs of the sampling / covariance GEMMs
+                               (accumulation is always fp32).
+        eigh_method            see ``evox_amd.ops.cma.decompose``.
+        decomposition          "eigh": ``B``/``D`` are eigenvectors / sqrt-eigenvalues of ``C`` (the
+                               tutorial's formulation).  "newton_schulz": the two matrix functions
+                               the algorithm consumes, ``C^{1/2}`` (sampling) and ``C^{-1/2}``
+                               (σ-path), are computed directly by a GEMM-only iteration; the state
+                               then holds ``B = C^{1/2}``, ``D = 1`` so that the sampling rule
+                               ``m + σ (Z∘D) Bᵀ`` and ``B D² Bᵀ = C`` keep holding.  Both draw
+                               ``N(m, σ²C)`` and give the same ``ps``; only the noise-to-sample map
+                               differs by an orthogonal factor.
+        """
+        super().__init__()
+        self.center_init = torch.as_tensor(center_init, dtype=torch.float32)
+        if not init_stdev > 0:
+            raise ValueError("init_stdev must be positive")
+        self.init_stdev = float(init_stdev)
+        self.dim = self.center_init.shape[0]
+        self.cm = cm
+        self.precision = precision
+        self.eigh_method = eigh_method
+        if decomposition not in ("eigh", "newton_schulz"):
+            raise ValueError("decomposition must be 'eigh' or 'newton_schulz'")
+        self.decomposition = decomposition
+        self._ns = _cma.NewtonSchulzSqrt() if decomposition == "newton_schulz" else None
+        self.pop_size = 4 + math.floor(3 * math.log(self.dim)) if pop_size is None else int(pop_size)
+        dev = self.center_init.device
+        if recombination_weights is None:
+            self.mu = self.pop_size // 2
+            w = math.log(self.mu + 0.5) - torch.log(torch.arange(1, self.mu + 1, dtype=torch.float64))
+            w = w / w.sum()
+        else:
+            w = torch.as_tensor(recombination_weights, dtype=torch.float64).cpu()
+            if not bool((w[1:] <= w[:-1]).all()):
+                raise ValueError("recombination_weights must be non-increasing")
+            if abs(float(w.sum()) - 1) >= 1e-6:
+                raise ValueError("sum of recombination_weights must be 1")
+            if not bool((w > 0).all()):
+                raise ValueError("recombination_weights must be positive")
+            self.mu = w.shape[0]
+            if self.mu > self.pop_size:
+                raise ValueError("more recombination weights than individuals")
+        self.weights = w.to(torch.float32).to(dev)
+        n = float(self.dim)
+        self.mueff = float(w.sum() ** 2 / (w ** 2).sum())
+        self.cc = (4 + self.mueff / n) / (n + 4 + 2 * self.mueff / n)
+        self.cs = (2 + self.mueff) / (n + self.mueff + 5)
+        self.c1 = 2 / ((n + 1.3) ** 2 + self.mueff)
+        self.cmu = min(1 - self.c1, 2 * (self.mueff - 2 + 1 / self.mueff) / ((n + 2) ** 2 + self.mueff))
+        self.damps = 1 + 2 * max(0.0, math.sqrt((self.mueff - 1) / (n + 1)) - 1) + self.cs
+        self.chiN = n ** 0.5 * (1 - 1 / (4 * n) + 1 / (21 * n ** 2))
+        if decomp_per_iter is None:
+            decomp_per_iter = max(int(math.floor(1 / (self.c1 + self.cmu) / n / 10)), 1)
+        self.decomp_per_iter = int(decomp_per_iter)
+
+    # ------------------------------------------------------------------------------------
+    def setup(self, key):
+        dev = self.center_init.device
+        eye = torch.eye(self.dim, device=dev)
+        return State(
+            pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev), B=eye,
+            D=torch.ones(self.dim, device=dev), C=eye.clone(), count_eigen=0, count_iter=0, invsqrtC=eye.clone(),
+            mean=self.center_init, sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
+            population=torch.empty((self.pop_size, self.dim), device=dev))
+
+    def graph_signature(self, state):
+        """Host-side control flow of the next ``tell`` (which HIP graph variant applies)."""
+        return ((state.count_iter + 1) % self.decomp_per_iter == 0,)
+
+    def ask(self, state):
+        key, sample_key = rnd.split(state.key)
+        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, self.pop_size, self.precision)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+
+    # -- pieces of tell ------------------------------------------------------------------
+    def _paths(self, state, mean, order=None):
+        delta = mean - state.mean
+        z = self._whiten(state, delta) / state.sigma
+        ps = (1 - self.cs) * state.ps + math.sqrt(self.cs * (2 - self.cs) * self.mueff) * z
+        ps_norm = torch.linalg.vector_norm(ps)
+        denom = math.sqrt(1 - (1 - self.cs) ** (2 * state.count_iter))
+        hsig = (ps_norm / denom < (1.4 + 2 / (self.dim + 1)) * self.chiN).to(torch.float32)
+        pc = (1 - self.cc) * state.pc + hsig * math.sqrt(self.cc * (2 - self.cc) * self.mueff) * delta / state.sigma
+        sigma = state.sigma * torch.exp((self.cs / self.damps) * (ps_norm / self.chiN - 1))
+        return ps, pc, hsig, sigma
+
+    def _whiten(self, state, delta):
+        return state.invsqrtC @ delta
+
+    def tell(self, state, fitness):
+        order = _sort.argsort(fitness)
+        elite = state.population[order[: self.mu]]
+        mean = state.mean + self.cm * (self.weights @ (elite - state.mean))
+        ps, pc, hsig, sigma = self._paths(state, mean)
+        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+        C = _cma.covariance_update(state.C, state.population, order, state.mean, state.sigma, self.weights, pc,
+                                   alpha, self.c1, self.cmu, self.precision)
+        if state.count_iter % self.decomp_per_iter == 0:
+            if self._ns is not None:
+                B, invsqrtC = self._ns(C)
+                D = state.D
+            else:
+                B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
+            count_eigen = state.count_eigen + 1
+        else:
+            B, D, invsqrtC, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
+        return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=invsqrtC,
+                             count_eigen=count_eigen)
+
+
+class SepCMAES(CMAES):
+    """Separable CMA-ES: diagonal covariance, O(n) per individual, no eigendecomposition."""
+
+    def setup(self, key):
+        dev = self.center_init.device
+        return State(pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev),
+                     C=torch.ones(self.dim, device=dev), count_iter=0, mean=self.center_init,
+                     sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
+                     population=torch.empty((self.pop_size, self.dim), device=dev))
+
+    def graph_signature(self, state):
+        return ()
+
+    def ask(self, state):
+        key, sample_key = rnd.split(state.key)
+        noise = rnd.normal(sample_key, (self.pop_size, self.dim))
+        population = state.mean + state.sigma * torch.sqrt(state.C) * noise
+        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+
+    def _whiten(self, state, delta):
+        return delta / torch.sqrt(state.C)
+
+    def tell(self, state, fitness):
+        order = _sort.argsort(fitness)
+        elite = state.population[order[: self.mu]]
+        mean = state.mean + self.cm * (self.weights @ (elite - state.mean))
+        ps, pc, hsig, sigma = self._paths(state, mean)
+        y = (elite - state.mean) / state.sigma
+        C = ((1 - self.c1 - self.cmu) * state.C
+             + self.c1 * (pc * pc + (1 - hsig) * self.cc * (2 - self.cc) * state.C)
+             + self.cmu * (self.weights @ (y * y)))
+        return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma)
+
+
+class IPOPCMAES(CMAES):
+    """CMA-ES with restarts and increasing population (Auger & Hansen 2005).
+
+    A restart is triggered after ``stagnation_threshold`` generations without improvement of
+    the best fitness; the run is re-initialised around the initial mean with the population
+    multiplied by ``2**restarts``.  Because the population size changes, the restart decision
+    is taken on the host (one scalar read-back per generation) and the state tensors are
+    re-allocated.  (The reference's version never changes the population: its restart
+    bookkeeping lives in Python attributes, ``cma_es.py:256-354``.)"""
+
+    def __init__(self, center_init, init_stdev, pop_size=None, recombination_weights=None, cm=1,
+                 stagnation_threshold=50, **kwargs):
+        super().__init__(center_init, init_stdev, pop_size, recombination_weights, cm, **kwargs)
+        self._ctor = dict(center_init=center_init, init_stdev=init_stdev, recombination_weights=None, cm=cm, **kwargs)
+        self.original_pop_size = self.pop_size
+        self.stagnation_threshold = stagnation_threshold
+
+    def setup(self, key):
+        s = super().setup(key)
+        return s.replace(best_fitness=float("inf"), restarts=0, stagnation_count=0, pop_size=self.original_pop_size)
+
+    def _variant(self, pop_size) -> CMAES:
+        return CMAES(pop_size=pop_size, **self._ctor)
+
+    def ask(self, state):
+        if state.pop_size != self.pop_size:
+            return self._variant(state.pop_size).ask(state)
+        return super().ask(state)
+
+    def _next_pop_size(self, state, restarts):
+        return self.original_pop_size * (2 ** restarts)
+
+    def tell(self, state, fitness):
+        algo = self if state.pop_size == self.pop_size else self._variant(state.pop_size)
+        state = CMAES.tell(algo, state, fitness)
+        current = float(fitness.min())
+        if current < state.best_fitness:
+            return state.replace(best_fitness=current, stagnation_count=0)
+        stagnation = state.stagnation_count + 1
+        if stagnation < self.stagnation_threshold:
+            return state.replace(stagnation_count=stagnation)
+        restarts = state.restarts + 1
+        new_pop = self._next_pop_size(state, restarts)
+        key, sub = rnd.split(state.key)
+        fresh = self._variant(new_pop).setup(sub)
+        fields = {k: getattr(fresh, k) for k in fresh.keys()}
+        fields.update(key=key, best_fitness=state.best_fitness, restarts=restarts, stagnation_count=0,
+                      pop_size=new_pop)
+        return state.replace(**fields)
+
+
+class BIPOPCMAES(IPOPCMAES):
+    """Restart schedule alternating large and small populations: the population doubles per
+    restart until it exceeds 16× the original, then falls back to the original size
+    (regime rule of the reference, ``cma_es.py:357-388``)."""
+
+    def _next_pop_size(self, state, restarts):
+        if state.pop_size > 16 * self.original_pop_size:
+            return self.original_pop_size
+        return state.pop_size * 2

@@ -1,0 +1,41 @@
+"""Reference-vector-guided selection (Cheng et al. 2016, RVEA).  Behaviour of the reference's
+``src/evox/operators/selection/rvea_selection.py:8-54``: rows of the result that belong to a
+reference vector without associated solutions are NaN."""
+from __future__ import annotations
+
+import torch
+
+from ...utils.common import cos_dist
+
+
+def ref_vec_guided(x, f, v, theta):
+    n, m = f.shape
+    nv = v.shape[0]
+    fmin = torch.where(torch.isnan(f), torch.full_like(f, float("inf")), f).amin(0)
+    obj = (f - fmin).clamp_min(1e-32)
+    cosine = cos_dist(v, v)
+    cosine = cosine.masked_fill(torch.eye(nv, dtype=torch.bool, device=v.device), 0.0).clamp(0, 1)
+    gamma = torch.acos(cosine).amin(1)                                  # (nv,)
+    angle = torch.acos(cos_dist(obj, v).clamp(0, 1))                    # (n, nv)
+    nan_row = torch.isnan(obj).any(1)
+    angle_for_assoc = torch.where(torch.isnan(angle), torch.full_like(angle, float("inf")), angle)
+    associate = torch.argmin(angle_for_assoc, dim=1)
+    associate = torch.where(nan_row, torch.full_like(associate, -1), associate)
+    member = associate[:, None] == torch.arange(nv, device=f.device)[None, :]     # (n, nv)
+    norm = torch.sqrt((obj * obj).sum(1))                                          # (n,)
+    apd = (1 + m * theta * angle / gamma[None, :]) * norm[:, None]
+    apd = torch.where(member, apd, torch.full_like(apd, float("inf")))
+    apd = torch.where(torch.isnan(apd), torch.full_like(apd, float("inf")), apd)
+    next_ind = torch.argmin(apd, dim=0)                                            # (nv,)
+    empty = ~member.any(0)
+    nan = torch.tensor(float("nan"), device=f.device)
+    next_x = torch.where(empty[:, None], nan, x[next_ind])
+    next_f = torch.where(empty[:, None], nan, f[next_ind])
+    return next_x, next_f
+
+
+class ReferenceVectorGuided:
+    """Reference vector guided environmental selection."""
+
+    def __call__(self, x, f, v, theta):
+        return ref_vec_guided(x, f, v, theta)

@@ -1,0 +1,112 @@
+"""GEMM-shaped hot ops on the gfx950 matrix cores (kernels: ``csrc/mfma_gemm.hip``).
+
+``matmul_nt / matmul``      fp32 GEMM with exact-fp32 MFMA (plain library-style GEMM).
+``cma_sample``              X = mean + σ (Z∘d) Bᵀ with Z drawn inside the kernel.
+``cma_covariance_update``   C' = αC + c₁ pc pcᵀ + cμ Yᵀ diag(w) Y with Y gathered on the fly.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import _native
+from ..core import random as rnd
+from ._util import check, hip, stream_of
+
+P, I, I64, F = _native.P, _native.I, _native.I64, _native.F
+_native.register_hip_api({
+    "evox_hip_gemm_f32": (I, [P, P, P, P, I, I, I, I64, I64, I64, I64, I, I, F, F, P]),
+    "evox_hip_cma_sample": (I, [P, P, P, P, P, P, I, I, I64, P]),
+    "evox_hip_cma_cov": (I, [P, P, P, P, P, P, P, P, F, F, P, I, I, I64, P]),
+})
+
+
+def _impl() -> str:
+    return os.environ.get("EVOX_AMD_GEMM", "hip")
+
+
+def _layout(x: torch.Tensor):
+    """(tensor, leading dimension, k_major) for a 2-D operand used as rows × K.
+
+    A row-major contiguous (R, K) tensor is K-contiguous; its transpose view (strides (1, ld))
+    is k-major.  Anything else is made contiguous."""
+    if x.stride(1) == 1 and x.stride(0) >= x.shape[1]:
+        return x, x.stride(0), 0
+    if x.stride(0) == 1 and x.stride(1) >= x.shape[0]:
+        return x, x.stride(1), 1
+    x = x.contiguous()
+    return x, x.stride(0), 0
+
+
+def matmul_nt(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0, beta: float = 0.0, c0=None, out=None):
+    """``alpha * a @ b.T + beta * c0`` for fp32 ``a`` (M, K) and ``b`` (N, K) in any stride order."""
+    if a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise TypeError("matmul_nt expects fp32 operands")
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2:
+        raise ValueError(f"inner dimensions differ: {K} vs {K2}")
+    a, lda, ak = _layout(a)
+    b, ldb, bk = _layout(b)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    elif not out.is_contiguous() or tuple(out.shape) != (M, N):
+        raise ValueError("out must be a contiguous (M, N) tensor")
+    if c0 is not None:
+        c0 = c0.contiguous()
+        if tuple(c0.shape) != (M, N):
+            raise ValueError("c0 must have shape (M, N)")
+    check(hip().evox_hip_gemm_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), c0.data_ptr() if c0 is not None else None,
+                                  M, N, K, lda, ldb, N, N, ak, bk, float(alpha), float(beta), stream_of(a)), "gemm_f32")
+    return out
+
+
+def matmul(a: torch.Tensor, b: torch.Tensor, **kw):
+    """``a @ b`` (fp32, exact-fp32 MFMA)."""
+    return matmul_nt(a, b.T, **kw)
+
+
+def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0):
+    n = mean.shape[0]
+    if _impl() == "torch" or precision == "bf16":
+        z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
+        if precision == "bf16":
+            return mean + sigma * ((z * D).bfloat16() @ B.T.bfloat16()).float()
+        return mean + sigma * ((z * D) @ B.T)
+    if tuple(B.shape) != (n, n) or D.shape[0] != n:
+        raise ValueError("B must be (n, n) and D (n,)")
+    B = B.contiguous()
+    sigma = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
+    out = torch.empty((pop_size, n), dtype=torch.float32, device=mean.device)
+    check(hip().evox_hip_cma_sample(key.contiguous().data_ptr(), mean.contiguous().data_ptr(), sigma.data_ptr(),
+                                    B.data_ptr(), D.contiguous().data_ptr(), out.data_ptr(), pop_size, n,
+                                    int(row_offset), stream_of(mean)), "cma_sample")
+    return out
+
+
+def cma_covariance_update(C, pop, order, mean, sigma, weights, pc, alpha, c1, cmu, precision="fp32"):
+    n = C.shape[0]
+    mu = weights.shape[0]
+    if _impl() == "torch" or precision == "bf16":
+        y = (pop[order[:mu]] - mean) / sigma
+        if precision == "bf16":
+            g = ((y.T * weights).bfloat16() @ y.bfloat16()).float()
+        else:
+            g = (y.T * weights) @ y
+        return alpha * C + c1 * torch.outer(pc, pc) + cmu * g
+    if order.dtype != torch.int64:
+        order = order.to(torch.int64)
+    if order.shape[0] < mu:
+        raise ValueError("order is shorter than the number of recombination weights")
+    if pop.stride(1) != 1:
+        pop = pop.contiguous()
+    dev = C.device
+    sigma = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(1)
+    alpha = torch.as_tensor(alpha, dtype=torch.float32, device=dev).reshape(1)
+    out = torch.empty_like(C, memory_format=torch.contiguous_format)
+    check(hip().evox_hip_cma_cov(C.contiguous().data_ptr(), pop.data_ptr(), order.contiguous().data_ptr(),
+                                 mean.contiguous().data_ptr(), sigma.data_ptr(), weights.contiguous().data_ptr(),
+                                 pc.contiguous().data_ptr(), alpha.data_ptr(), float(c1), float(cmu), out.data_ptr(),
+                                 n, mu, pop.stride(0), stream_of(C)), "cma_cov")
+    return out

@@ -1,0 +1,121 @@
+"""Pareto ranking and crowding distance.
+
+Host path (also the oracle of the kernels): dominance matrix + front peeling in PyTorch.
+GPU path: ``csrc/nds.hip`` — matrix-free tiled dominance counting and per-front peeling
+(compacted index lists, counts in registers/LDS), segmented sorts for crowding distance.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _native
+from ._util import check, hip, on_gpu, stream_of
+
+
+def _has(symbol: str) -> bool:
+    try:
+        getattr(hip(), symbol)
+        return True
+    except AttributeError:
+        return False
+
+
+def non_dominated_rank_reference(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
+    n = x.shape[0]
+    xf = x.float()
+    a, b = xf[:, None, :], xf[None, :, :]
+    dom = (a <= b).all(-1) & (a < b).any(-1)                      # dom[i, j]: i dominates j
+    count = dom.sum(0).to(torch.int64)
+    rank = torch.zeros(n, dtype=torch.int64, device=x.device)
+    assigned = torch.zeros(n, dtype=torch.bool, device=x.device)
+    cur = 0
+    front = count == 0
+    domf = dom.to(torch.float32)
+    while bool(front.any()):
+        rank = torch.where(front, torch.full_like(rank, cur), rank)
+        assigned |= front
+        count = count - (front.to(torch.float32) @ domf).to(torch.int64) - front.to(torch.int64)
+        cur += 1
+        if until is not None and int(assigned.sum()) >= until:
+            rank = torch.where(assigned, rank, torch.full_like(rank, cur))
+            break
+        front = count == 0
+    else:
+        # rows that can never reach count 0 (NaN objectives): ranked last
+        rank = torch.where(assigned, rank, torch.full_like(rank, cur))
+    return rank
+
+
+def non_dominated_rank(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
+    if on_gpu(x) and _has("evox_hip_nds_count"):
+        from . import _nds_hip
+
+        return _nds_hip.rank(x, until)
+    n = x.shape[0]
+    if n > 8192 and not x.is_cuda:
+        return _blocked_reference(x, until)
+    return non_dominated_rank_reference(x, until)
+
+
+def _blocked_reference(x: torch.Tensor, until: Optional[int]) -> torch.Tensor:
+    """Same result as the reference without materialising n×n at once (row blocks)."""
+    n = x.shape[0]
+    xf = x.float()
+    blk = 2048
+    count = torch.zeros(n, dtype=torch.int64, device=x.device)
+    for s in range(0, n, blk):
+        a = xf[s:s + blk, None, :]
+        count += ((a <= xf[None]).all(-1) & (a < xf[None]).any(-1)).sum(0)
+    rank = torch.zeros(n, dtype=torch.int64, device=x.device)
+    assigned = torch.zeros(n, dtype=torch.bool, device=x.device)
+    cur = 0
+    front = count == 0
+    while bool(front.any()):
+        rank[front] = cur
+        assigned |= front
+        f = xf[front]
+        rem = ~assigned
+        if bool(rem.any()):
+            r = xf[rem]
+            dec = torch.zeros(r.shape[0], dtype=torch.int64, device=x.device)
+            for s in range(0, f.shape[0], blk):
+                a = f[s:s + blk, None, :]
+                dec += ((a <= r[None]).all(-1) & (a < r[None]).any(-1)).sum(0)
+            count[rem] -= dec
+        count[front] = -1
+        cur += 1
+        if until is not None and int(assigned.sum()) >= until:
+            break
+        front = (count == 0) & ~assigned
+    rank[~assigned] = cur
+    return rank
+
+
+def crowding_distance_reference(costs: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, m = costs.shape
+    dev = costs.device
+    if mask is None:
+        mask = torch.ones(n, dtype=torch.bool, device=dev)
+    nvalid = mask.sum()
+    c = costs.float()
+    # masked-out rows sort last in every objective
+    keyed = torch.where(mask[:, None], c, torch.full_like(c, float("inf")))
+    order = torch.argsort(keyed, dim=0, stable=True)                       # (n, m)
+    sorted_c = torch.gather(keyed, 0, order)
+    last = (nvalid - 1).clamp_min(0)
+    span = sorted_c[last] - sorted_c[0]                                    # (m,)
+    gaps = torch.zeros_like(sorted_c)
+    gaps[1:-1] = (sorted_c[2:] - sorted_c[:-2]) / span
+    pos = torch.arange(n, device=dev)[:, None]
+    gaps = torch.where((pos == 0) | (pos == last), torch.full_like(gaps, float("inf")), gaps)
+    dist_sorted = gaps
+    dist = torch.zeros_like(c)
+    dist.scatter_(0, order, dist_sorted)
+    total = dist.sum(1)
+    return torch.where(mask, total, torch.full_like(total, float("-inf")))
+
+
+def crowding_distance(costs: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return crowding_distance_reference(costs, mask)

@@ -1,0 +1,103 @@
+"""Numerics of the HIP kernels against plain PyTorch fp32/fp64 references (GPU box only)."""
+import math
+
+import pytest
+import torch
+
+from evox_amd.core import random as rnd
+from evox_amd.ops import cma, fitness, gemm, swarm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["sphere", "ackley", "rastrigin", "rosenbrock", "griewank", "schwefel"])
+@pytest.mark.parametrize("shape", [(1000, 1000), (333, 7), (64, 33), (5, 2), (4096, 130)])
+def test_fitness_kernels(cuda, name, shape):
+    x = (torch.rand(shape, device=cuda) * 2 - 1) * (500 if name == "schwefel" else 5)
+    got = getattr(fitness, name)(x)
+    ref = getattr(fitness, name + "_reference")(x.double().cpu()).float()
+    assert torch.allclose(got.cpu(), ref, rtol=2e-4, atol=2e-3), (got.cpu() - ref).abs().max()
+
+
+def test_fitness_bf16_and_strided(cuda):
+    x = torch.randn(257, 96, device=cuda)
+    got = fitness.sphere(x.bfloat16())
+    assert torch.allclose(got, fitness.sphere_reference(x.bfloat16()), rtol=1e-3)
+    wide = torch.randn(100, 64, device=cuda)
+    view = wide[:, :48]
+    assert torch.allclose(fitness.ackley(view), fitness.ackley_reference(view), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1000, 1000), (10000, 1000, 1000), (130, 70, 33), (64, 64, 2), (257, 1024, 515)])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_f32(cuda, M, N, K, ta, tb):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g)
+    b = torch.randn(N, K, generator=g)            # asymmetric operands: a swapped layout cannot pass
+    ref = (a.double() @ b.double().T).float()
+    ad = a.to(cuda).T.contiguous().T if ta else a.to(cuda)
+    bd = b.to(cuda).T.contiguous().T if tb else b.to(cuda)
+    got = gemm.matmul_nt(ad, bd)
+    err = (got.cpu() - ref).abs().max() / ref.abs().max()
+    assert err < 2e-6, err
+    c0 = torch.randn(M, N, device=cuda)
+    got2 = gemm.matmul_nt(ad, bd, alpha=0.5, beta=-2.0, c0=c0)
+    assert torch.allclose(got2.cpu(), 0.5 * ref - 2.0 * c0.cpu(), rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_identity_with_asymmetric_operand(cuda):
+    n = 96
+    b = torch.arange(n * n, dtype=torch.float32, device=cuda).reshape(n, n) % 97
+    eye = torch.eye(n, device=cuda)
+    assert torch.equal(gemm.matmul(eye, b), b)
+    assert torch.equal(gemm.matmul(b, eye), b)
+
+
+@pytest.mark.parametrize("lam,n", [(10000, 1000), (300, 64), (37, 10), (256, 129)])
+def test_cma_sample_matches_reference(cuda, lam, n):
+    key = rnd.PRNGKey(5).to(cuda)
+    q, _ = torch.linalg.qr(torch.randn(n, n, device=cuda))
+    d = torch.rand(n, device=cuda) + 0.5
+    mean = torch.randn(n, device=cuda)
+    sigma = torch.tensor(0.7, device=cuda)
+    got = gemm.cma_sample(key, mean, sigma, q, d, lam)
+    ref = cma.sample_reference(key.cpu(), mean.cpu().double(), 0.7, q.cpu().double(), d.cpu().double(), lam)
+    assert torch.allclose(got.cpu().double(), ref, rtol=1e-4, atol=2e-5), (got.cpu() - ref).abs().max()
+    # a window of rows equals the same rows of the full draw (row-sharded sampling)
+    part = gemm.cma_sample(key, mean, sigma, q, d, lam // 2 + 1, row_offset=lam // 4)
+    assert torch.allclose(part, got[lam // 4: lam // 4 + lam // 2 + 1], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("lam,n", [(10000, 1000), (200, 64), (50, 10), (600, 130)])
+def test_cma_covariance_update_matches_reference(cuda, lam, n):
+    mu = lam // 2
+    pop = torch.randn(lam, n, device=cuda) * 0.5 + 1.0
+    fit = torch.randn(lam, device=cuda)
+    order = torch.argsort(fit)
+    mean = torch.randn(n, device=cuda)
+    w = torch.rand(mu, device=cuda)
+    w = (w / w.sum()).sort(descending=True).values
+    pc = torch.randn(n, device=cuda)
+    a = torch.randn(n, n, device=cuda)
+    C = a @ a.T / n + torch.eye(n, device=cuda)
+    alpha = torch.tensor(0.93, device=cuda)
+    got = gemm.cma_covariance_update(C, pop, order, mean, torch.tensor(0.8, device=cuda), w, pc, alpha, 0.01, 0.05)
+    ref = cma.covariance_update_reference(C.double().cpu(), pop.double().cpu(), order.cpu(), mean.double().cpu(), 0.8,
+                                          w.double().cpu(), pc.double().cpu(), 0.93, 0.01, 0.05)
+    assert torch.allclose(got.cpu().double(), ref, rtol=1e-4, atol=1e-4), (got.cpu() - ref).abs().max()
+    assert torch.equal(got, got.T)
+
+
+def test_pso_step_matches_reference(cuda):
+    n, d = 333, 17
+    key = rnd.PRNGKey(1).to(cuda)
+    lb, ub = torch.full((d,), -3.0, device=cuda), torch.full((d,), 3.0, device=cuda)
+    pop, vel, pbest = (torch.randn(n, d, device=cuda) for _ in range(3))
+    fit, pfit = torch.rand(n, device=cuda), torch.rand(n, device=cuda)
+    gbest, gfit = torch.randn(d, device=cuda), torch.tensor([0.5], device=cuda)
+    for gf in (gfit, torch.tensor([-1.0], device=cuda)):
+        got = swarm.pso_step(key, pop, vel, fit, pbest, pfit, gbest, gf, lb, ub, 0.6, 2.5, 0.8)
+        ref = swarm.pso_step_reference(key.cpu(), pop.cpu(), vel.cpu(), fit.cpu(), pbest.cpu(), pfit.cpu(),
+                                       gbest.cpu(), gf.cpu(), lb.cpu(), ub.cpu(), 0.6, 2.5, 0.8)
+        for g, r in zip(got, ref):
+            assert torch.allclose(g.cpu(), r, rtol=1e-5, atol=1e-5)
