@@ -1,0 +1,241 @@
+"""Self-adaptive DE variants: JaDE, SHADE, SaDE, CoDE.
+
+Reference: ``de_variants/{jade,shade,sade,code}.py``.  The success-history statistics that the
+reference accumulates with O(N) sequential loops only ever enter order-independent sums, so
+they are single masked reductions here.
+"""
+from __future__ import annotations
+
+import torch
+
+from ....core import random as rnd
+from .base import ARITH, BEST, BIN, CURRENT, EXP, PBEST, RAND, DEBase
+
+
+def _nan_to(x, v=0.0):
+    return torch.where(torch.isnan(x), torch.full_like(x, v), x)
+
+
+class JaDE(DEBase):
+    """JADE (Zhang & Sanderson 2009) without archive: current-to-pbest/1/bin,
+    F ~ N(μF, 0.1), CR ~ Cauchy(μCR, 0.1), Lehmer / arithmetic mean adaptation."""
+
+    strict_improvement = False
+
+    def __init__(self, lb, ub, pop_size=100, diff_padding_num=9, differential_weight=None, cross_probability=None,
+                 c=0.1):
+        self._init_common(lb, ub, pop_size)
+        self.diff_padding_num = diff_padding_num
+        self.c = c
+        self.num_diff_vects = 1
+
+    def setup(self, key):
+        dev = self.lb.device
+        return self._base_state(key, F_u=torch.tensor(0.5, device=dev), CR_u=torch.tensor(0.5, device=dev),
+                                F_vect=torch.zeros(self.pop_size, device=dev),
+                                CR_vect=torch.zeros(self.pop_size, device=dev))
+
+    def _draw_params(self, state, kF, kCR, loc_F, loc_CR):
+        F = torch.clamp(rnd.normal(kF, (self.pop_size,)) * 0.1 + loc_F, 0.0, 1.0)
+        CR = torch.clamp(rnd.cauchy(kCR, (self.pop_size,)) * 0.1 + loc_CR, 0.0, 1.0)
+        return F, CR
+
+    def ask(self, state):
+        key, k_var, kF, kCR = rnd.split(state.key, 4)
+        F, CR = self._draw_params(state, kF, kCR, state.F_u, state.CR_u)
+        idx = self._window(state)
+        trial = self._strategy_trials(k_var, state, idx, CURRENT, PBEST, self.num_diff_vects, BIN, F, CR,
+                                      self.diff_padding_num)
+        return trial, state.replace(trial_vectors=trial, key=key, F_vect=F, CR_vect=CR)
+
+    def tell(self, state, trial_fitness):
+        population, fitness, best_index, start, ok, _ = self._select(state, state.trial_vectors, trial_fitness)
+        okf = ok.to(torch.float32)
+        n_ok = okf.sum()
+        sF, sF2 = (okf * state.F_vect).sum(), (okf * state.F_vect ** 2).sum()
+        lehmer = sF2 / sF
+        mean_cr = (okf * state.CR_vect).sum() / n_ok
+        # with no success the reference's nansum/nanmean give NaN and poison the means; keep
+        # the previous means instead
+        F_u = torch.where(n_ok > 0, (1 - self.c) * state.F_u + self.c * _nan_to(lehmer), state.F_u)
+        CR_u = torch.where(n_ok > 0, (1 - self.c) * state.CR_u + self.c * _nan_to(mean_cr), state.CR_u)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+                             F_u=F_u, CR_u=CR_u)
+
+
+class SHADE(JaDE):
+    """SHADE (Tanabe & Fukunaga 2013): JADE's variation with a success-history memory of
+    (F, CR) pairs updated by improvement-weighted means.  ``memory_size`` is the number of
+    history slots H (the reference fixes 100 slots while sampling indices below ``pop_size``,
+    ``shade.py:58,78,88``; here H is an explicit parameter)."""
+
+    strict_improvement = True
+
+    def __init__(self, lb, ub, pop_size=100, diff_padding_num=9, memory_size=100):
+        self._init_common(lb, ub, pop_size)
+        self.diff_padding_num = diff_padding_num
+        self.H = int(memory_size)
+        self.num_diff_vects = 1
+
+    def setup(self, key):
+        dev = self.lb.device
+        return self._base_state(key, Memory_FCR=torch.full((2, self.H), 0.5, device=dev),
+                                F_vect=torch.zeros(self.pop_size, device=dev),
+                                CR_vect=torch.zeros(self.pop_size, device=dev))
+
+    def ask(self, state):
+        key, k_var, k_slot, kF, kCR = rnd.split(state.key, 5)
+        slot = rnd.randint(k_slot, (self.pop_size,), 0, self.H)
+        F, CR = self._draw_params(state, kF, kCR, state.Memory_FCR[0, slot], state.Memory_FCR[1, slot])
+        idx = self._window(state)
+        trial = self._strategy_trials(k_var, state, idx, CURRENT, PBEST, self.num_diff_vects, BIN, F, CR,
+                                      self.diff_padding_num)
+        return trial, state.replace(trial_vectors=trial, key=key, F_vect=F, CR_vect=CR)
+
+    def tell(self, state, trial_fitness):
+        population, fitness, best_index, start, ok, parent_fit = self._select(state, state.trial_vectors, trial_fitness)
+        delta = torch.where(ok, parent_fit - trial_fitness, torch.zeros_like(trial_fitness))
+        delta = torch.where(torch.isfinite(delta), delta, torch.zeros_like(delta))
+        total = delta.sum()
+        w = delta / total
+        M_CR = (w * state.CR_vect).sum()
+        M_F = (w * state.F_vect ** 2).sum() / (w * state.F_vect).sum()
+        rolled = torch.roll(state.Memory_FCR, 1, dims=1)
+        rolled = torch.cat([torch.stack([M_F, M_CR])[:, None], rolled[:, 1:]], dim=1)
+        valid = (total > 0) & torch.isfinite(M_F) & torch.isfinite(M_CR)
+        memory = torch.where(valid, rolled, state.Memory_FCR)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+                             Memory_FCR=memory)
+
+    def migrate(self, state, foreign_population, foreign_fitness):
+        """Island-model hook: the immigrants replace the worst residents they improve on."""
+        k = foreign_fitness.shape[0]
+        worst = torch.topk(state.fitness, k, largest=True).indices
+        better = foreign_fitness < state.fitness[worst]
+        pop = state.population.index_copy(0, worst, torch.where(better[:, None], foreign_population,
+                                                                state.population[worst]))
+        fit = state.fitness.index_copy(0, worst, torch.where(better, foreign_fitness, state.fitness[worst]))
+        return state.replace(population=pop, fitness=fit, best_index=torch.argmin(fit))
+
+
+# strategy tables: (primary base, secondary base, #difference vectors, crossover)
+_RAND_1_BIN = (RAND, RAND, 1, BIN)
+_RAND2BEST_2_BIN = (RAND, BEST, 2, BIN)
+_RAND_2_BIN = (RAND, RAND, 2, BIN)
+_CURRENT2RAND_1 = (RAND, RAND, 1, ARITH)
+
+
+class SaDE(DEBase):
+    """SaDE (Qin, Huang & Suganthan 2009): four strategies chosen with probabilities learned
+    from success/failure counts over the last ``LP`` generations; CR per strategy drawn around
+    the median of its recent successful values; F ~ N(0.5, 0.3)."""
+
+    strict_improvement = False
+
+    def __init__(self, lb, ub, pop_size=100, diff_padding_num=9, LP=50):
+        self._init_common(lb, ub, pop_size)
+        self.diff_padding_num = diff_padding_num
+        self.LP = LP
+        self.strategy_pool = torch.tensor([_RAND_1_BIN, _RAND2BEST_2_BIN, _RAND_2_BIN, _CURRENT2RAND_1],
+                                          device=self.lb.device)
+
+    def setup(self, key):
+        dev = self.lb.device
+        return self._base_state(
+            key, success_memory=torch.zeros((self.LP, 4), device=dev), failure_memory=torch.zeros((self.LP, 4), device=dev),
+            CR_memory=torch.full((self.LP, 4), float("nan"), device=dev), CRs=torch.zeros(self.batch_size, device=dev),
+            strategy_ids=torch.zeros(self.batch_size, dtype=torch.int64, device=dev), iter=0)
+
+    def ask(self, state):
+        key, k_var, k_strat, k_cr, k_cr2, k_f = rnd.split(state.key, 6)
+        dev = self.lb.device
+        if state.iter >= self.LP:
+            s, f = state.success_memory.sum(0), state.failure_memory.sum(0)
+            rate = _nan_to(s / (s + f)) + 0.01
+            p = rate / rate.sum()
+        else:
+            p = torch.full((4,), 0.25, device=dev)
+        if state.iter > self.LP:
+            crm = _nan_to(torch.nanmedian(state.CR_memory, dim=0).values, 0.5)
+        else:
+            crm = torch.full((4,), 0.5, device=dev)
+        sid = rnd.choice(k_strat, 4, (self.batch_size,), p=p)
+        cr_all = rnd.normal(k_cr, (self.batch_size, 4)) * 0.1 + crm
+        cr_fix = rnd.normal(k_cr2, (self.batch_size, 4)) * 0.1 + crm
+        cr_all = torch.where((cr_all < 0) | (cr_all > 1), cr_fix, cr_all)
+        CR = cr_all[torch.arange(self.batch_size, device=dev), sid]
+        F = rnd.normal(k_f, (self.batch_size,)) * 0.3 + 0.5
+        code = self.strategy_pool[sid]
+        idx = self._window(state)
+        trial = self._strategy_trials(k_var, state, idx, code[:, 0], code[:, 1], code[:, 2], code[:, 3], F, CR,
+                                      self.diff_padding_num)
+        return trial, state.replace(trial_vectors=trial, key=key, CRs=CR, strategy_ids=sid, iter=state.iter + 1)
+
+    def tell(self, state, trial_fitness):
+        population, fitness, best_index, start, ok, _ = self._select(state, state.trial_vectors, trial_fitness)
+        onehot = torch.nn.functional.one_hot(state.strategy_ids, 4).to(torch.float32)
+        succ = (onehot * ok[:, None]).sum(0)
+        fail = (onehot * (~ok)[:, None]).sum(0)
+        success_memory = torch.cat([succ[None], state.success_memory[:-1]], dim=0)
+        failure_memory = torch.cat([fail[None], state.failure_memory[:-1]], dim=0)
+        # per strategy, push the successful CR values of this generation (most recent first)
+        # onto its column of the LP-deep memory
+        cols = []
+        for k in range(4):
+            sel = ok & (state.strategy_ids == k)
+            # stable compaction of the successful values, newest (highest index) first
+            order = torch.argsort(sel.to(torch.int64) * (torch.arange(sel.shape[0], device=sel.device) + 1),
+                                  descending=True)
+            vals = torch.where(sel[order], state.CRs[order], torch.full_like(state.CRs, float("nan")))[: self.LP]
+            cnt = sel.sum().clamp(max=self.LP)
+            old = state.CR_memory[:, k]
+            pos = torch.arange(self.LP, device=sel.device)
+            shifted = old[(pos - cnt).clamp_min(0)]
+            pad = torch.full((self.LP,), float("nan"), device=sel.device)
+            pad[: vals.shape[0]] = vals
+            cols.append(torch.where(pos < cnt, pad, shifted))
+        CR_memory = torch.stack(cols, dim=1)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+                             success_memory=success_memory, failure_memory=failure_memory, CR_memory=CR_memory)
+
+
+class CoDE(DEBase):
+    """CoDE (Wang, Cai & Zhang 2011): every individual gets three trial vectors (rand/1/bin,
+    rand/2/bin, current-to-rand/1), each with control parameters drawn from a small pool; the
+    best of the three competes with the parent."""
+
+    strict_improvement = False
+
+    def __init__(self, lb, ub, pop_size=100, batch_size=None, diff_padding_num=5, param_pool=None, replace=False):
+        self._init_common(lb, ub, pop_size, batch_size)
+        pool = [[1, 0.1], [1, 0.9], [0.8, 0.2]] if param_pool is None else param_pool
+        self.param_pool = torch.as_tensor(pool, dtype=torch.float32).to(self.lb.device)
+        self.diff_padding_num = diff_padding_num
+        self.strategies = (_RAND_1_BIN, _RAND_2_BIN, _CURRENT2RAND_1)
+        self.replace = replace
+
+    def setup(self, key):
+        return self._base_state(key, trial_rows=3 * self.batch_size)
+
+    def ask(self, state):
+        key, k_var, k_par = rnd.split(state.key, 3)
+        idx = self._window(state)
+        keys = rnd.split(k_var, 3)
+        pid = rnd.randint(k_par, (3, self.batch_size), 0, self.param_pool.shape[0])
+        trials = []
+        for s, (prim, sec, nd, cross) in enumerate(self.strategies):
+            par = self.param_pool[pid[s]]
+            trials.append(self._strategy_trials(keys[s], state, idx, prim, sec, nd, cross, par[:, 0], par[:, 1],
+                                                self.diff_padding_num, self.replace))
+        trial = torch.cat(trials, dim=0)
+        return trial, state.replace(trial_vectors=trial, key=key)
+
+    def tell(self, state, trial_fitness):
+        b = self.batch_size
+        fit3 = trial_fitness.reshape(3, b)
+        which = torch.argmin(fit3, dim=0)
+        cols = torch.arange(b, device=fit3.device)
+        best_fit = fit3[which, cols]
+        best_vec = state.trial_vectors.reshape(3, b, self.dim)[which, cols]
+        population, fitness, best_index, start, _, _ = self._select(state, best_vec, best_fit)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start)

@@ -1,0 +1,139 @@
+"""Shared machinery of the differential-evolution family.
+
+All variants keep the steady-state batch layout of the reference (``population, fitness,
+best_index, start_index, key, trial_vectors``; a window of ``batch_size`` individuals is varied
+per generation and slides over the population) and the greedy compare-and-replace ``tell``
+(reference: ``src/evox/algorithms/so/de_variants/de.py:137-166``).  Variation is batched: one
+call builds the trial vectors of the whole window.
+"""
+from __future__ import annotations
+
+import torch
+
+from ....core import random as rnd
+from ....core.algorithm import Algorithm
+from ....core.state import State
+
+# base-vector codes of the strategy tables (rand, best, pbest, current) and crossover codes
+RAND, BEST, PBEST, CURRENT = 0, 1, 2, 3
+BIN, EXP, ARITH = 0, 1, 2
+
+
+class DEBase(Algorithm):
+    strict_improvement = True       # replace when trial < parent (else <=)
+
+    def _init_common(self, lb, ub, pop_size, batch_size=None):
+        super().__init__()
+        self.lb = torch.as_tensor(lb, dtype=torch.float32)
+        self.ub = torch.as_tensor(ub, dtype=torch.float32).to(self.lb.device)
+        if not bool((self.lb < self.ub).all()):
+            raise ValueError("lb must be below ub in every dimension")
+        self.dim = self.lb.shape[0]
+        self.pop_size = int(pop_size)
+        self.batch_size = int(batch_size) if batch_size else self.pop_size
+
+    def _init_population(self, key, mean=None, stdvar=None):
+        dev = self.lb.device
+        if mean is not None and stdvar is not None:
+            pop = torch.clamp(stdvar * rnd.normal(key, (self.pop_size, self.dim)) + mean, self.lb, self.ub)
+        else:
+            pop = rnd.uniform(key, (self.pop_size, self.dim)) * (self.ub - self.lb) + self.lb
+        return pop, torch.full((self.pop_size,), float("inf"), device=dev)
+
+    def _base_state(self, key, trial_rows=None, **extra):
+        dev = self.lb.device
+        state_key, init_key = rnd.split(key.to(dev))
+        pop, fit = self._init_population(init_key, getattr(self, "mean", None), getattr(self, "stdvar", None))
+        return State(population=pop, fitness=fit, best_index=torch.zeros((), dtype=torch.int64, device=dev),
+                     start_index=0, key=state_key,
+                     trial_vectors=torch.zeros((trial_rows or self.batch_size, self.dim), device=dev), **extra)
+
+    def _window(self, state):
+        s = state.start_index
+        idx = torch.arange(s, s + self.batch_size, device=self.lb.device)
+        return idx % self.pop_size if s + self.batch_size > self.pop_size else idx
+
+    def _select(self, state, trial_vectors, trial_fitness):
+        """Greedy replacement inside the window; returns (population, fitness, best_index,
+        next start_index, success mask, parent fitness)."""
+        idx = self._window(state)
+        parent_fit = state.fitness[idx]
+        better = trial_fitness < parent_fit if self.strict_improvement else trial_fitness <= parent_fit
+        new_rows = torch.where(better[:, None], trial_vectors, state.population[idx])
+        new_fit = torch.where(better, trial_fitness, parent_fit)
+        if self.batch_size == self.pop_size and state.start_index == 0:
+            population, fitness = new_rows, new_fit
+        else:
+            population = state.population.index_copy(0, idx, new_rows)
+            fitness = state.fitness.index_copy(0, idx, new_fit)
+        best_index = torch.argmin(fitness)
+        start = (state.start_index + self.batch_size) % self.pop_size
+        return population, fitness, best_index, start, better, parent_fit
+
+    def tell(self, state, trial_fitness):
+        population, fitness, best_index, start, _, _ = self._select(state, state.trial_vectors, trial_fitness)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start)
+
+    # -- batched strategy evaluation -----------------------------------------------------
+    def _strategy_trials(self, key, state, idx, prim, sec, num_diff, cross, F, CR, diff_padding_num, replace=False):
+        """Trial vectors for window ``idx``.  ``prim``/``sec`` (base-vector codes), ``num_diff``
+        and ``cross`` may be ints or per-row tensors; ``F``/``CR`` scalars or per-row tensors::
+
+            base  = prim + F (sec − prim)
+            v     = base + F Σ± differences
+            trial = crossover(v, current; CR)   clipped to the bounds
+        """
+        from ....operators.crossover.differential_evolution import de_arith_recom, de_bin_cross, de_exp_cross
+        from ....operators.selection.misc import select_rand_pbest
+
+        pop, fit = state.population, state.fitness
+        b = idx.shape[0]
+        dev = pop.device
+        k_sel, k_pb, k_x = rnd.split(key, 3)
+        if replace:
+            picks = rnd.randint(k_sel, (b, diff_padding_num), 0, self.pop_size)
+            picks = torch.where(picks == idx[:, None], torch.full_like(picks, self.pop_size - 1), picks)
+        else:
+            picks = rnd.choice_distinct(k_sel, self.pop_size, b, diff_padding_num, exclude=idx)
+        nd = torch.as_tensor(num_diff, device=dev).reshape(-1, 1)
+        pos = torch.arange(diff_padding_num, device=dev)[None, :]
+        live = (pos >= 1) & (pos < 2 * nd + 1)
+        sign = (torch.where(pos % 2 == 1, 1.0, -1.0) * live).to(pop.dtype)
+        diff = torch.einsum("bk,bkd->bd", sign.expand(b, -1), pop[picks])
+        current = pop[idx]
+
+        def base_of(code):
+            code_t = torch.as_tensor(code, device=dev)
+            if code_t.dim() == 0:
+                c = int(code_t)
+                if c == RAND:
+                    return pop[picks[:, 0]]
+                if c == BEST:
+                    return pop[state.best_index].expand(b, -1)
+                if c == PBEST:
+                    return select_rand_pbest(k_pb, 0.05, pop, fit, num=b)
+                return current
+            cands = torch.stack([pop[picks[:, 0]], pop[state.best_index].expand(b, -1),
+                                 select_rand_pbest(k_pb, 0.05, pop, fit, num=b), current], dim=1)
+            return cands[torch.arange(b, device=dev), code_t]
+
+        Fc = torch.as_tensor(F, device=dev, dtype=pop.dtype)
+        Fc = Fc[:, None] if Fc.dim() == 1 else Fc
+        p, s = base_of(prim), base_of(sec)
+        mutant = p + Fc * (s - p) + Fc * diff
+        cross_t = torch.as_tensor(cross, device=dev)
+        if cross_t.dim() == 0:
+            c = int(cross_t)
+            if c == BIN:
+                trial = de_bin_cross(k_x, mutant, current, CR)
+            elif c == EXP:
+                trial = de_exp_cross(k_x, mutant, current, CR)
+            else:
+                trial = de_arith_recom(mutant, current, CR)
+        else:
+            kb, ke = rnd.split(k_x)
+            t_bin = de_bin_cross(kb, mutant, current, CR)
+            t_exp = de_exp_cross(ke, mutant, current, CR)
+            t_ari = de_arith_recom(mutant, current, CR)
+            trial = torch.where((cross_t == BIN)[:, None], t_bin, torch.where((cross_t == EXP)[:, None], t_exp, t_ari))
+        return torch.clamp(trial, self.lb, self.ub)

@@ -243,3 +243,29 @@ def categorical(key: torch.Tensor, logits: torch.Tensor, shape: Shape = ()) -> t
     full = shape + tuple(logits.shape)
     g = -torch.log(exponential(key, full).clamp_min(1e-38))
     return torch.argmax(logits + g, dim=-1)
+
+
+def choice_distinct(key: torch.Tensor, n: int, batch: int, k: int, exclude: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``(batch, k)`` indices in ``[0, n)``, distinct within each row and (optionally) different
+    from ``exclude[row]`` — exact uniform sampling without replacement in O(batch · k²), for the
+    small ``k`` of DE-style parent selection (a permutation per row would cost O(batch · n))."""
+    k0 = _single(key)
+    taken = 0 if exclude is None else 1
+    if k + taken > n:
+        raise ValueError("not enough distinct individuals")
+    # j-th pick: uniform over the n - taken - j remaining values, then shifted past the
+    # already taken values in ascending order
+    u = bits(k0, (batch, k))
+    dev = k0.device
+    picks = []
+    base = [] if exclude is None else [exclude.to(dev).reshape(batch).to(torch.int64)]
+    for j in range(k):
+        m = n - taken - j
+        r = (u[:, j] * m) >> 32                      # multiply-shift: uniform in [0, m)
+        prev = base + picks
+        if prev:
+            srt = torch.sort(torch.stack(prev, dim=1), dim=1).values
+            for c in range(srt.shape[1]):
+                r = r + (r >= srt[:, c]).to(torch.int64)
+        picks.append(r)
+    return torch.stack(picks, dim=1)

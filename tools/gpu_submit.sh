@@ -4,11 +4,11 @@
 # again.  Output of the client goes to /tmp/gpurun_<tag>.out
 tag=$1; limit=$2; shift 2
 out=/tmp/gpurun_${tag}.out
-for attempt in 1 2 3 4 5 6 7 8 9 10 11 12; do
+for attempt in $(seq 1 80); do
   /usr/local/graft/bin/gpurun --timeout "$limit" -- "$@" > "$out" 2>&1
   rc=$?
   if [ $rc -ne 3 ]; then echo "done rc=$rc" >> "$out"; exit $rc; fi
-  sleep 60
+  sleep 100
 done
 echo "gave up: no box" >> "$out"
 exit 3
