@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--eigh", default=None, help="eigensolver override: jacobi | solver")
+    ap.add_argument("--decomp", default="eigh", choices=["eigh", "newton_schulz"],
+                    help="how C^(1/2), C^(-1/2) are obtained each generation")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
     args = ap.parse_args()
 
@@ -56,7 +58,7 @@ def main():
     key = ex.PRNGKey(20240611)
     center = ex.random.uniform(ex.random.fold_in(key, 1), (args.dim,), minval=-5.0, maxval=5.0).to(dev)
     algo = algorithms.CMAES(center_init=center, init_stdev=1.0, pop_size=total_pop, precision=args.precision,
-                            eigh_method=args.eigh)
+                            eigh_method=args.eigh, decomposition=args.decomp)
     problem = problems.numerical.Ackley() if args.problem == "ackley" else problems.numerical.Sphere()
     if world > 1:
         from evox_amd.workflows import ShardedWorkflow
@@ -104,7 +106,7 @@ def main():
             "config": {"model": f"CMA-ES dim={args.dim} on {args.problem}", "global_batch": total_pop,
                        "pop_per_gpu": total_pop // world, "seq_len": args.dim,
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated eigh)",
-                       "decomp_per_iter": algo.decomp_per_iter, "mu": algo.mu, "graph": bool(args.graph)},
+                       "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph)},
             "sigma_end": sigma,
         }
         print(json.dumps(out), flush=True)

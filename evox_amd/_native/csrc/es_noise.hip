@@ -1,0 +1,75 @@
+// Weighted reductions over regenerated Gaussian noise:
+//     g[j]  = sum_i w[i] * z(i, j)                 (ES gradient estimate)
+//     h[j]  = sum_i v[i] * (z(i, j)^2 - 1)         (variance gradient of PGPE / SNES; optional)
+// z(i, j) is element (row_offset + i) * dim + j of the Philox normal stream of `key`, i.e. the
+// value the sampling step produced; nothing is read from memory except the two weight vectors.
+// One thread owns four consecutive columns (one counter block when dim % 4 == 0) and walks a
+// slice of the rows; blockIdx.y selects the slice, partial sums go to slab[slice][dim].
+#include "hip_common.h"
+#include "philox.h"
+
+using namespace evox;
+
+namespace {
+
+template <bool WITH_V>
+__global__ __launch_bounds__(256) void noise_wsum_kernel(const int32_t* __restrict__ key, const float* __restrict__ w,
+                                                         const float* __restrict__ v, float* __restrict__ gslab,
+                                                         float* __restrict__ hslab, int64_t n, int64_t dim,
+                                                         int64_t row_offset, int splits) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // column quad
+  const int64_t c0 = q * 4;
+  if (c0 >= dim) return;
+  const int64_t rows_per = (n + splits - 1) / splits;
+  const int64_t rbeg = (int64_t)blockIdx.y * rows_per;
+  const int64_t rend = min(n, rbeg + rows_per);
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, h[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool aligned = (dim & 3) == 0;
+  for (int64_t i = rbeg; i < rend; ++i) {
+    const float wi = w[i];
+    const float vi = WITH_V ? v[i] : 0.f;
+    const uint64_t e = (uint64_t)(row_offset + i) * (uint64_t)dim + (uint64_t)c0;
+    float z[4];
+    const f32x4 a = normal4(philox_block(k0, k1, e >> 2, kStreamDraw));
+    if (aligned) {
+      z[0] = a.x; z[1] = a.y; z[2] = a.z; z[3] = a.w;
+    } else {
+      const int sh = (int)(e & 3);
+      const f32x4 b = normal4(philox_block(k0, k1, (e >> 2) + 1, kStreamDraw));
+#pragma unroll
+      for (int l = 0; l < 4; ++l) z[l] = (l + sh < 4) ? lane_of(a, l + sh) : lane_of(b, l + sh - 4);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      g[l] = fmaf(wi, z[l], g[l]);
+      if (WITH_V) h[l] = fmaf(vi, fmaf(z[l], z[l], -1.0f), h[l]);
+    }
+  }
+  float* go = gslab + (int64_t)blockIdx.y * dim + c0;
+#pragma unroll
+  for (int l = 0; l < 4; ++l)
+    if (c0 + l < dim) go[l] = g[l];
+  if (WITH_V) {
+    float* ho = hslab + (int64_t)blockIdx.y * dim + c0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (c0 + l < dim) ho[l] = h[l];
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_noise_wsum(const int32_t* key, const float* w, const float* v, float* gslab, float* hslab,
+                                 void* reserved, int64_t n, int64_t dim, int64_t row_offset, int64_t splits, int flags,
+                                 void* stream) {
+  (void)reserved; (void)flags;
+  if (n <= 0 || dim <= 0) return 0;
+  const int64_t quads = (dim + 3) / 4;
+  dim3 grid((unsigned)((quads + 255) / 256), (unsigned)splits);
+  if (v != nullptr)
+    noise_wsum_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(key, w, v, gslab, hslab, n, dim, row_offset, (int)splits);
+  else
+    noise_wsum_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(key, w, v, gslab, hslab, n, dim, row_offset, (int)splits);
+  return last_launch_status();
+}

@@ -120,6 +120,7 @@ struct PhiloxNormalTimesD {
   const float* __restrict__ d;
   int64_t row_offset;
   int rows, kdim;
+  int pitch;   // columns of the logical noise tensor (kdim may be cut by split-K)
   struct Regs { float4 v[NV]; };
   __device__ __forceinline__ void fetch(int r0, int k0, Regs& g) const {
 #pragma unroll
@@ -128,7 +129,7 @@ struct PhiloxNormalTimesD {
       const int r = r0 + (f >> 2), k = k0 + 4 * (f & 3);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < rows && k < kdim) {
-        const uint64_t e = (uint64_t)(row_offset + r) * (uint64_t)kdim + (uint64_t)k;
+        const uint64_t e = (uint64_t)(row_offset + r) * (uint64_t)pitch + (uint64_t)k;
         const int sh = (int)(e & 3);
         const f32x4 a = normal4(philox_block(k0key, k1key, e >> 2, kStreamDraw));
         float z[4];
@@ -218,7 +219,7 @@ struct EpiAxpby {
   const float* __restrict__ c0;
   int64_t ldc, ldc0;
   float alpha, beta;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
+  __device__ __forceinline__ void operator()(int row, int col, float acc, int) const {
     float v = alpha * acc;
     if (c0 != nullptr) v = fmaf(beta, c0[(int64_t)row * ldc0 + col], v);
     c[(int64_t)row * ldc + col] = v;
@@ -230,7 +231,7 @@ struct EpiSample {
   const float* __restrict__ mean;
   const float* __restrict__ sigma;
   int64_t ldo;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
+  __device__ __forceinline__ void operator()(int row, int col, float acc, int) const {
     out[(int64_t)row * ldo + col] = fmaf(sigma[0], acc, mean[col]);
   }
 };
@@ -242,9 +243,18 @@ struct EpiCov {
   const float* __restrict__ alpha;   // device scalar
   float c1, cmu;
   int64_t ld;
-  __device__ __forceinline__ void operator()(int row, int col, float acc) const {
-    const float v = fmaf(alpha[0], c[(int64_t)row * ld + col], fmaf(c1 * pc[row], pc[col], cmu * acc));
+  __device__ __forceinline__ void operator()(int row, int col, float acc, int) const {
+    const float v = fmaf(alpha[0], c[(int64_t)row * ld + col], fmaf(c1, pc[row] * pc[col], cmu * acc));
     out[(int64_t)row * ld + col] = v;
+  }
+};
+
+// split-K partial result: slab `split` of a [splits][n][ld] workspace
+struct EpiSlab {
+  float* __restrict__ ws;
+  int64_t ld, slab;
+  __device__ __forceinline__ void operator()(int row, int col, float acc, int split) const {
+    ws[split * slab + (int64_t)row * ld + col] = acc;
   }
 };
 
@@ -282,9 +292,15 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(PA pa, PB pb, Epi epi, int
 
   typename PA::Regs ra;
   typename PB::Regs rb;
-  const int nk = (K + BK - 1) / BK;
-  pa.fetch(m0, 0, ra);
-  pb.fetch(n0, 0, rb);
+  // split-K: gridDim.y slices of the K range, each a multiple of BK long
+  const int kchunk = ((K + (int)gridDim.y - 1) / (int)gridDim.y + BK - 1) / BK * BK;
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+  pa.kdim = kend;
+  pb.kdim = kend;
+  pa.fetch(m0, kbeg, ra);
+  pb.fetch(n0, kbeg, rb);
   pa.template store<LDA>(ra, As);
   pb.template store<LDB>(rb, Bs);
   __syncthreads();
@@ -293,8 +309,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(PA pa, PB pb, Epi epi, int
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      pa.fetch(m0, (kt + 1) * BK, ra);
-      pb.fetch(n0, (kt + 1) * BK, rb);
+      pa.fetch(m0, kbeg + (kt + 1) * BK, ra);
+      pb.fetch(n0, kbeg + (kt + 1) * BK, rb);
     }
     const float* a = As + cur * BK * LDA + wm + l31;
     const float* b = Bs + cur * BK * LDB + wn + l31;
@@ -328,17 +344,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(PA pa, PB pb, Epi epi, int
         const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         const int col = n0 + wn + 32 * j + l31;
         if (row < M && col < N) {
-          epi(row, col, acc[i][j][r]);
-          if (UPPER_ONLY && tm != tn) epi(col, row, acc[i][j][r]);
+          epi(row, col, acc[i][j][r], (int)blockIdx.y);
+          if (UPPER_ONLY && tm != tn) epi(col, row, acc[i][j][r], (int)blockIdx.y);
         }
       }
 }
 
 template <int BM, int BN, class PA, class PB, class Epi, bool UPPER_ONLY = false>
-int launch(PA pa, PB pb, Epi epi, int M, int N, int K, hipStream_t st) {
+int launch(PA pa, PB pb, Epi epi, int M, int N, int K, hipStream_t st, int splits = 1) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  gemm_f32_kernel<BM, BN, PA, PB, Epi, UPPER_ONLY><<<tiles_m * tiles_n, NT, 0, st>>>(pa, pb, epi, M, N, K, tiles_m,
-                                                                                    tiles_n);
+  gemm_f32_kernel<BM, BN, PA, PB, Epi, UPPER_ONLY><<<dim3(tiles_m * tiles_n, splits), NT, 0, st>>>(
+      pa, pb, epi, M, N, K, tiles_m, tiles_n);
   return last_launch_status();
 }
 
@@ -382,15 +398,15 @@ struct PhiloxNormalTimesDPtr {
   const int32_t* __restrict__ key;
   const float* __restrict__ d;
   int64_t row_offset;
-  int rows, kdim;
+  int rows, kdim, pitch;
   using Regs = typename PhiloxNormalTimesD<R>::Regs;
   __device__ __forceinline__ void fetch(int r0, int k0, Regs& g) const {
-    PhiloxNormalTimesD<R> p{(uint32_t)key[0], (uint32_t)key[1], d, row_offset, rows, kdim};
+    PhiloxNormalTimesD<R> p{(uint32_t)key[0], (uint32_t)key[1], d, row_offset, rows, kdim, pitch};
     p.fetch(r0, k0, g);
   }
   template <int LD>
   __device__ __forceinline__ void store(const Regs& g, float* lds) const {
-    PhiloxNormalTimesD<R> p{0u, 0u, d, row_offset, rows, kdim};
+    PhiloxNormalTimesD<R> p{0u, 0u, d, row_offset, rows, kdim, pitch};
     p.template store<LD>(g, lds);
   }
 };
@@ -404,19 +420,46 @@ EVOX_API int evox_hip_cma_sample(const int32_t* key, const float* mean, const fl
   EpiSample epi{out, mean, sigma, (int64_t)n};
   const int64_t big_tiles = (int64_t)((lam + 127) / 128) * ((n + 127) / 128);
   if (big_tiles >= 192)
-    return launch<128, 128>(PhiloxNormalTimesDPtr<128>{key, d, row_offset, lam, n}, RowMajorK<128>{Bm, n, n, n, vb},
+    return launch<128, 128>(PhiloxNormalTimesDPtr<128>{key, d, row_offset, lam, n, n}, RowMajorK<128>{Bm, n, n, n, vb},
                             epi, lam, n, n, st);
-  return launch<64, 64>(PhiloxNormalTimesDPtr<64>{key, d, row_offset, lam, n}, RowMajorK<64>{Bm, n, n, n, vb}, epi,
+  return launch<64, 64>(PhiloxNormalTimesDPtr<64>{key, d, row_offset, lam, n, n}, RowMajorK<64>{Bm, n, n, n, vb}, epi,
                         lam, n, n, st);
 }
 
-// out = alpha * C + c1 * pc pc^T + cmu * sum_k w_k y_k y_k^T, y_k = (pop[order[k]] - mean) / sigma
+namespace {
+// out = alpha C + c1 pc pc^T + cmu * sum_s slab_s  (the second half of the split-K rank-mu update)
+__global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ C,
+                                                         const float* __restrict__ pc, const float* __restrict__ alpha,
+                                                         float c1, float cmu, float* __restrict__ out, int n) {
+  const int64_t total = (int64_t)n * n;
+  const float a = alpha[0];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(e / n), col = (int)(e - (int64_t)row * n);
+    float g = 0.f;
+    for (int s = 0; s < splits; ++s) g += ws[(int64_t)s * total + e];
+    out[e] = fmaf(a, C[e], fmaf(c1, pc[row] * pc[col], cmu * g));
+  }
+}
+}  // namespace
+
+// out = alpha * C + c1 * pc pc^T + cmu * sum_k w_k y_k y_k^T, y_k = (pop[order[k]] - mean) / sigma.
+// ws: workspace of splits * n * n floats (splits > 1 spreads the K = mu reduction over more
+// workgroups than the 64 x 64 upper-triangular tiles alone provide; the partial slabs are summed
+// in a fixed order, so the result does not depend on scheduling).
 EVOX_API int evox_hip_cma_cov(const float* C, const float* pop, const int64_t* order, const float* mean,
                               const float* sigma, const float* w, const float* pc, const float* alpha, float c1,
-                              float cmu, float* out, int n, int mu, int64_t ldpop, void* stream) {
+                              float cmu, float* out, int n, int mu, int64_t ldpop, float* ws, int splits,
+                              void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool v = aligned16(pop) && aligned16(mean) && (ldpop % 4 == 0);
-  EpiCov epi{out, C, pc, alpha, c1, cmu, (int64_t)n};
   GatherCentered<64> pa{pop, order, mean, w, sigma, ldpop, n, mu, v};
-  return launch<64, 64, GatherCentered<64>, GatherCentered<64>, EpiCov, true>(pa, pa, epi, n, n, mu, st);
+  if (splits <= 1 || ws == nullptr) {
+    EpiCov epi{out, C, pc, alpha, c1, cmu, (int64_t)n};
+    return launch<64, 64, GatherCentered<64>, GatherCentered<64>, EpiCov, true>(pa, pa, epi, n, n, mu, st);
+  }
+  EpiSlab epi{ws, (int64_t)n, (int64_t)n * n};
+  int rc = launch<64, 64, GatherCentered<64>, GatherCentered<64>, EpiSlab, true>(pa, pa, epi, n, n, mu, st, splits);
+  if (rc) return rc;
+  cov_reduce_kernel<<<stream_grid((int64_t)n * n, 256), 256, 0, st>>>(ws, splits, C, pc, alpha, c1, cmu, out, n);
+  return last_launch_status();
 }

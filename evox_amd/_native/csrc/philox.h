@@ -139,12 +139,19 @@ EVOX_HD void det_sincos2pi(float u, float* s, float* c) {
   *s = rs; *c = rc;
 }
 
+// sqrt for x in [0, ~40] from fused multiply-adds only: the hardware / libm square roots of the
+// two sides do not round identically, a fixed fma sequence does.  Bit-trick seed for 1/sqrt(x),
+// three Newton steps, then one residual correction of s = x * r (accurate to <= 1 ulp).
 EVOX_HD float det_sqrtf(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(x);
-#else
-  return sqrtf(x);
-#endif
+  float r = u2f(0x5f3759dfu - (f2u(x) >> 1));
+  const float hx = 0.5f * x;
+  r = r * fmaf(-hx * r, r, 1.5f);
+  r = r * fmaf(-hx * r, r, 1.5f);
+  r = r * fmaf(-hx * r, r, 1.5f);
+  float s = x * r;
+  const float e = fmaf(-s, s, x);
+  s = fmaf(e, 0.5f * r, s);
+  return s;
 }
 
 EVOX_HD f32x4 unit4(u32x4 b) {

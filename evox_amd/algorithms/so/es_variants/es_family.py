@@ -1,0 +1,552 @@
+"""Gradient-estimating evolution strategies: OpenES, PGPE, ARS, DES, ESMC, SNES, SeparableNES,
+XNES, GuidedES, ASEBO, Noise_reuse_es, PersistentES.
+
+Reference behaviour: ``src/evox/algorithms/so/es_variants/{open_es,pgpe,ars,des,esmc,snes,nes,
+guided_es,asebo,noise_reuse_es,persistent_es}.py``.  Design difference: the isotropic variants do
+not keep the ``(pop, dim)`` noise tensor in their state.  ``ask`` stores only the key the noise
+was drawn from and ``tell`` *regenerates* the rows inside the reduction that consumes them
+(``evox_amd.ops.es``), so memory per algorithm copy is O(dim) instead of O(pop · dim).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Union
+
+import torch
+
+from ....core import random as rnd
+from ....core.algorithm import Algorithm
+from ....core.module import Stateful, use_state
+from ....core.state import State
+from ....ops import es as _es
+from ....utils import optimizers as optim
+
+
+def _make_optimizer(name_or_obj, lr, params):
+    if isinstance(name_or_obj, Stateful):
+        return name_or_obj
+    if isinstance(name_or_obj, optim.GradientTransformation):
+        return optim.OptaxWrapper(name_or_obj, params)
+    if name_or_obj == "clipup":
+        return optim.ClipUp(step_size=0.15, max_speed=0.3, momentum=0.9, params=params)
+    return optim.OptaxWrapper(optim.by_name(name_or_obj, lr), params)
+
+
+class _ESBase(Algorithm):
+    def _center(self, center_init):
+        super().__init__()
+        self.center_init = torch.as_tensor(center_init, dtype=torch.float32)
+        self.dim = self.center_init.shape[0]
+
+    def _step_center(self, state, grad):
+        """center ← center + optimizer(grad); returns (center, state)."""
+        updates, state = use_state(self.optimizer.update)(state, grad, state.center)
+        return state.center + updates, state
+
+
+class OpenES(_ESBase):
+    """OpenAI-ES (Salimans et al. 2017).  ``optimizer="adam"`` applies Adam to the estimated
+    gradient (the reference passes the parameters instead of the gradient to Adam,
+    ``open_es.py:80``; the gradient is used here)."""
+
+    def __init__(self, center_init, pop_size, learning_rate, noise_stdev, optimizer=None, mirrored_sampling=True):
+        if not (noise_stdev > 0 and learning_rate > 0 and pop_size > 0):
+            raise ValueError("noise_stdev, learning_rate and pop_size must be positive")
+        if mirrored_sampling and pop_size % 2:
+            raise ValueError("When mirrored_sampling is True, pop_size must be a multiple of 2.")
+        self._center(center_init)
+        self.pop_size, self.learning_rate, self.noise_stdev = pop_size, learning_rate, noise_stdev
+        self.mirrored_sampling = mirrored_sampling
+        self.optimizer = _make_optimizer("adam", learning_rate, self.center_init) if optimizer == "adam" else None
+
+    def setup(self, key):
+        key = key.to(self.center_init.device)
+        return State(center=self.center_init, key=key, noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        population = _es.perturb(noise_key, state.center, self.noise_stdev, self.pop_size, self.mirrored_sampling)
+        return population, state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        if self.mirrored_sampling:
+            h = self.pop_size // 2
+            w = fitness[:h] - fitness[h:]
+        else:
+            w = fitness
+        g, _ = _es.weighted_noise_sum(state.noise_key, w, self.dim)
+        grad = g / self.pop_size / self.noise_stdev
+        if self.optimizer is None:
+            return state.replace(center=state.center - self.learning_rate * grad)
+        center, state = self._step_center(state, grad)
+        return state.replace(center=center)
+
+
+class PGPE(_ESBase):
+    """Parameter-exploring policy gradients with symmetric sampling (Sehnke et al. 2010)."""
+
+    def __init__(self, pop_size, center_init, optimizer: Union[str, Stateful, optim.GradientTransformation],
+                 stdev_init=0.1, center_learning_rate=0.15, stdev_learning_rate=0.1, stdev_max_change=0.2):
+        self._center(center_init)
+        if pop_size % 2:
+            raise ValueError("pop_size must be even (symmetric sampling)")
+        self.pop_size = pop_size
+        self.stdev_init = stdev_init
+        self.center_learning_rate = center_learning_rate
+        self.stdev_learning_rate = stdev_learning_rate
+        self.stdev_max_change = stdev_max_change
+        self.optimizer = _make_optimizer(optimizer, center_learning_rate, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key = key.to(dev)
+        return State(center=self.center_init, stdev=torch.full((self.dim,), float(self.stdev_init), device=dev),
+                     key=key, noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        population = _es.perturb(noise_key, state.center, state.stdev, self.pop_size, mirrored=True)
+        return population, state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        h = self.pop_size // 2
+        f_pos, f_neg = fitness[:h], fitness[h:]
+        w = (f_pos - f_neg) / 2
+        v = (f_pos + f_neg) / 2 - fitness.mean()
+        g, s = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=v)
+        delta_x = state.stdev * g / h
+        delta_stdev = state.stdev * s / h
+        updates, state = use_state(self.optimizer.update)(state, delta_x, state.center)
+        center = state.center + updates
+        bound = (state.stdev * self.stdev_max_change).abs()
+        step = torch.clamp(self.stdev_learning_rate * delta_stdev, -bound, bound)
+        return state.replace(center=center, stdev=state.stdev - step)
+
+
+class ARS(_ESBase):
+    """Augmented random search (Mania et al. 2018): mirrored directions, only the best
+    ``elite_ratio`` of the direction pairs contribute, step normalised by the reward spread."""
+
+    def __init__(self, pop_size, center_init, elite_ratio=0.1, optimizer="adam", lr=0.05, sigma=0.03):
+        if pop_size % 2 or not 0 <= elite_ratio <= 1:
+            raise ValueError("pop_size must be even and elite_ratio in [0, 1]")
+        self._center(center_init)
+        self.pop_size, self.lr, self.sigma, self.elite_ratio = pop_size, lr, sigma, elite_ratio
+        self.elite_pop_size = max(1, int(pop_size / 2 * elite_ratio))
+        if optimizer != "adam":
+            raise NotImplementedError(optimizer)
+        self.optimizer = _make_optimizer("adam", lr, self.center_init)
+
+    def setup(self, key):
+        key = key.to(self.center_init.device)
+        return State(key=key, center=self.center_init, noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        x = _es.perturb(noise_key, state.center, self.sigma, self.pop_size, mirrored=True)
+        return x, state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        h = self.pop_size // 2
+        f1, f2 = fitness[:h], fitness[h:]
+        elite = torch.argsort(torch.minimum(f1, f2), stable=True)[: self.elite_pop_size]
+        spread = torch.cat([f1[elite], f2[elite]]).std(unbiased=False) + 1e-5
+        w = torch.zeros_like(f1).index_copy(0, elite, (f1 - f2)[elite])
+        g, _ = _es.weighted_noise_sum(state.noise_key, w, self.dim)
+        grad = g / (self.elite_pop_size * spread)
+        center, state = self._step_center(state, grad)
+        return state.replace(center=center)
+
+
+def get_des_weights(popsize: int, temperature: float = 12.5):
+    ranks = torch.arange(popsize, dtype=torch.float32) / (popsize - 1) - 0.5
+    return torch.softmax(-20 * torch.sigmoid(temperature * ranks), 0)
+
+
+class DES(_ESBase):
+    """Discovered evolution strategy (Lange et al. 2023): rank-softmax recombination of mean
+    and per-coordinate standard deviation."""
+
+    def __init__(self, pop_size, center_init, temperature=12.5, sigma_init=0.1, mean_decay=0.0):
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.temperature, self.sigma_init = temperature, sigma_init
+        self.lrate_sigma, self.lrate_mean = 0.1, 1.0
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key = key.to(dev)
+        return State(key=key, sigma=torch.full((self.dim,), float(self.sigma_init), device=dev),
+                     center=self.center_init, weights=get_des_weights(self.popsize, self.temperature).to(dev),
+                     noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        x = _es.perturb(noise_key, state.center, state.sigma, self.popsize)
+        return x, state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        order = torch.argsort(fitness, stable=True)
+        w = torch.zeros_like(fitness).index_copy(0, order, state.weights)      # weight of row i by its rank
+        g, s = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        wsum = w.sum()
+        weighted_mean = wsum * state.center + state.sigma * g
+        weighted_sigma = torch.sqrt(state.sigma ** 2 * (s + wsum) + 1e-6)
+        center = state.center + self.lrate_mean * (weighted_mean - state.center)
+        sigma = state.sigma + self.lrate_sigma * (weighted_sigma - state.sigma)
+        return state.replace(center=center, sigma=sigma)
+
+
+class ESMC(_ESBase):
+    """ES with a baseline individual (Merchant et al. 2021): odd population = the unperturbed
+    centre plus mirrored pairs; pair differences are clipped at the baseline fitness."""
+
+    def __init__(self, pop_size, center_init, optimizer="adam", lrate_decay=1.0, lrate_limit=0.001, sigma_decay=1.0,
+                 sigma_limit=0.01, lr=0.05, sigma=0.03, init_min=0.0, init_max=0.0, clip_min=None, clip_max=None):
+        if pop_size % 2 == 0:
+            raise ValueError("ESMC needs an odd population (baseline + mirrored pairs)")
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.lr, self.sigma, self.sigma_decay, self.sigma_limit = lr, sigma, sigma_decay, sigma_limit
+        if optimizer not in ("adam", "sgd"):
+            raise NotImplementedError(optimizer)
+        self.optimizer = _make_optimizer(optimizer, lr, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key = key.to(dev)
+        return State(key=key, center=self.center_init, sigma=torch.full((self.dim,), float(self.sigma), device=dev),
+                     noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        pairs = _es.perturb(noise_key, state.center, state.sigma, self.popsize - 1, mirrored=True)
+        return torch.cat([state.center[None, :], pairs], dim=0), state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        h = (self.popsize - 1) // 2
+        base, f1, f2 = fitness[0], fitness[1:1 + h], fitness[1 + h:]
+        w = torch.minimum(f1, base) - torch.minimum(f2, base)
+        g, _ = _es.weighted_noise_sum(state.noise_key, w, self.dim)
+        center, state = self._step_center(state, g / h)
+        sigma = torch.clamp(state.sigma * self.sigma_decay, min=self.sigma_limit)
+        return state.replace(center=center, sigma=sigma)
+
+
+def _nes_utilities(popsize: int):
+    w = (math.log(popsize / 2 + 1) - torch.log(torch.arange(1, popsize + 1, dtype=torch.float32))).clamp_min(0)
+    return w / w.sum() - 1.0 / popsize
+
+
+def get_recombination_weights(popsize: int, use_baseline: bool = True):
+    w = (math.log(popsize / 2 + 1) - torch.log(torch.arange(1, popsize + 1, dtype=torch.float32))).clamp_min(0)
+    return w / w.sum() - (1.0 / popsize if use_baseline else 0.0)
+
+
+def get_temp_weights(popsize: int, temperature: float):
+    ranks = torch.arange(popsize, dtype=torch.float32) / (popsize - 1) - 0.5
+    return torch.softmax(-temperature * ranks, 0)
+
+
+class SNES(_ESBase):
+    """Separable natural evolution strategy (Wierstra et al. 2014)."""
+
+    def __init__(self, pop_size, center_init, sigma=1.0, lrate_mean=1.0, temperature=0.0, init_min=0.0, init_max=0.0):
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.sigma, self.lrate_mean, self.temperature = sigma, lrate_mean, temperature
+        self.lrate_sigma = (3 + math.log(self.dim)) / (5 * math.sqrt(self.dim))
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key = key.to(dev)
+        w = get_temp_weights(self.popsize, self.temperature) if self.temperature > 0 else get_recombination_weights(self.popsize)
+        return State(key=key, sigma=torch.full((self.dim,), float(self.sigma), device=dev), center=self.center_init,
+                     weights=w.to(dev), noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        x = _es.perturb(noise_key, state.center, state.sigma, self.popsize)
+        return x, state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        order = torch.argsort(fitness, stable=True)
+        w = torch.zeros_like(fitness).index_copy(0, order, state.weights)
+        grad_mean, grad_sigma = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        center = state.center + self.lrate_mean * state.sigma * grad_mean
+        sigma = state.sigma * torch.exp(self.lrate_sigma / 2 * grad_sigma)
+        return state.replace(center=center, sigma=sigma)
+
+
+class SeparableNES(Algorithm):
+    """Separable NES in the formulation of the NES paper (the population for the next call of
+    ``ask`` is drawn at the end of ``tell``).  The reference's ``tell`` calls an undefined
+    helper (``nes.py:188``); this is the algorithm that code describes."""
+
+    def __init__(self, init_mean, init_std, pop_size=None, recombination_weights=None, learning_rate_mean=None,
+                 learning_rate_var=None):
+        super().__init__()
+        self.init_mean = torch.as_tensor(init_mean, dtype=torch.float32)
+        self.dim = self.init_mean.shape[0]
+        self.init_std = torch.as_tensor(init_std, dtype=torch.float32).to(self.init_mean.device)
+        if tuple(self.init_std.shape) != (self.dim,):
+            raise ValueError("init_std must have shape (dim,)")
+        self.pop_size = pop_size or 4 + math.floor(3 * math.log(self.dim))
+        self.learning_rate_mean = 1 if learning_rate_mean is None else learning_rate_mean
+        self.learning_rate_var = (3 + math.log(self.dim)) / 5 / math.sqrt(self.dim) if learning_rate_var is None else learning_rate_var
+        if recombination_weights is None:
+            recombination_weights = _nes_utilities(self.pop_size)
+        self.weight = torch.as_tensor(recombination_weights, dtype=torch.float32).to(self.init_mean.device)
+
+    def setup(self, key):
+        key, noise_key = rnd.split(key.to(self.init_mean.device))
+        pop = _es.perturb(noise_key, self.init_mean, self.init_std, self.pop_size)
+        return State(population=pop, mean=self.init_mean, sigma=self.init_std, key=key, noise_key=noise_key)
+
+    def ask(self, state):
+        return state.population, state
+
+    def tell(self, state, fitness):
+        order = torch.argsort(fitness, stable=True)
+        w = torch.zeros_like(fitness).index_copy(0, order, self.weight)
+        g_mu, g_sigma = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        mean = state.mean + self.learning_rate_mean * state.sigma * g_mu
+        sigma = state.sigma * torch.exp(self.learning_rate_var / 2 * g_sigma)
+        key, noise_key = rnd.split(state.key)
+        pop = _es.perturb(noise_key, mean, sigma, self.pop_size)
+        return state.replace(population=pop, mean=mean, sigma=sigma, key=key, noise_key=noise_key)
+
+
+class XNES(Algorithm):
+    """Exponential NES (Glasmachers et al. 2010): full covariance adapted through the matrix
+    exponential of the natural gradient."""
+
+    def __init__(self, init_mean, init_covar, pop_size=None, recombination_weights=None, learning_rate_mean=None,
+                 learning_rate_var=None, learning_rate_B=None, covar_as_cholesky=False):
+        super().__init__()
+        self.init_mean = torch.as_tensor(init_mean, dtype=torch.float32)
+        self.dim = self.init_mean.shape[0]
+        dev = self.init_mean.device
+        self.pop_size = pop_size or 4 + math.floor(3 * math.log(self.dim))
+        self.learning_rate_mean = 1 if learning_rate_mean is None else learning_rate_mean
+        self.learning_rate_var = ((9 + 3 * math.log(self.dim)) / 5 / math.pow(self.dim, 1.5)
+                                  if learning_rate_var is None else learning_rate_var)
+        self.learning_rate_B = self.learning_rate_var if learning_rate_B is None else learning_rate_B
+        cov = torch.as_tensor(init_covar, dtype=torch.float32).to(dev)
+        self.init_covar = cov if covar_as_cholesky else torch.linalg.cholesky(cov)
+        if recombination_weights is None:
+            recombination_weights = _nes_utilities(self.pop_size)
+        self.recombination_weights = torch.as_tensor(recombination_weights, dtype=torch.float32).to(dev)
+        if not bool((self.recombination_weights[1:] <= self.recombination_weights[:-1]).all()):
+            raise ValueError("recombination_weights must be in descending order")
+
+    def setup(self, key):
+        sigma = torch.prod(torch.diagonal(self.init_covar)) ** (1 / self.dim)
+        key = key.to(self.init_mean.device)
+        return State(mean=self.init_mean, sigma=sigma, B=self.init_covar / sigma, key=key, noise_key=key)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        noise = _es.noise_rows(noise_key, self.pop_size, self.dim)
+        return state.mean + state.sigma * (noise @ state.B.T), state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        noise = _es.noise_rows(state.noise_key, self.pop_size, self.dim)[torch.argsort(fitness, stable=True)]
+        w = self.recombination_weights
+        eye = torch.eye(self.dim, device=noise.device)
+        grad_delta = w @ noise
+        grad_M = (noise.T * w) @ noise - w.sum() * eye
+        grad_sigma = torch.trace(grad_M) / self.dim
+        grad_B = grad_M - grad_sigma * eye
+        mean = state.mean + self.learning_rate_mean * state.sigma * (state.B @ grad_delta)
+        sigma = state.sigma * torch.exp(self.learning_rate_var / 2 * grad_sigma)
+        B = state.B @ torch.linalg.matrix_exp(self.learning_rate_B / 2 * grad_B)
+        return state.replace(mean=mean, sigma=sigma, B=B)
+
+
+class GuidedES(_ESBase):
+    """Guided ES (Maheswaranathan et al. 2019): search distribution elongated along the
+    subspace spanned by recent gradient estimates."""
+
+    def __init__(self, pop_size, center_init, subspace_dims=1, optimizer="sgd", sigma_init=0.03, lrate_init=60,
+                 lrate_decay=1.0, lrate_limit=0.001, sigma_decay=1.0, sigma_limit=0.01, mean_decay=0.0):
+        if pop_size % 2:
+            raise ValueError("pop_size must be even")
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.sigma, self.subspace_dims = sigma_init, subspace_dims
+        self.sigma_decay, self.sigma_limit = sigma_decay, sigma_limit
+        self.alpha, self.beta = 0.5, 1.0
+        if optimizer not in ("adam", "sgd"):
+            raise NotImplementedError(optimizer)
+        self.optimizer = _make_optimizer(optimizer, lrate_init, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key, k_sub = rnd.split(key.to(dev))
+        return State(key=key, center=self.center_init, sigma=torch.tensor(float(self.sigma), device=dev),
+                     grad_subspace=rnd.normal(k_sub, (self.subspace_dims, self.dim)), noise_key=key)
+
+    def _directions(self, state, noise_key):
+        h = self.popsize // 2
+        k_full, k_sub = rnd.split(noise_key)
+        a = state.sigma * math.sqrt(self.alpha / self.dim)
+        c = state.sigma * math.sqrt((1.0 - self.alpha) / self.subspace_dims)
+        eps_full = _es.noise_rows(k_full, h, self.dim)
+        eps_sub = rnd.normal(k_sub, (h, self.subspace_dims))
+        q, _ = torch.linalg.qr(state.grad_subspace.T)                     # (dim, subspace)
+        return a * eps_full + c * (eps_sub @ q.T)
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        z = self._directions(state, noise_key)
+        return torch.cat([state.center + z, state.center - z], dim=0), state.replace(key=key, noise_key=noise_key)
+
+    def tell(self, state, fitness):
+        h = self.popsize // 2
+        z = self._directions(state, state.noise_key) / state.sigma
+        grad = (self.beta / self.popsize) * ((fitness[:h] - fitness[h:]) @ z)
+        subspace = torch.cat([state.grad_subspace[1:], grad[None, :]], dim=0)
+        state = state.replace(grad_subspace=subspace)
+        center, state = self._step_center(state, grad)
+        sigma = torch.clamp(self.sigma_decay * state.sigma, min=self.sigma_limit)
+        return state.replace(center=center, sigma=sigma)
+
+
+class ASEBO(_ESBase):
+    """Adaptive ES-active subspaces (Choromanski et al. 2019): the sampling covariance blends
+    the identity with the principal subspace of past gradients."""
+
+    def __init__(self, pop_size, center_init, optimizer="adam", lr=0.05, lr_decay=1.0, lr_limit=0.001, sigma=0.03,
+                 sigma_decay=1.0, sigma_limit=0.01, mean_decay=0.0, subspace_dims=50):
+        if pop_size % 2:
+            raise ValueError("pop_size must be even")
+        if optimizer != "adam":
+            raise NotImplementedError(optimizer)
+        self._center(center_init)
+        self.pop_size, self.lr, self.sigma = pop_size, lr, sigma
+        self.sigma_decay, self.sigma_limit, self.subspace_dims = sigma_decay, sigma_limit, subspace_dims
+        self.optimizer = _make_optimizer("adam", lr, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        zeros = torch.zeros((self.dim, self.dim), device=dev)
+        return State(key=key.to(dev), center=self.center_init,
+                     grad_subspace=torch.zeros((self.subspace_dims, self.dim), device=dev), gen_counter=0,
+                     sigma=torch.tensor(float(self.sigma), device=dev), alpha=torch.tensor(0.1, device=dev),
+                     UUT=zeros, UUT_ort=zeros, population=torch.zeros((self.pop_size, self.dim), device=dev))
+
+    def ask(self, state):
+        key, k_noise = rnd.split(state.key)
+        h = self.pop_size // 2
+        X = state.grad_subspace - state.grad_subspace.mean(0)
+        _, _, Vt = torch.linalg.svd(X, full_matrices=False)
+        U, U_ort = Vt[:h], Vt[h:]
+        ready = state.gen_counter > self.subspace_dims
+        UUT = U.T @ U if ready else torch.zeros_like(state.UUT)
+        UUT_ort = U_ort.T @ U_ort
+        eye = torch.eye(self.dim, device=X.device)
+        # alpha is kept inside (0, 1] so that the blend stays positive definite (the reference
+        # lets it leave that range, after which its Cholesky factor is NaN)
+        alpha = torch.clamp(state.alpha, 1e-3, 1.0)
+        cov = state.sigma * (alpha / self.dim) * eye + ((1 - alpha) / h) * UUT
+        chol = torch.linalg.cholesky(cov)
+        z = rnd.normal(k_noise, (h, self.dim)) @ chol.T
+        z = z / torch.linalg.vector_norm(z, dim=-1, keepdim=True)
+        x = torch.cat([state.center + z, state.center - z], dim=0)
+        return x, state.replace(key=key, population=x, UUT=UUT, UUT_ort=UUT_ort, gen_counter=state.gen_counter + 1)
+
+    def tell(self, state, fitness):
+        h = self.pop_size // 2
+        noise_1 = (state.population[:h] - state.center) / state.sigma
+        grad = 0.5 * ((fitness[:h] - fitness[h:]) @ noise_1)
+        if state.gen_counter > self.subspace_dims:
+            alpha = torch.linalg.vector_norm(grad @ state.UUT_ort) / torch.linalg.vector_norm(grad @ state.UUT)
+        else:
+            alpha = torch.ones_like(state.alpha)
+        subspace = torch.cat([state.grad_subspace[1:], grad[None, :]], dim=0)
+        grad = grad / (torch.linalg.vector_norm(grad) / self.dim + 1e-8)
+        center, state = self._step_center(state, grad)
+        sigma = torch.clamp(state.sigma * self.sigma_decay, min=self.sigma_limit)
+        return state.replace(center=center, sigma=sigma, alpha=alpha, grad_subspace=subspace)
+
+
+class Noise_reuse_es(_ESBase):
+    """Noise-reuse ES (Li et al. 2023) for unrolled computation graphs: the same perturbation
+    is kept for a whole inner episode of length ``T`` (advanced ``K`` steps per generation)."""
+
+    def __init__(self, pop_size, center_init, optimizer="adam", lr=0.05, sigma=0.03, T=100, K=10, lrate_decay=1.0,
+                 lrate_limit=0.001, sigma_decay=1.0, sigma_limit=0.01, sigma_lrate=0.2, init_min=0.0, init_max=0.0,
+                 clip_min=None, clip_max=None):
+        if pop_size % 2:
+            raise ValueError("pop_size must be even")
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.lr, self.sigma, self.T, self.K = lr, sigma, T, K
+        self.sigma_decay, self.sigma_limit = sigma_decay, sigma_limit
+        if optimizer not in ("adam", "sgd"):
+            raise NotImplementedError(optimizer)
+        self.optimizer = _make_optimizer(optimizer, lr, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        key = key.to(dev)
+        return State(key=key, pert_key=key, center=self.center_init, inner_step_counter=0,
+                     sigma=torch.tensor(float(self.sigma), device=dev), pert_sigma=torch.tensor(float(self.sigma), device=dev))
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        if state.inner_step_counter == 0:
+            state = state.replace(pert_key=noise_key, pert_sigma=state.sigma)
+        x = _es.perturb(state.pert_key, state.center, state.pert_sigma, self.popsize, mirrored=True)
+        return x, state.replace(key=key)
+
+    def tell(self, state, fitness):
+        h = self.popsize // 2
+        g, _ = _es.weighted_noise_sum(state.pert_key, fitness[:h] - fitness[h:], self.dim)
+        grad = g * state.pert_sigma / (state.sigma ** 2) / self.popsize
+        center, state = self._step_center(state, grad)
+        counter = state.inner_step_counter + self.K
+        counter = 0 if counter >= self.T else counter
+        sigma = torch.clamp(self.sigma_decay * state.sigma, min=self.sigma_limit)
+        return state.replace(center=center, inner_step_counter=counter, sigma=sigma)
+
+
+class PersistentES(_ESBase):
+    """Persistent ES (Vicol et al. 2021): unbiased gradients for truncated unrolls by
+    accumulating the perturbations applied so far within an episode."""
+
+    def __init__(self, pop_size, center_init, optimizer="adam", lr=0.05, sigma=0.03, T=100, K=10, lrate_decay=1.0,
+                 lrate_limit=0.001, sigma_decay=1.0, sigma_limit=0.01, sigma_lrate=0.2, sigma_max_change=0.2,
+                 init_min=0.0, init_max=0.0, clip_min=None, clip_max=None):
+        if pop_size % 2:
+            raise ValueError("Population size must be even")
+        self._center(center_init)
+        self.popsize = self.pop_size = pop_size
+        self.lr, self.sigma, self.T, self.K = lr, sigma, T, K
+        self.sigma_decay, self.sigma_limit = sigma_decay, sigma_limit
+        if optimizer not in ("adam", "sgd"):
+            raise NotImplementedError(optimizer)
+        self.optimizer = _make_optimizer(optimizer, lr, self.center_init)
+
+    def setup(self, key):
+        dev = self.center_init.device
+        return State(key=key.to(dev), center=self.center_init, inner_step_counter=0,
+                     sigma=torch.tensor(float(self.sigma), device=dev),
+                     pert_accum=torch.zeros((self.popsize, self.dim), device=dev))
+
+    def ask(self, state):
+        key, noise_key = rnd.split(state.key)
+        pos = _es.noise_rows(noise_key, self.popsize // 2, self.dim) * self.sigma
+        perts = torch.cat([pos, -pos], dim=0)
+        return state.center + perts, state.replace(key=key, pert_accum=state.pert_accum + perts)
+
+    def tell(self, state, fitness):
+        grad = (fitness @ state.pert_accum) / (self.sigma ** 2) / self.popsize
+        center, state = self._step_center(state, grad)
+        counter = state.inner_step_counter + self.K
+        reset = counter >= self.T
+        pert_accum = torch.zeros_like(state.pert_accum) if reset else state.pert_accum
+        sigma = torch.clamp(self.sigma_decay * state.sigma, min=self.sigma_limit)
+        return state.replace(center=center, sigma=sigma, pert_accum=pert_accum,
+                             inner_step_counter=0 if reset else counter)

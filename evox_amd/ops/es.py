@@ -1,0 +1,93 @@
+"""Noise handling of the evolution-strategy family.
+
+ES gradient estimates are reductions over the population of (fitness-derived weight × noise
+row).  The noise is a pure function of (key, row, column), so it is *regenerated* where it is
+consumed instead of being kept in memory: a population of 4096 perturbations of a 10⁶-parameter
+network would otherwise pin 16 GB per copy.
+
+``perturb``             x_i = center + scale_i-th noise row (mirrored: rows come in ± pairs)
+``weighted_noise_sum``  Σ_i w_i z_i  and optionally Σ_i v_i (z_i² − 1)   — the K18 reduction
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _native
+from ..core import random as rnd
+from ._util import check, hip, on_gpu, stream_of
+
+_native.register_hip_api({
+    "evox_hip_noise_wsum": (_native.I, [_native.P, _native.P, _native.P, _native.P, _native.P, _native.P, _native.I64,
+                                        _native.I64, _native.I64, _native.I64, _native.I, _native.P]),
+})
+
+_CHUNK_ELEMS = 1 << 24
+
+
+def noise_rows(key, n_rows: int, dim: int, row_offset: int = 0) -> torch.Tensor:
+    """Rows ``[row_offset, row_offset + n_rows)`` of the logical (·, dim) Gaussian tensor."""
+    return rnd.normal(key, (n_rows, dim), offset=row_offset * dim)
+
+
+def perturb(key, center, scale, n_rows: int, mirrored: bool = False, row_offset: int = 0, total_rows=None):
+    """Population ``center + scale * z``; ``scale`` scalar or (dim,).  With ``mirrored`` the
+    logical population of ``total_rows`` (default ``n_rows``) is ``[+z; −z]`` stacked and
+    ``row_offset`` / ``n_rows`` address a window of it (for row-sharded sampling)."""
+    dim = center.shape[0]
+    total = n_rows if total_rows is None else total_rows
+    if not mirrored:
+        return center + scale * noise_rows(key, n_rows, dim, row_offset)
+    half = total // 2
+    lo, hi = row_offset, row_offset + n_rows
+    parts = []
+    if lo < half:
+        e = min(hi, half)
+        parts.append(center + scale * noise_rows(key, e - lo, dim, lo))
+    if hi > half:
+        b = max(lo, half)
+        parts.append(center - scale * noise_rows(key, hi - b, dim, b - half))
+    return torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
+
+
+def weighted_noise_sum_reference(key, w, dim: int, v=None, row_offset: int = 0):
+    """``(Σ_i w_i z_i, Σ_i v_i (z_i² − 1) or None)`` over noise rows ``row_offset + i``."""
+    n = w.shape[0]
+    g = torch.zeros(dim, dtype=torch.float32, device=w.device)
+    h = torch.zeros(dim, dtype=torch.float32, device=w.device) if v is not None else None
+    step = max(1, _CHUNK_ELEMS // max(dim, 1))
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        z = noise_rows(key, e - s, dim, row_offset + s)
+        g += w[s:e] @ z
+        if v is not None:
+            h += v[s:e] @ (z * z - 1)
+    return g, h
+
+
+def weighted_noise_sum(key, w, dim: int, v=None, row_offset: int = 0):
+    if on_gpu(w) and _has("evox_hip_noise_wsum"):
+        n = w.shape[0]
+        dev = w.device
+        w = w.contiguous().float()
+        vv = v.contiguous().float() if v is not None else None
+        # rows are split over blockIdx.y so that narrow problems still fill the chip; partial
+        # sums land in a [splits][dim] slab and are added in a fixed order
+        col_threads = (dim + 3) // 4
+        splits = max(1, min(64, (256 * 256 * 4) // max(col_threads, 1), n // 64 if n >= 64 else 1))
+        slab = torch.empty((2 if v is not None else 1, splits, dim), dtype=torch.float32, device=dev)
+        check(hip().evox_hip_noise_wsum(key.contiguous().data_ptr(), w.data_ptr(), vv.data_ptr() if vv is not None else None,
+                                        slab[0].data_ptr(), slab[1].data_ptr() if v is not None else None, None,
+                                        n, dim, int(row_offset), splits, 0, stream_of(w)), "noise_wsum")
+        red = slab.sum(1)
+        return red[0], (red[1] if v is not None else None)
+    return weighted_noise_sum_reference(key, w, dim, v, row_offset)
+
+
+def _has(symbol: str) -> bool:
+    try:
+        getattr(hip(), symbol)
+        return True
+    except AttributeError:
+        return False

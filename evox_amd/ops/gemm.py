@@ -18,7 +18,7 @@ P, I, I64, F = _native.P, _native.I, _native.I64, _native.F
 _native.register_hip_api({
     "evox_hip_gemm_f32": (I, [P, P, P, P, I, I, I, I64, I64, I64, I64, I, I, F, F, P]),
     "evox_hip_cma_sample": (I, [P, P, P, P, P, P, I, I, I64, P]),
-    "evox_hip_cma_cov": (I, [P, P, P, P, P, P, P, P, F, F, P, I, I, I64, P]),
+    "evox_hip_cma_cov": (I, [P, P, P, P, P, P, P, P, F, F, P, I, I, I64, P, I, P]),
 })
 
 
@@ -105,8 +105,13 @@ def cma_covariance_update(C, pop, order, mean, sigma, weights, pc, alpha, c1, cm
     sigma = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(1)
     alpha = torch.as_tensor(alpha, dtype=torch.float32, device=dev).reshape(1)
     out = torch.empty_like(C, memory_format=torch.contiguous_format)
+    # enough K-slices that (upper-triangular tiles x slices) covers the 256 CUs about twice
+    tiles = ((n + 63) // 64) * ((n + 63) // 64 + 1) // 2
+    splits = max(1, min(8, 512 // max(tiles, 1), mu // 256))
+    ws = torch.empty((splits, n, n), dtype=torch.float32, device=dev) if splits > 1 else None
     check(hip().evox_hip_cma_cov(C.contiguous().data_ptr(), pop.data_ptr(), order.contiguous().data_ptr(),
                                  mean.contiguous().data_ptr(), sigma.data_ptr(), weights.contiguous().data_ptr(),
                                  pc.contiguous().data_ptr(), alpha.data_ptr(), float(c1), float(cmu), out.data_ptr(),
-                                 n, mu, pop.stride(0), stream_of(C)), "cma_cov")
+                                 n, mu, pop.stride(0), ws.data_ptr() if ws is not None else None, splits,
+                                 stream_of(C)), "cma_cov")
     return out

@@ -101,3 +101,17 @@ def test_pso_step_matches_reference(cuda):
                                        gbest.cpu(), gf.cpu(), lb.cpu(), ub.cpu(), 0.6, 2.5, 0.8)
         for g, r in zip(got, ref):
             assert torch.allclose(g.cpu(), r, rtol=1e-5, atol=1e-5)
+
+
+def test_newton_schulz_sqrt_on_gpu(cuda):
+    n = 300
+    a = torch.randn(n, n, device=cuda)
+    C = a @ a.T / n + 0.2 * torch.eye(n, device=cuda)
+    ns = cma.NewtonSchulzSqrt(start_iters=25)
+    S, R = ns(C)
+    eye = torch.eye(n, device=cuda)
+    assert float((S @ S - C).norm() / C.norm()) < 1e-4
+    assert float((R @ C @ R - eye).norm() / n ** 0.5) < 1e-3
+    torch.cuda.synchronize()
+    ns(C)
+    assert ns.last_residual is not None and ns.last_residual < 1e-5

@@ -4,6 +4,8 @@
 # again.  Output of the client goes to /tmp/gpurun_<tag>.out
 tag=$1; limit=$2; shift 2
 out=/tmp/gpurun_${tag}.out
+# the exact PID of this loop, so that it can be stopped with `kill $(cat /tmp/gpurun_<tag>.pid)`
+echo $$ > /tmp/gpurun_${tag}.pid
 for attempt in $(seq 1 80); do
   /usr/local/graft/bin/gpurun --timeout "$limit" -- "$@" > "$out" 2>&1
   rc=$?
