@@ -143,6 +143,57 @@ class CMAES(Algorithm):
                              count_eigen=count_eigen)
 
 
+    # -- row-sharded protocol (evox_amd.parallel.ShardedWorkflow) ---------------------------
+    # Every rank holds the replicated distribution parameters and only its own rows of the
+    # population.  The counter-based generator makes rank r's rows exactly rows
+    # [r·λ/W, (r+1)·λ/W) of the single-process sample, the fitness is all-gathered (λ floats),
+    # and the mean / covariance updates are sums over individuals, so each rank reduces its
+    # rows and one all-reduce of n + n² floats completes them.  The decomposition is
+    # replicated work.
+    def ask_sharded(self, state, rank: int, world: int):
+        if self.pop_size % world:
+            raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
+        local = self.pop_size // world
+        key, sample_key = rnd.split(state.key)
+        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, local, self.precision,
+                                 row_offset=rank * local)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        local = self.pop_size // world
+        order = _sort.argsort(fitness)
+        ranking = torch.empty_like(order)
+        ranking[order] = torch.arange(self.pop_size, device=order.device)
+        my_rank = ranking[rank * local:(rank + 1) * local]
+        padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
+        w_local = padded[my_rank]                                   # 0 for rows outside the best μ
+        pop = state.population
+        step_sum = w_local @ (pop - state.mean)
+        ident = torch.arange(local, device=pop.device)
+        zero = torch.zeros(self.dim, device=pop.device)
+        gram = _cma.covariance_update(torch.zeros_like(state.C), pop, ident, state.mean, state.sigma, w_local, zero,
+                                      0.0, 0.0, 1.0, self.precision)
+        packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
+        step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
+        mean = state.mean + self.cm * step_sum
+        ps, pc, hsig, sigma = self._paths(state, mean)
+        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+        C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
+        if state.count_iter % self.decomp_per_iter == 0:
+            if self._ns is not None:
+                B, invsqrtC = self._ns(C)
+                D = state.D
+            else:
+                B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
+            count_eigen = state.count_eigen + 1
+        else:
+            B, D, invsqrtC, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
+        return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=invsqrtC,
+                             count_eigen=count_eigen)
+
+
 class SepCMAES(CMAES):
     """Separable CMA-ES: diagonal covariance, O(n) per individual, no eigendecomposition."""
 
@@ -152,6 +203,9 @@ class SepCMAES(CMAES):
                      C=torch.ones(self.dim, device=dev), count_iter=0, mean=self.center_init,
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
+
+    ask_sharded = None
+    tell_sharded = None
 
     def graph_signature(self, state):
         return ()
@@ -193,6 +247,9 @@ class IPOPCMAES(CMAES):
         self._ctor = dict(center_init=center_init, init_stdev=init_stdev, recombination_weights=None, cm=cm, **kwargs)
         self.original_pop_size = self.pop_size
         self.stagnation_threshold = stagnation_threshold
+
+    ask_sharded = None
+    tell_sharded = None
 
     def setup(self, key):
         s = super().setup(key)

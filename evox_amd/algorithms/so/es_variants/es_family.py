@@ -32,6 +32,33 @@ def _make_optimizer(name_or_obj, lr, params):
     return optim.OptaxWrapper(optim.by_name(name_or_obj, lr), params)
 
 
+def _mirrored_local_sum(noise_key, w_full, dim, pop_size, mirrored, rank, world, v_full=None):
+    """Σ over this rank's rows of (row weight × noise row) for a logical population whose
+    second half mirrors the first: row i ≥ N/2 is −z_{i−N/2}."""
+    local = pop_size // world
+    lo, hi = rank * local, (rank + 1) * local
+    if not mirrored:
+        return _es.weighted_noise_sum(noise_key, w_full[lo:hi], dim, v=None if v_full is None else v_full[lo:hi],
+                                      row_offset=lo) if v_full is not None else \
+            _es.weighted_noise_sum(noise_key, w_full[lo:hi], dim, row_offset=lo)[0]
+    half = pop_size // 2
+    g = torch.zeros(dim, device=w_full.device)
+    h = torch.zeros(dim, device=w_full.device) if v_full is not None else None
+    if lo < half:
+        e = min(hi, half)
+        gg, hh = _es.weighted_noise_sum(noise_key, w_full[lo:e], dim, v=None if v_full is None else v_full[lo:e],
+                                        row_offset=lo)
+        g = g + gg
+        h = h + hh if h is not None else None
+    if hi > half:
+        b = max(lo, half)
+        gg, hh = _es.weighted_noise_sum(noise_key, -w_full[b:hi], dim, v=None if v_full is None else v_full[b:hi],
+                                        row_offset=b - half)
+        g = g + gg
+        h = h + hh if h is not None else None
+    return g if v_full is None else (g, h)
+
+
 class _ESBase(Algorithm):
     def _center(self, center_init):
         super().__init__()
@@ -76,10 +103,30 @@ class OpenES(_ESBase):
             w = fitness
         g, _ = _es.weighted_noise_sum(state.noise_key, w, self.dim)
         grad = g / self.pop_size / self.noise_stdev
+        return self._apply(state, grad)
+
+    def _apply(self, state, grad):
         if self.optimizer is None:
             return state.replace(center=state.center - self.learning_rate * grad)
         center, state = self._step_center(state, grad)
         return state.replace(center=center)
+
+    # row-sharded protocol: a rank perturbs / evaluates rows [r·N/W, (r+1)·N/W) of the logical
+    # (mirrored) population and reduces the gradient over those rows; one all-reduce of `dim`
+    # floats finishes the estimate.  Nothing of size pop × dim ever exists on a rank.
+    def ask_sharded(self, state, rank: int, world: int):
+        local = self.pop_size // world
+        key, noise_key = rnd.split(state.key)
+        population = _es.perturb(noise_key, state.center, self.noise_stdev, local, self.mirrored_sampling,
+                                 row_offset=rank * local, total_rows=self.pop_size)
+        return population, state.replace(key=key, noise_key=noise_key)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        g = _mirrored_local_sum(state.noise_key, fitness, self.dim, self.pop_size, self.mirrored_sampling, rank, world)
+        grad = dist.all_reduce(g) / self.pop_size / self.noise_stdev
+        return self._apply(state, grad)
 
 
 class PGPE(_ESBase):
@@ -116,11 +163,36 @@ class PGPE(_ESBase):
         g, s = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=v)
         delta_x = state.stdev * g / h
         delta_stdev = state.stdev * s / h
+        return self._apply(state, delta_x, delta_stdev)
+
+    def _apply(self, state, delta_x, delta_stdev):
         updates, state = use_state(self.optimizer.update)(state, delta_x, state.center)
         center = state.center + updates
         bound = (state.stdev * self.stdev_max_change).abs()
         step = torch.clamp(self.stdev_learning_rate * delta_stdev, -bound, bound)
         return state.replace(center=center, stdev=state.stdev - step)
+
+    def ask_sharded(self, state, rank: int, world: int):
+        local = self.pop_size // world
+        key, noise_key = rnd.split(state.key)
+        population = _es.perturb(noise_key, state.center, state.stdev, local, True, row_offset=rank * local,
+                                 total_rows=self.pop_size)
+        return population, state.replace(key=key, noise_key=noise_key)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        h = self.pop_size // 2
+        f_pos, f_neg = fitness[:h], fitness[h:]
+        # per-row weights of the logical population: +w_i on row i, −w_i on its mirror (for the
+        # mean); v_i on both (z² is even)
+        w = (f_pos - f_neg) / 4
+        v = ((f_pos + f_neg) / 2 - fitness.mean()) / 2
+        g, s = _mirrored_local_sum(state.noise_key, torch.cat([w, -w]), self.dim, self.pop_size, True, rank, world,
+                                   v_full=torch.cat([v, v]))
+        packed = dist.all_reduce(torch.cat([g, s]))
+        g, s = packed[: self.dim], packed[self.dim:]
+        return self._apply(state, state.stdev * g / h, state.stdev * s / h)
 
 
 class ARS(_ESBase):

@@ -25,6 +25,9 @@ class MAES(CMAES):
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
+    ask_sharded = None
+    tell_sharded = None
+
     def graph_signature(self, state):
         return ()
 
@@ -92,6 +95,8 @@ class AMaLGaM(CMAES):
 
     ams_alpha = 0.05
     avs_beta = 0.05
+    ask_sharded = None
+    tell_sharded = None
 
     def _scale(self, sdr, C):
         up = (1 + self.avs_beta * (sdr - 1)) * C

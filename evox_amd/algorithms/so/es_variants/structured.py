@@ -153,6 +153,9 @@ class RMES(CMAES):
         self.c_sigma = (self.mueff + 2) / (self.dim + self.mueff + 5)
         self.q_star, self.c_s = 0.5, 0.3
 
+    ask_sharded = None
+    tell_sharded = None
+
     def setup(self, key):
         dev = self.center_init.device
         s = super().setup(key)

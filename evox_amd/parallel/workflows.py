@@ -1,0 +1,124 @@
+"""Multi-GPU workflows: one process per GPU, collectives over RCCL (``gloo`` on CPU).
+
+``ShardedWorkflow``   one algorithm instance spread over all ranks.  If the algorithm implements
+                      the row-sharded protocol (``ask_sharded`` / ``tell_sharded``) each rank
+                      generates, evaluates and reduces only its rows; otherwise the replicated
+                      mode of ``StdWorkflow.enable_multi_devices`` is used (full ``ask`` on every
+                      rank, sliced evaluation, fitness all-gather, full ``tell``).
+``IslandWorkflow``    one *independent* population per rank; every ``migrate_every`` generations
+                      each island's best individuals are all-gathered and offered to
+                      ``algorithm.migrate`` (the hook the reference leaves unimplemented,
+                      ``std_workflow.py:230-244``).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from ..core import distributed as dist
+from ..core import random as rnd
+from ..core import tree as _tree
+from ..core.algorithm import has_init_ask, has_init_tell
+from ..core.module import use_state
+from ..core.state import State
+from ..workflows.std_workflow import StdWorkflow
+
+
+def supports_sharding(algorithm) -> bool:
+    return callable(getattr(algorithm, "ask_sharded", None)) and callable(getattr(algorithm, "tell_sharded", None))
+
+
+class ShardedWorkflow(StdWorkflow):
+    def __init__(self, algorithm, problem, monitors=(), opt_direction="min", candidate_transforms=(),
+                 fitness_transforms=(), **kwargs):
+        super().__init__(algorithm, problem, monitors, opt_direction, candidate_transforms, fitness_transforms, **kwargs)
+        self.row_sharded = supports_sharding(algorithm)
+        self.pmap_axis_name = dist.POP_AXIS_NAME
+
+    def init(self, key=None, no_state: bool = False):
+        state = super().init(key, no_state)
+        if state is None:
+            return None
+        return state.replace(rank=dist.get_process_id(), world_size=dist.get_world_size())
+
+    def _step(self, state):
+        if not self.row_sharded or state.world_size == 1 and not self.row_sharded:
+            return super()._step(state)
+        hooks = self.registered_hooks
+        rank, world = state.rank, state.world_size
+        for m in hooks["pre_step"]:
+            m.pre_step(state)
+        for m in hooks["pre_ask"]:
+            m.pre_ask(state)
+        cands, state = use_state(self.algorithm.ask_sharded)(state, rank, world)
+        for m in hooks["post_ask"]:
+            m.post_ask(state, cands)
+        tcands = cands
+        for t in self.candidate_transforms:
+            tcands = t(tcands)
+        for m in hooks["pre_eval"]:
+            m.pre_eval(state, cands, tcands)
+        fitness, state = self._evaluate(state, tcands)          # includes the fitness all-gather
+        for m in hooks["post_eval"]:
+            m.post_eval(state, cands, tcands, fitness)
+        tfitness = fitness
+        for t in self.fitness_transforms:
+            tfitness = t(tfitness)
+        for m in hooks["pre_tell"]:
+            m.pre_tell(state, cands, tcands, fitness, tfitness)
+        state = use_state(self.algorithm.tell_sharded)(state, tfitness, rank, world)
+        for m in hooks["post_tell"]:
+            m.post_tell(state)
+        state = state.replace(generation=state.generation + 1, first_step=False)
+        for m in hooks["post_step"]:
+            m.post_step(state)
+        return state
+
+
+class IslandWorkflow(StdWorkflow):
+    """Island model.  Every rank derives its own key (``fold_in(key, rank)``), so islands
+    explore independently.  Migration: all-gather of each island's ``num_migrants`` best
+    ``(individual, fitness)`` pairs — ``W · k · (dim + 1)`` floats, a latency-bound message —
+    after which every island offers the *other* islands' migrants to ``algorithm.migrate``.
+
+    The algorithm must expose ``population`` / ``fitness`` in its state and a
+    ``migrate(state, pop, fit) -> state`` method."""
+
+    def __init__(self, algorithm, problem, monitors=(), opt_direction="min", migrate_every: int = 10,
+                 num_migrants: int = 8, topology: str = "all", **kwargs):
+        super().__init__(algorithm, problem, monitors, opt_direction, **kwargs)
+        if not callable(getattr(algorithm, "migrate", None)):
+            raise TypeError(f"{type(algorithm).__name__} has no migrate(state, pop, fit) method")
+        if topology not in ("all", "ring"):
+            raise ValueError("topology must be 'all' or 'ring'")
+        self.migrate_every, self.num_migrants, self.topology = migrate_every, num_migrants, topology
+
+    def init(self, key=None, no_state: bool = False):
+        rank = dist.get_process_id()
+        state = super().init(rnd.fold_in(key, rank) if key is not None else None, no_state)
+        if state is None:
+            return None
+        return state.replace(rank=rank)
+
+    def _migrate(self, state):
+        alg = state.get_child_state("algorithm")
+        k = self.num_migrants
+        best = torch.topk(alg.fitness, k, largest=False).indices
+        packet = torch.cat([alg.population[best], alg.fitness[best, None]], dim=1)       # (k, dim + 1)
+        world = dist.get_world_size()
+        everyone = dist.all_gather(packet, dist.POP_AXIS_NAME, axis=0, tiled=True).reshape(world, k, -1)
+        rank = dist.get_process_id()
+        if self.topology == "ring":
+            src = everyone[(rank - 1) % world]
+        else:
+            keep = [r for r in range(world) if r != rank] or [rank]
+            flat = everyone[keep].reshape(-1, everyone.shape[-1])
+            src = flat[torch.topk(flat[:, -1], min(k, flat.shape[0]), largest=False).indices]
+        return use_state(self.algorithm.migrate)(state, src[:, :-1].contiguous(), src[:, -1].contiguous())
+
+    def _step(self, state):
+        state = super()._step(state)
+        if self.migrate_every > 0 and state.generation % self.migrate_every == 0:
+            state = self._migrate(state)
+        return state

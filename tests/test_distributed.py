@@ -1,0 +1,83 @@
+"""Multi-process behaviour on CPU (gloo, 127.0.0.1): sharded / replicated / island workflows
+give the single-process answer for world sizes 1, 2 and 4."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(case, world, tmp_path):
+    out = str(tmp_path / f"{case}_{world}.json")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), case, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode())
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def test_collectives(tmp_path):
+    res = launch("collectives", 2, tmp_path)
+    for r in res:
+        assert r["gather"] == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
+        assert r["sum"] == [10.0, 12.0, 14.0] and r["max"] == [10.0, 11.0, 12.0]
+        assert r["bcast"] == [10.0, 11.0, 12.0] and r["gather_axis1"] == [1, 6]
+
+
+@pytest.mark.parametrize("case", ["cmaes", "openes", "pgpe"])
+def test_row_sharded_matches_single_process(case, tmp_path):
+    base = launch(case, 1, tmp_path)[0]
+    for world in (2, 4):
+        res = launch(case, world, tmp_path)
+        for r in res:
+            assert r["row_sharded"] and r["world"] == world
+            assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
+        assert all(r["vec"] == res[0]["vec"] for r in res), "replicas diverged"
+        if case == "cmaes":
+            assert res[0]["local_rows"] == 16 // world
+
+
+def test_replicated_mode_for_algorithms_without_sharding(tmp_path):
+    base = launch("pso_replicated", 1, tmp_path)[0]
+    res = launch("pso_replicated", 2, tmp_path)
+    assert not res[0]["row_sharded"]
+    for r in res:
+        assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=1e-5)
+
+
+def test_enable_multi_devices(tmp_path):
+    base = launch("std_multi_device", 1, tmp_path)[0]
+    res = launch("std_multi_device", 2, tmp_path)
+    assert res[0]["world"] == 2
+    for r in res:
+        assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=1e-5)
+
+
+def test_island_model(tmp_path):
+    res = launch("island", 2, tmp_path)
+    assert res[0]["first"] != res[1]["first"], "islands must start from different populations"
+    assert all(r["best"] < 1e-2 for r in res)
