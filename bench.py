@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--eigh", default=None, help="eigensolver override: jacobi | solver")
     ap.add_argument("--decomp", default="eigh", choices=["eigh", "newton_schulz"],
                     help="how C^(1/2), C^(-1/2) are obtained each generation")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: rehearsal of the multi-process path over gloo (not a benchmark)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
     args = ap.parse_args()
 
@@ -47,12 +49,16 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    on_gpu = args.device == "cuda"
     if world > 1:
-        dist.init_process_group()
+        dist.init_process_group("nccl" if on_gpu else "gloo")
     rank = dist.get_process_id()
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    if on_gpu:
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
 
     total_pop = args.pop * world if args.scaling == "weak" else args.pop
     key = ex.PRNGKey(20240611)
@@ -70,7 +76,8 @@ def main():
 
     def sync():
         dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         state = wf.step(state)

@@ -1,0 +1,136 @@
+// One-at-a-time environmental-selection loops as single persistent launches.
+//
+// IBEA removal, SPEA2 truncation and SRA's stochastic bubble sort update the scores of the
+// survivors after every step, so their length is inherent.  Launching one kernel per step would
+// cost more in launch boundaries than in work; instead ONE workgroup (1024 threads = 16
+// wavefronts) runs the whole loop, synchronising with workgroup barriers only: the working set
+// (a score vector, one matrix row per step) lives in LDS / L2 and no other workgroup is
+// involved, so no inter-workgroup hand-off is needed.  Every loop has a fixed trip count.
+#include "hip_common.h"
+
+using namespace evox;
+
+namespace {
+
+constexpr int NT = 1024;
+
+struct ArgMin { float v; int i; };
+
+__device__ __forceinline__ ArgMin block_argmin(float v, int i, float* s_v, int* s_i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();                        // protect s_v / s_i of the previous call
+  if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
+  __syncthreads();
+  ArgMin r{s_v[0], s_i[0]};
+  for (int w = 1; w < NT / 64; ++w)
+    if (s_v[w] < r.v || (s_v[w] == r.v && s_i[w] < r.i)) { r.v = s_v[w]; r.i = s_i[w]; }
+  return r;
+}
+
+__global__ __launch_bounds__(NT) void ibea_remove_kernel(float* __restrict__ fit, const float* __restrict__ I,
+                                                         const float* __restrict__ C, float kappa, int n, int n_remove,
+                                                         uint8_t* __restrict__ alive) {
+  __shared__ float s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  for (int j = threadIdx.x; j < n; j += NT) alive[j] = 1;
+  __syncthreads();
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += NT)
+      if (alive[j]) { const float f = fit[j]; if (f < v || (f == v && j < idx)) { v = f; idx = j; } }
+    const ArgMin m = block_argmin(v, idx, s_v, s_i);
+    if (m.i == 0x7fffffff) break;                       // uniform: nothing left
+    const float s = 1.0f / (C[m.i] * kappa);
+    const float* row = I + (int64_t)m.i * n;
+    for (int j = threadIdx.x; j < n; j += NT) fit[j] += expf(-row[j] * s);
+    if (threadIdx.x == 0) alive[m.i] = 0;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(NT) void spea2_truncate_kernel(float* __restrict__ dis, int n, int n_remove,
+                                                            uint8_t* __restrict__ keep, float* __restrict__ rowmin,
+                                                            int* __restrict__ nn) {
+  __shared__ float s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = NT / 64;
+  auto scan_row = [&](int i) {           // one wavefront scans one row
+    float v = INFINITY; int a = 0x7fffffff;
+    const float* row = dis + (int64_t)i * n;
+    for (int j = lane; j < n; j += 64) { const float d = row[j]; if (d < v || (d == v && j < a)) { v = d; a = j; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64); const int oa = __shfl_xor(a, o, 64);
+      if (ov < v || (ov == v && oa < a)) { v = ov; a = oa; }
+    }
+    if (lane == 0) { rowmin[i] = v; nn[i] = (v == INFINITY) ? -1 : a; }
+  };
+  for (int i = wave; i < n; i += nwave) scan_row(i);
+  __syncthreads();
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += NT) { const float f = rowmin[j]; if (f < v || (f == v && j < idx)) { v = f; idx = j; } }
+    const ArgMin m = block_argmin(v, idx, s_v, s_i);
+    const int x = m.i == 0x7fffffff ? 0 : m.i;
+    for (int j = threadIdx.x; j < n; j += NT) { dis[(int64_t)x * n + j] = INFINITY; dis[(int64_t)j * n + x] = INFINITY; }
+    if (threadIdx.x == 0) { keep[x] = 0; rowmin[x] = INFINITY; nn[x] = -1; }
+    __syncthreads();
+    for (int i = wave; i < n; i += nwave)
+      if (nn[i] == x) scan_row(i);                      // wave-uniform condition
+    __syncthreads();
+  }
+}
+
+// The bubble sort is a chain of dependent compare-swaps: one lane walks it with the permutation
+// in LDS (n <= 16384) while the rest of the workgroup idles.
+__global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
+                                                                const float* __restrict__ u, float pc, int n,
+                                                                int64_t* __restrict__ rank, int* __restrict__ scratch) {
+  extern __shared__ __attribute__((aligned(16))) int s_rank[];
+  int* rk = scratch != nullptr ? scratch : s_rank;
+  for (int i = threadIdx.x; i < n; i += 64) rk[i] = i;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int sweeps = (n + 1) / 2;
+    for (int s = 0; s < sweeps; ++s) {
+      bool swapped = false;
+      int a = rk[0];
+      for (int j = 0; j + 1 < n; ++j) {
+        const int b = rk[j + 1];
+        const float* key = u[j] < pc ? I1 : I2;
+        if (key[a] < key[b]) { rk[j] = b; swapped = true; /* a keeps moving right */ }
+        else { rk[j] = a; a = b; }
+      }
+      rk[n - 1] = a;
+      if (!swapped) break;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 64) rank[i] = rk[i];
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_ibea_remove(float* fit, const float* I, const float* C, float kappa, int n, int n_remove,
+                                  uint8_t* alive, void* stream) {
+  ibea_remove_kernel<<<1, NT, 0, (hipStream_t)stream>>>(fit, I, C, kappa, n, n_remove, alive);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_spea2_truncate(float* dis, int n, int n_remove, uint8_t* keep, float* rowmin, int* nn, void* stream) {
+  spea2_truncate_kernel<<<1, NT, 0, (hipStream_t)stream>>>(dis, n, n_remove, keep, rowmin, nn);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
+                                         int64_t* rank, int* scratch, void* stream) {
+  const size_t lds = scratch != nullptr ? 0 : (size_t)n * sizeof(int);
+  stochastic_ranking_kernel<<<1, 64, lds, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);
+  return last_launch_status();
+}

@@ -1,1 +1,2 @@
+from .mo import *
 from .so import *

@@ -1,0 +1,69 @@
+"""Shared pieces of the multi-objective algorithms: bounded random initialisation, the
+evaluate-the-initial-population first step, SBX + polynomial-mutation variation, and
+rank/crowding truncation."""
+from __future__ import annotations
+
+import torch
+
+from ...core import random as rnd
+from ...core.algorithm import Algorithm
+from ...core.state import State
+from ...operators import crossover, mutation
+from ...operators.selection.non_dominate import crowding_distance, non_dominated_sort
+
+
+class MOAlgorithm(Algorithm):
+    def _init_mo(self, lb, ub, n_objs, pop_size, mutation_op=None, crossover_op=None, selection_op=None):
+        super().__init__()
+        self.lb = torch.as_tensor(lb, dtype=torch.float32)
+        self.ub = torch.as_tensor(ub, dtype=torch.float32).to(self.lb.device)
+        self.n_objs = n_objs
+        self.dim = self.lb.shape[0]
+        self.pop_size = int(pop_size)
+        self.selection = selection_op
+        self.mutation = mutation_op if mutation_op is not None else mutation.Polynomial((self.lb, self.ub))
+        self.crossover = crossover_op if crossover_op is not None else crossover.SimulatedBinary()
+
+    @property
+    def device(self):
+        return self.lb.device
+
+    def _random_population(self, key, n=None):
+        n = self.pop_size if n is None else n
+        return rnd.uniform(key, (n, self.dim)) * (self.ub - self.lb) + self.lb
+
+    def _base_fields(self, key):
+        key, sub = rnd.split(key.to(self.device))
+        population = self._random_population(sub)
+        return dict(population=population, fitness=torch.zeros((self.pop_size, self.n_objs), device=self.device),
+                    next_generation=population, key=key)
+
+    def setup(self, key):
+        return State(**self._base_fields(key))
+
+    def init_ask(self, state):
+        return state.population, state
+
+    def init_tell(self, state, fitness):
+        return state.replace(fitness=fitness)
+
+    def _vary(self, x_key, mut_key, parents):
+        off = self.mutation(mut_key, self.crossover(x_key, parents))
+        return torch.clamp(off, self.lb, self.ub)
+
+    def _merged(self, state, fitness):
+        return (torch.cat([state.population, state.next_generation], dim=0),
+                torch.cat([state.fitness, fitness], dim=0))
+
+
+def rank_crowding_truncate(pop, fit, k):
+    """Indices of the ``k`` survivors by (front index, then larger crowding distance in the
+    front that straddles the cut)."""
+    rank = non_dominated_sort(fit, until=k)
+    order = torch.argsort(rank, stable=True)
+    worst = rank[order[k - 1]]
+    mask = rank == worst
+    dist = crowding_distance(fit, mask)
+    key2 = torch.where(mask, -dist, torch.zeros_like(dist))
+    idx = torch.argsort(key2, stable=True)
+    return idx[torch.argsort(rank[idx], stable=True)][:k]

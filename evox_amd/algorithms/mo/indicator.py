@@ -1,0 +1,145 @@
+"""Indicator- and strength-based MOEAs: IBEA, SPEA2, HypE.
+Reference: ``src/evox/algorithms/mo/ibea.py:20-132``, ``spea2.py:20-158``, ``hype.py:20-147``.
+
+IBEA and SPEA2 shrink the merged population by removing one individual at a time, each removal
+changing the scores of the others; these loops are inherently sequential in the number of
+removals and run on the device through ``evox_amd.ops.moselect`` (one persistent launch on a
+GPU, a tight host loop otherwise)."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from ...core import random as rnd
+from ...core.state import State
+from ...operators import selection
+from ...operators.selection.non_dominate import non_dominated_sort
+from ...ops import moselect as _sel
+from ...utils.common import cal_max, dominate_relation
+from .common import MOAlgorithm
+
+
+def ibea_fitness(pop_obj, kappa):
+    lo, hi = pop_obj.min(), pop_obj.max()
+    obj = (pop_obj - lo) / (hi - lo)
+    I = cal_max(obj, obj)
+    C = I.abs().amax(0)
+    fit = (-torch.exp(-I / C[None, :] / kappa)).sum(0) + 1
+    return fit, I, C
+
+
+class IBEA(MOAlgorithm):
+    """Indicator-based EA with the additive ε-indicator; ``kappa`` scales the fitness."""
+
+    def __init__(self, lb, ub, n_objs, pop_size, kappa=0.05, mutation_op=None, crossover_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op, crossover_op)
+        self.kappa = kappa
+        self.selection = selection.Tournament(n_round=self.pop_size)
+
+    def ask(self, state):
+        key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
+        fit = ibea_fitness(state.fitness, self.kappa)[0]
+        parents, _ = self.selection(k_sel, state.population, -fit)
+        nxt = self._vary(k_x, k_mut, parents)
+        return nxt, state.replace(next_generation=nxt, key=key)
+
+    def tell(self, state, fitness):
+        pop, obj = self._merged(state, fitness)
+        fit, I, C = ibea_fitness(obj, self.kappa)
+        alive = _sel.ibea_remove(fit, I, C, self.kappa, obj.shape[0] - self.pop_size)
+        idx = torch.argsort((~alive).to(torch.int8), stable=True)[: self.pop_size]
+        return state.replace(population=pop[idx], fitness=obj[idx])
+
+
+def spea2_fitness(obj):
+    """Raw fitness (sum of the strengths of one's dominators) + k-th-nearest-neighbour density."""
+    n = obj.shape[0]
+    dom = dominate_relation(obj, obj)
+    strength = dom.sum(1).to(torch.float32)
+    raw = (dom.to(torch.float32) * strength[:, None]).sum(0)
+    dis = torch.cdist(obj, obj)
+    dis = dis.masked_fill(torch.eye(n, dtype=torch.bool, device=obj.device), float("inf"))
+    kth = torch.sort(dis, dim=1).values[:, int(math.floor(math.sqrt(6))) - 1]
+    return 1.0 / (kth + 2) + raw
+
+
+class SPEA2(MOAlgorithm):
+    def __init__(self, lb, ub, n_objs, pop_size, mutation_op=None, crossover_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op, crossover_op)
+        self.selection = selection.Tournament(n_round=self.pop_size)
+
+    def ask(self, state):
+        key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
+        parents, _ = self.selection(k_sel, state.population, spea2_fitness(state.fitness))
+        nxt = self._vary(k_x, k_mut, parents)
+        # the reference forgets to store the advanced key here (``spea2.py:128``)
+        return nxt, state.replace(next_generation=nxt, key=key)
+
+    def tell(self, state, fitness):
+        pop, obj = self._merged(state, fitness)
+        sig = spea2_fitness(obj)
+        nondominated = sig < 1
+        n_valid = int(nondominated.sum())
+        if n_valid <= self.pop_size:
+            idx = torch.argsort(sig, stable=True)[: self.pop_size]
+        else:
+            keep = _sel.spea2_truncate(obj, nondominated, n_valid - self.pop_size)
+            idx = torch.argsort((~keep).to(torch.int8), stable=True)[: self.pop_size]
+        return state.replace(population=pop[idx], fitness=obj[idx])
+
+
+def cal_hv(points, ref, k, n_sample, key):
+    """HypE's Monte-Carlo estimate of each point's hypervolume contribution when ``k`` points
+    are to be removed: a sample dominated by j points credits each of them α_j."""
+    n, m = points.shape
+    dev = points.device
+    i = torch.arange(1, n, device=dev, dtype=torch.float32)
+    alpha = torch.cumprod(torch.cat([torch.ones(1, device=dev), (k - i) / (n - i)]), 0) / torch.arange(
+        1, n + 1, device=dev, dtype=torch.float32)
+    f_min = points.amin(0)
+    samples = f_min + rnd.uniform(key, (n_sample, m)) * (ref - f_min)
+    credit = torch.zeros(n, device=dev)
+    step = max(1, (1 << 22) // max(n, 1))
+    for s in range(0, n_sample, step):
+        blk = samples[s:s + step]
+        dominated = (points[:, None, :] <= blk[None, :, :]).all(-1)                # (n, S)
+        cnt = dominated.sum(0)
+        a = torch.where(cnt > 0, alpha[(cnt - 1).clamp_min(0)], torch.zeros_like(cnt, dtype=torch.float32))
+        credit += (dominated.to(torch.float32) * a[None, :]).sum(1)
+    return credit * (ref - f_min).prod() / n_sample
+
+
+class HypE(MOAlgorithm):
+    def __init__(self, lb, ub, n_objs, pop_size, n_sample=10000, mutation_op=None, crossover_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op, crossover_op)
+        self.n_sample = n_sample
+        self.selection = selection.Tournament(n_round=self.pop_size, multi_objective=True)
+
+    def setup(self, key):
+        return State(ref_point=torch.zeros(self.n_objs, device=self.device), **self._base_fields(key))
+
+    def init_tell(self, state, fitness):
+        ref = torch.zeros(self.n_objs, device=self.device) + fitness.max() * 1.2
+        return state.replace(fitness=fitness, ref_point=ref)
+
+    def ask(self, state):
+        key, k_hv, k_sel, k_x, k_mut = rnd.split(state.key, 5)
+        hv = cal_hv(state.fitness, state.ref_point, self.pop_size, self.n_sample, k_hv)
+        parents, _ = self.selection(k_sel, state.population, -hv)
+        nxt = self._vary(k_x, k_mut, parents)
+        return nxt, state.replace(next_generation=nxt, key=key)
+
+    def tell(self, state, fitness):
+        pop, obj = self._merged(state, fitness)
+        n = obj.shape[0]
+        key, k_hv = rnd.split(state.key)
+        rank = non_dominated_sort(obj, until=self.pop_size)
+        order = torch.argsort(rank, stable=True)
+        cut_rank = rank[order[self.pop_size - 1]]
+        mask = rank == cut_rank
+        hv = cal_hv(obj, state.ref_point, n, self.n_sample, k_hv)
+        tie = torch.where(mask, -hv, torch.zeros_like(hv))
+        idx = torch.argsort(tie, stable=True)
+        idx = idx[torch.argsort(rank[idx], stable=True)][: self.pop_size]
+        return state.replace(population=pop[idx], fitness=obj[idx], key=key)

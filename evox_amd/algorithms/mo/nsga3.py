@@ -1,0 +1,115 @@
+"""NSGA-III (Deb & Jain 2014).  Reference: ``src/evox/algorithms/mo/nsga3.py:27-211``.
+
+The reference fills the last front with a loop that admits one individual per iteration.  The
+same selection is computed here without a population-length sequential loop: the loop always
+serves the reference direction with the fewest members, so the final niche counts are a
+*water-filling* of the remaining slots — the smallest level L with
+Σ_j min(c_j, max(0, L − ρ_j)) ≥ K, found by bisection — and inside a niche the loop takes the
+closest candidate first when the niche was empty and random candidates otherwise, i.e. a prefix
+of a (partly) random order.  Ties between niches at the last level go to the lower index, as
+``argmin`` does."""
+from __future__ import annotations
+
+import torch
+
+from ...core import random as rnd
+from ...core.state import State
+from ...operators.sampling import UniformSampling
+from ...operators.selection.non_dominate import non_dominated_sort
+from ...utils.common import cos_dist
+from .common import MOAlgorithm
+
+
+def _niche_fill(rho, cnt, k):
+    """Slots t_j granted to each niche (ρ_j members already, c_j candidates) when ``k`` more
+    individuals are admitted one at a time to the currently least crowded niche."""
+    rho = rho.to(torch.int64)
+    cnt = cnt.to(torch.int64)
+    lo = torch.zeros((), dtype=torch.int64, device=rho.device)
+    hi = (rho.max() + cnt.max() + 1).to(torch.int64)
+
+    def granted(level):
+        return torch.minimum(cnt, (level - rho).clamp_min(0))
+
+    for _ in range(40):                     # bisection on the level; 2^40 exceeds any count
+        mid = (lo + hi) // 2
+        enough = granted(mid).sum() >= k
+        hi = torch.where(enough, mid, hi)
+        lo = torch.where(enough, lo, mid + 1)
+    level = hi
+    base = granted(level - 1)
+    extra_ok = granted(level) > base
+    need = k - base.sum()
+    order = torch.cumsum(extra_ok.to(torch.int64), 0)
+    return base + (extra_ok & (order <= need)).to(torch.int64)
+
+
+class NSGA3(MOAlgorithm):
+    def __init__(self, lb, ub, n_objs, pop_size, selection_op=None, mutation_op=None, crossover_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op, crossover_op, selection_op)
+        self.ref = UniformSampling(self.pop_size, self.n_objs)()[0].to(self.device)
+
+    def ask(self, state):
+        key, mut_key, x_key = rnd.split(state.key, 3)
+        nxt = self._vary(x_key, mut_key, state.population)
+        return nxt, state.replace(next_generation=nxt, key=key)
+
+    def _normalise(self, fit, considered):
+        m = self.n_objs
+        inf = torch.full_like(fit, float("inf"))
+        ideal = torch.where(considered[:, None], fit, inf).amin(0)
+        shifted = fit - ideal
+        # extreme point of axis i: minimiser of the achievement scalarising function
+        w = torch.eye(m, device=fit.device) + 1e-6
+        asf = (shifted[None, :, :] / w[:, None, :]).amax(-1)                       # (m, n)
+        asf = torch.where(considered[None, :], asf, torch.full_like(asf, float("inf")))
+        extreme = shifted[torch.argmin(asf, dim=1)]                                # (m, m)
+        worst = torch.where(considered[:, None], shifted, -inf).amax(0)
+        # hyperplane through the extreme points; fall back to the worst point when degenerate
+        sol = torch.linalg.lstsq(extreme, torch.ones(m, 1, device=fit.device)).solution[:, 0]
+        intercept = 1.0 / sol
+        full_rank = torch.linalg.matrix_rank(extreme) == m
+        ok = full_rank & torch.isfinite(intercept).all() & (intercept > 1e-12).all()
+        nadir = torch.where(ok, intercept, worst).clamp_min(1e-12)
+        return shifted / nadir
+
+    def tell(self, state, fitness):
+        key, k_sel = rnd.split(state.key)
+        pop, fit = self._merged(state, fitness)
+        n, k_total = fit.shape[0], self.pop_size
+        rank = non_dominated_sort(fit, until=k_total)
+        order = torch.argsort(rank, stable=True)
+        last_rank = rank[order[k_total - 1]]
+        considered = rank <= last_rank
+        norm = self._normalise(fit, considered)
+        cosine = cos_dist(norm, self.ref).clamp(-1, 1)
+        dist = torch.linalg.vector_norm(norm, dim=-1, keepdim=True) * torch.sqrt((1 - cosine ** 2).clamp_min(0))
+        dist = torch.where(torch.isnan(dist), torch.full_like(dist, float("inf")), dist)
+        group = torch.argmin(dist, dim=1)
+        gdist = dist.amin(1)
+        nref = self.ref.shape[0]
+        earlier, last = rank < last_rank, rank == last_rank
+        rho = torch.bincount(group[earlier], minlength=nref) if bool(earlier.any()) else torch.zeros(nref, dtype=torch.int64, device=fit.device)
+        rho = torch.zeros(nref, dtype=torch.int64, device=fit.device).scatter_add(0, group, earlier.to(torch.int64))
+        cnt = torch.zeros(nref, dtype=torch.int64, device=fit.device).scatter_add(0, group, last.to(torch.int64))
+        need = k_total - earlier.sum()
+        slots = _niche_fill(rho, cnt, need)                                        # (nref,)
+        # order of the candidates inside their niche: closest first if the niche was empty,
+        # otherwise random
+        u = rnd.uniform(k_sel, (n,))
+        closest = torch.full((nref,), float("inf"), device=fit.device).scatter_reduce(
+            0, group, torch.where(last, gdist, torch.full_like(gdist, float("inf"))), reduce="amin")
+        is_closest = last & (gdist == closest[group]) & (rho[group] == 0)
+        inner = torch.where(is_closest, torch.full_like(u, -1.0), u)
+        inner = torch.where(last, inner, torch.full_like(u, 2.0))
+        by_inner = torch.argsort(inner, stable=True)
+        by_group = by_inner[torch.argsort(group[by_inner], stable=True)]           # grouped, inner-sorted
+        g_sorted = group[by_group]
+        start = torch.zeros(nref + 1, dtype=torch.int64, device=fit.device)
+        start[1:] = torch.cumsum(torch.bincount(g_sorted, minlength=nref), 0)
+        pos_sorted = torch.arange(n, device=fit.device) - start[g_sorted]
+        pos = torch.empty(n, dtype=torch.int64, device=fit.device)
+        pos[by_group] = pos_sorted
+        chosen = earlier | (last & (pos < slots[group]))
+        idx = torch.argsort((~chosen).to(torch.int8), stable=True)[:k_total]
+        return state.replace(population=pop[idx], fitness=fit[idx], key=key)

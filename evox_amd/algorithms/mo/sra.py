@@ -1,0 +1,114 @@
+"""SRA (Li et al. 2016, stochastic ranking of two indicators) and LMOCSO (Tian et al. 2019,
+competitive swarm for large-scale MOPs).  Reference: ``src/evox/algorithms/mo/sra.py:21-191``,
+``lmocso.py:21-184``."""
+from __future__ import annotations
+
+import torch
+
+from ...core import random as rnd
+from ...core.state import State
+from ...operators import crossover
+from ...operators.sampling import UniformSampling
+from ...operators.selection.rvea_selection import ReferenceVectorGuided
+from ...ops import moselect as _sel
+from ...utils.common import cal_max
+from .common import MOAlgorithm
+from .rvea import _valid_first
+
+
+def shifted_distance_matrix(f):
+    """SDE distances: ``d[i, j] = ‖f_i − max(f_j, f_i)‖`` (j shifted so that it is nowhere better
+    than i), computed in row blocks to bound the (n, n, m) intermediate."""
+    n = f.shape[0]
+    out = torch.empty((n, n), dtype=f.dtype, device=f.device)
+    step = max(1, (1 << 22) // max(n * f.shape[1], 1))
+    for s in range(0, n, step):
+        a = f[s:s + step, None, :]
+        out[s:s + step] = torch.linalg.vector_norm(a - torch.maximum(f[None, :, :], a), dim=-1)
+    return out
+
+
+class SRA(MOAlgorithm):
+    def __init__(self, lb, ub, n_objs, pop_size, mutation_op=None, crossover_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op,
+                      crossover_op if crossover_op is not None else crossover.SimulatedBinary(type=2))
+
+    def ask(self, state):
+        key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
+        pool = rnd.randint(k_sel, (self.pop_size * 2,), 0, self.pop_size)
+        nxt = self._vary(k_x, k_mut, state.population[pool])
+        return nxt, state.replace(next_generation=nxt, key=key)
+
+    def tell(self, state, fitness):
+        pop, obj = self._merged(state, fitness)
+        key, k_pc, k_env = rnd.split(state.key, 3)
+        n = obj.shape[0]
+        pc = rnd.uniform(k_pc, ()) * 0.2 + 0.4
+        I = cal_max(obj, obj)
+        I1 = (-torch.exp(-I / 0.05)).sum(0) + 1
+        # the reference fills only the strictly lower triangle of the SDE matrix (``sra.py:94-
+        # 106``): individual i is compared with the individuals before it
+        sde = shifted_distance_matrix(obj)
+        lower = torch.tril(torch.ones((n, n), dtype=torch.bool, device=obj.device), diagonal=-1)
+        I2 = torch.where(lower, sde, torch.full_like(sde, float("inf"))).amin(1)
+        order = _sel.stochastic_ranking(I1, I2, rnd.uniform(k_env, (n - 1,)), float(pc))
+        idx = order[: self.pop_size]
+        return state.replace(population=pop[idx], fitness=obj[idx], key=key)
+
+
+def sde_fitness(obj):
+    f_min, f_max = obj.amin(0), obj.amax(0)
+    f = (obj - f_min) / (f_max - f_min)
+    d = shifted_distance_matrix(f)
+    d = d.masked_fill(torch.eye(f.shape[0], dtype=torch.bool, device=f.device), float("inf"))
+    return d.amin(1)
+
+
+class LMOCSO(MOAlgorithm):
+    """``alpha`` and ``max_gen`` shape the angle penalty of the reference-vector selection, as
+    in RVEA.  Note the argument order ``(n_objs, lb, ub, pop_size)`` of the reference."""
+
+    def __init__(self, n_objs, lb, ub, pop_size, alpha=2, max_gen=100, selection_op=None, mutation_op=None):
+        self._init_mo(lb, ub, n_objs, pop_size, mutation_op, None,
+                      selection_op if selection_op is not None else ReferenceVectorGuided())
+        self.alpha, self.max_gen = alpha, max_gen
+        v, n = UniformSampling(self.pop_size, self.n_objs)()
+        self._v = v.to(self.device)
+        self.pop_size = n
+
+    def setup(self, key):
+        f = self._base_fields(key)
+        f["fitness"] = torch.full((self.pop_size, self.n_objs), float("inf"), device=self.device)
+        return State(velocity=torch.zeros((self.pop_size // 2 * 2, self.dim), device=self.device),
+                     reference_vector=self._v, gen=0, **f)
+
+    def ask(self, state):
+        key, k_mate, k_pair, k_r, k_mut = rnd.split(state.key, 5)
+        n, half = self.pop_size, self.pop_size // 2
+        order, count = _valid_first(state.population)
+        pick = (rnd.uniform(k_mate, (n,)) * count).to(torch.int64).clamp_(max=n - 1)
+        chosen = order[pick]
+        population = state.population[chosen]
+        fit = state.fitness[chosen]
+        finite = torch.where(torch.isfinite(fit), fit, torch.zeros_like(fit))
+        score = sde_fitness(finite)
+        pair = rnd.permutation(k_pair, half * 2).reshape(2, half)
+        first_wins = score[pair[0]] > score[pair[1]]
+        winner = torch.where(first_wins, pair[0], pair[1])
+        loser = torch.where(first_wins, pair[1], pair[0])
+        r = rnd.uniform(k_r, (2, half, self.dim))
+        v_old = state.velocity[loser]
+        v_new = r[0] * v_old + r[1] * (population[winner] - population[loser])
+        moved = torch.clamp(population[loser] + v_new + r[0] * (v_new - v_old), self.lb, self.ub)
+        population = population.index_copy(0, loser, moved)
+        velocity = state.velocity.index_copy(0, loser, v_new)
+        nxt = torch.clamp(self.mutation(k_mut, population), self.lb, self.ub)
+        return nxt, state.replace(next_generation=nxt, velocity=velocity, key=key)
+
+    def tell(self, state, fitness):
+        gen = state.gen + 1
+        pop = torch.cat([state.population, state.next_generation])
+        fit = torch.cat([state.fitness, fitness])
+        fit = torch.where(torch.isinf(fit), torch.full_like(fit, float("nan")), fit)
+        survivors, survivor_fit = self.selection(pop, fit, state.reference_vector, (gen / self.max_gen) ** self.alpha)
+        return state.replace(population=survivors, fitness=survivor_fit, gen=gen)

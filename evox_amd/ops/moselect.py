@@ -1,0 +1,125 @@
+"""One-at-a-time removal / ranking loops of indicator and density based environmental selection
+(IBEA removal, SPEA2 truncation, SRA stochastic ranking).
+
+After each step the scores of the survivors change, so the loop length is inherent.  Native
+implementations run the whole loop in one call: C++ on the host (``csrc/moselect_cpu.cpp``), one
+persistent single-workgroup launch on the GPU (``csrc/moselect.hip``).  The ``*_reference``
+functions are straightforward PyTorch versions used as oracles."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _native
+from ._util import check, hip, on_gpu, stream_of
+
+P, I, I64, F = _native.P, _native.I, _native.I64, _native.F
+_native.register_cpu_api({
+    "evox_cpu_ibea_remove": (None, [P, P, P, F, I64, I64, P]),
+    "evox_cpu_spea2_truncate": (None, [P, I64, I64, P]),
+    "evox_cpu_stochastic_ranking": (None, [P, P, P, F, I64, P]),
+})
+_native.register_hip_api({
+    "evox_hip_ibea_remove": (I, [P, P, P, F, I, I, P, P]),
+    "evox_hip_spea2_truncate": (I, [P, I, I, P, P, P, P]),
+    "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
+})
+
+
+def ibea_remove_reference(fitness, I_mat, C, kappa, n_remove: int) -> torch.Tensor:
+    n = fitness.shape[0]
+    alive = torch.ones(n, dtype=torch.bool, device=fitness.device)
+    fit = fitness.clone()
+    inf = torch.tensor(float("inf"), device=fitness.device)
+    ar = torch.arange(n, device=fit.device)
+    for _ in range(int(n_remove)):
+        x = torch.argmin(torch.where(alive, fit, inf))
+        fit = fit + torch.exp(-I_mat[x, :] / C[x] / kappa)
+        alive = alive & (ar != x)
+    return alive
+
+
+def ibea_remove(fitness, I_mat, C, kappa, n_remove: int) -> torch.Tensor:
+    """IBEA: repeatedly drop the individual with the smallest fitness and add back the indicator
+    loss it caused to everyone else.  Returns the boolean survivor mask."""
+    n = fitness.shape[0]
+    fit = fitness.detach().clone().contiguous().float()
+    I_mat, C = I_mat.contiguous().float(), C.contiguous().float()
+    alive = torch.empty(n, dtype=torch.uint8, device=fit.device)
+    if on_gpu(fit):
+        check(hip().evox_hip_ibea_remove(fit.data_ptr(), I_mat.data_ptr(), C.data_ptr(), float(kappa), n, int(n_remove),
+                                         alive.data_ptr(), stream_of(fit)), "ibea_remove")
+    else:
+        _native.cpu().evox_cpu_ibea_remove(fit.data_ptr(), I_mat.data_ptr(), C.data_ptr(), float(kappa), n,
+                                           int(n_remove), alive.data_ptr())
+    return alive.bool()
+
+
+def _masked_distances(obj, mask):
+    n = obj.shape[0]
+    dis = torch.cdist(obj.float(), obj.float())
+    pair = mask[:, None] & mask[None, :] & ~torch.eye(n, dtype=torch.bool, device=obj.device)
+    return torch.where(pair, dis, torch.full_like(dis, float("inf"))).contiguous()
+
+
+def spea2_truncate_reference(obj, mask, n_remove: int) -> torch.Tensor:
+    n = obj.shape[0]
+    dis = _masked_distances(obj, mask)
+    keep = mask.clone()
+    ar = torch.arange(n, device=obj.device)
+    for _ in range(int(n_remove)):
+        x = torch.argmin(dis.amin(1))
+        gone = ar == x
+        keep = keep & ~gone
+        dis = torch.where(gone[:, None] | gone[None, :], torch.full_like(dis, float("inf")), dis)
+    return keep
+
+
+def spea2_truncate(obj, mask, n_remove: int) -> torch.Tensor:
+    """SPEA2 archive truncation among the rows selected by ``mask``: repeatedly drop the point
+    whose nearest remaining neighbour is closest.  Returns the survivor mask (⊂ mask)."""
+    n = obj.shape[0]
+    dis = _masked_distances(obj, mask)
+    keep = mask.to(torch.uint8).contiguous()
+    if on_gpu(dis):
+        rowmin = torch.empty(n, dtype=torch.float32, device=dis.device)
+        nn = torch.empty(n, dtype=torch.int32, device=dis.device)
+        check(hip().evox_hip_spea2_truncate(dis.data_ptr(), n, int(n_remove), keep.data_ptr(), rowmin.data_ptr(),
+                                            nn.data_ptr(), stream_of(dis)), "spea2_truncate")
+    else:
+        _native.cpu().evox_cpu_spea2_truncate(dis.data_ptr(), n, int(n_remove), keep.data_ptr())
+    return keep.bool()
+
+
+def stochastic_ranking_reference(I1, I2, u, pc):
+    n = I1.shape[0]
+    rank = list(range(n))
+    a, b, uu = I1.tolist(), I2.tolist(), u.tolist()
+    for _ in range((n + 1) // 2):
+        swapped = False
+        for j in range(n - 1):
+            key = a if uu[j] < pc else b
+            if key[rank[j]] < key[rank[j + 1]]:
+                rank[j], rank[j + 1] = rank[j + 1], rank[j]
+                swapped = True
+        if not swapped:
+            break
+    return torch.tensor(rank, dtype=torch.int64, device=I1.device)
+
+
+def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
+    """SRA's stochastic bubble sort: at most ⌈n/2⌉ sweeps; position j of a sweep compares by
+    ``I1`` when ``u[j] < pc`` and by ``I2`` otherwise; larger values move to the front."""
+    n = I1.shape[0]
+    I1, I2, u = I1.contiguous().float(), I2.contiguous().float(), u.contiguous().float()
+    rank = torch.empty(n, dtype=torch.int64, device=I1.device)
+    pc = float(pc)
+    if on_gpu(I1):
+        scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 16384 else None
+        check(hip().evox_hip_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr(),
+                                                scratch.data_ptr() if scratch is not None else None, stream_of(I1)),
+              "stochastic_ranking")
+    else:
+        _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
+    return rank

@@ -1,0 +1,63 @@
+"""Every multi-objective algorithm must approach the DTLZ2 front (IGD threshold after 100
+generations, far below the ≈0.6 of a random population) – stricter than the reference's
+smoke-only strategy (``tests/test_multi_objective_algorithms.py:17-31``, 10 iterations, no
+assertion)."""
+import pytest
+import torch
+
+import evox_amd as ex
+from evox_amd import algorithms, metrics, workflows
+from evox_amd.monitors import StdMOMonitor
+from evox_amd.problems.numerical import DTLZ1, DTLZ2
+
+N, M, POP = 12, 3, 100
+
+# (name, extra kwargs, steps, IGD bound)
+CASES = [
+    ("NSGA2", {}, 100, 0.12), ("NSGA3", {}, 100, 0.10), ("GDE3", {}, 100, 0.13), ("RVEA", {"max_gen": 100}, 100, 0.10),
+    ("RVEAa", {"max_gen": 100}, 100, 0.10), ("MOEAD", {}, 100, 0.10), ("MOEADDRA", {}, 100, 0.15),
+    ("MOEADM2M", {"max_gen": 100}, 100, 0.20), ("EAGMOEAD", {}, 100, 0.40), ("IBEA", {}, 100, 0.14),
+    ("BCEIBEA", {}, 201, 0.10), ("SPEA2", {}, 100, 0.10), ("HypE", {}, 100, 0.55), ("KnEA", {}, 100, 0.10),
+    ("BiGE", {}, 100, 0.13), ("TDEA", {}, 100, 0.10), ("SRA", {}, 100, 0.15), ("LMOCSO", {"max_gen": 100}, 100, 0.12),
+    ("IMMOEA", {}, 100, 0.14),
+]
+
+
+def run(name, kw, steps, problem):
+    algo = getattr(algorithms, name)(lb=torch.zeros(N), ub=torch.ones(N), n_objs=M, pop_size=POP, **kw)
+    monitor = StdMOMonitor(record_pf=False)
+    wf = workflows.StdWorkflow(algo, problem, monitors=[monitor])
+    state = wf.init(ex.PRNGKey(42))
+    for _ in range(steps):
+        state = wf.step(state)
+    return state, monitor
+
+
+@pytest.mark.parametrize("name,kw,steps,bound", CASES, ids=[c[0] for c in CASES])
+def test_dtlz2_convergence(name, kw, steps, bound):
+    problem = DTLZ2(m=M)
+    state, monitor = run(name, kw, steps, problem)
+    fit = state.get_child_state("algorithm").fitness
+    fit = fit[torch.isfinite(fit).all(1)]
+    assert fit.shape[0] >= POP // 2
+    igd = float(metrics.IGD(problem.pf())(fit))
+    assert igd < bound, (name, igd)
+    last = monitor.get_last()
+    assert last.shape[1] == M
+
+
+def test_all_inventory_covered():
+    assert sorted(c[0] for c in CASES) == sorted(algorithms.mo.__all__)
+
+
+@pytest.mark.parametrize("name", ["NSGA2", "MOEAD", "RVEA", "IBEA", "NSGA3"])
+def test_reference_smoke_dtlz1(name):
+    kw = {"max_gen": 10} if name == "RVEA" else {}
+    state, monitor = run(name, kw, 10, DTLZ1(m=M))
+    assert torch.isfinite(monitor.get_last()).any()
+
+
+def test_reproducible():
+    a, _ = run("NSGA2", {}, 5, DTLZ2(m=M))
+    b, _ = run("NSGA2", {}, 5, DTLZ2(m=M))
+    assert torch.equal(a.get_child_state("algorithm").population, b.get_child_state("algorithm").population)

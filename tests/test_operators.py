@@ -1,0 +1,126 @@
+"""Golden-value tests of the selection operators (fixtures from the reference's
+``tests/test_non_dominated_sort.py:8-27`` and ``tests/test_crowding_distance.py:7-24,150-170``)
+plus behavioural checks of crossover / mutation / sampling."""
+import math
+
+import pytest
+import torch
+
+import evox_amd as ex
+from evox_amd import operators
+from evox_amd.operators import crossover, mutation, sampling, selection
+from evox_amd.ops import nds
+
+INF = float("inf")
+
+
+def test_non_dominated_sort_golden():
+    x = torch.tensor([[0.5, 4], [1, 2], [2, 1], [3, 1], [4, 1], [5, 0.5], [1, 4], [2, 3], [3, 2], [3, 3], [4, 4]])
+    want = torch.tensor([0, 0, 0, 1, 2, 0, 1, 1, 2, 3, 4])
+    assert torch.equal(operators.non_dominated_sort(x).to(torch.int64), want)
+    assert torch.equal(nds.non_dominated_rank_reference(x).to(torch.int64), want)
+
+
+def test_non_dominated_sort_blocked_matches_reference():
+    torch.manual_seed(3)
+    x = torch.randn(700, 3)
+    a = nds.non_dominated_rank_reference(x)
+    b = nds.non_dominated_rank(x)
+    assert torch.equal(a.to(torch.int64), b.to(torch.int64))
+
+
+def test_crowding_distance_small():
+    x = torch.tensor([[0.5, 4], [1, 2.5], [2, 2], [3, 1], [4, 0.8]])
+    d = operators.crowding_distance(x)
+    want = torch.tensor([INF, 1.5 / 3.5 + 2 / 3.2, 2 / 3.5 + 1.5 / 3.2, 2 / 3.5 + 1.2 / 3.2, INF])
+    torch.testing.assert_close(d, want)
+
+
+def test_crowding_distance_masked():
+    x = torch.tensor([[-1, -1], [0.5, 4], [1, 2.5], [2, 2], [-2, -2], [3, 1], [4, 0.8], [-3, -3], [-3, -4.0]])
+    mask = torch.tensor([False, True, True, True, False, True, True, False, False])
+    d = operators.crowding_distance(x, mask)
+    want = torch.tensor([-INF, INF, 1.5 / 3.5 + 2 / 3.2, 2 / 3.5 + 1.5 / 3.2, -INF, 2 / 3.5 + 1.2 / 3.2, INF, -INF, -INF])
+    torch.testing.assert_close(d, want)
+
+
+def test_non_dominate_selection_keeps_front():
+    torch.manual_seed(0)
+    fit = torch.rand(64, 2)
+    pop = torch.arange(64, dtype=torch.float32)[:, None]
+    sel = selection.NonDominate(16)
+    p, f = sel(pop, fit)
+    rank = operators.non_dominated_sort(fit)
+    chosen_rank = rank[p[:, 0].long()]
+    assert chosen_rank.max() <= torch.sort(rank).values[15]
+
+
+def test_tournament_prefers_better():
+    key = ex.PRNGKey(0)
+    fit = torch.arange(100, dtype=torch.float32)
+    pop = fit[:, None].clone()
+    sel = selection.Tournament(n_round=1000)
+    p, idx = sel(key, pop, fit)
+    assert p.shape == (1000, 1)
+    assert p.mean() < 40
+
+
+def test_roulette_and_topk_and_uniform_rand():
+    key = ex.PRNGKey(1)
+    fit = torch.tensor([1.0, 2.0, 3.0, 100.0])
+    pop = torch.arange(4.0)[:, None]
+    p, idx = selection.RouletteWheelSelection(200)(key, pop, fit)
+    assert (idx == 3).float().mean() < 0.2
+    p, f = selection.TopkFit(2)(pop, fit)
+    assert f.tolist() == [1.0, 2.0]
+    p = selection.UniformRand(0.5)(key, pop)
+    assert p.shape[0] == 2
+
+
+def test_sbx_and_polynomial_stay_reasonable():
+    key = ex.PRNGKey(2)
+    pop = torch.rand(100, 10)
+    off = crossover.SimulatedBinary()(key, pop)
+    assert off.shape == pop.shape and torch.isfinite(off).all()
+    half = crossover.SimulatedBinary(type=2)(key, pop)
+    assert half.shape == (50, 10)
+    mut = mutation.Polynomial((torch.zeros(10), torch.ones(10)))(key, pop)
+    assert mut.shape == pop.shape and (mut >= 0).all() and (mut <= 1).all()
+    assert (mut != pop).any()
+
+
+def test_other_variation_ops():
+    key = ex.PRNGKey(3)
+    pop = torch.rand(20, 6)
+    assert crossover.UniformRand()(key, pop).shape == pop.shape
+    assert crossover.OnePoint()(key, pop).shape == pop.shape
+    g = mutation.Gaussian(stdvar=0.1)(key, pop)
+    assert 0.05 < (g - pop).std() < 0.2
+    bits = torch.rand(20, 32) < 0.5
+    flipped = mutation.Bitflip(0.5)(key, bits)
+    assert 0.3 < (flipped != bits).float().mean() < 0.7
+    de = crossover.DifferentialEvolve()(key, pop, pop.roll(1, 0), pop.roll(2, 0))
+    assert de.shape == pop.shape
+
+
+def test_sampling():
+    w, n = sampling.UniformSampling(100, 3)()
+    assert w.shape == (n, 3) and n == 91
+    torch.testing.assert_close(w.sum(1), torch.ones(n))
+    lhs = sampling.LatinHypercubeSampling(50, 4)(ex.PRNGKey(0))
+    assert lhs.shape == (50, 4)
+    # exactly one sample per stratum in every dimension
+    strata = torch.sort((lhs * 50).floor().long(), dim=0).values
+    assert torch.equal(strata, torch.arange(50)[:, None].expand(50, 4))
+    g, n = sampling.GridSampling(27, 3)()
+    assert g.shape == (27, 3)
+
+
+def test_reference_vector_guided_selection():
+    torch.manual_seed(0)
+    fit = torch.rand(200, 3) + 0.1
+    pop = torch.rand(200, 5)
+    v, _ = sampling.UniformSampling(50, 3)()
+    p, f = selection.ReferenceVectorGuided()(pop, fit, v, torch.tensor(0.5))
+    assert p.shape == (v.shape[0], 5)
+    assert torch.isfinite(f).all(1).sum() > 10
