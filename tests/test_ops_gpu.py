@@ -115,3 +115,48 @@ def test_newton_schulz_sqrt_on_gpu(cuda):
     torch.cuda.synchronize()
     ns(C)
     assert ns.last_residual is not None and ns.last_residual < 1e-5
+
+
+@pytest.mark.parametrize("n,dim,with_v", [(4096, 1000, False), (512, 70000, True), (37, 5, True)])
+def test_weighted_noise_sum_matches_reference(cuda, n, dim, with_v):
+    from evox_amd.ops import es
+    key = rnd.PRNGKey(5).to(cuda)
+    w = torch.randn(n, device=cuda)
+    v = torch.randn(n, device=cuda) if with_v else None
+    got = es.weighted_noise_sum(key, w, dim, v=v, row_offset=3)
+    ref = es.weighted_noise_sum_reference(key, w, dim, v=v, row_offset=3)
+    for g, r in zip(got, ref):
+        if r is None:
+            assert g is None
+            continue
+        scale = r.abs().max().clamp_min(1.0)
+        assert (g - r).abs().max() / scale < 2e-4
+
+
+def test_sequential_selection_kernels_match_reference(cuda):
+    from evox_amd.algorithms.mo.indicator import ibea_fitness
+    from evox_amd.ops import moselect
+    g = torch.Generator().manual_seed(0)
+    obj = torch.rand(200, 3, generator=g).to(cuda)
+    fit, I, C = ibea_fitness(obj, 0.05)
+    assert torch.equal(moselect.ibea_remove(fit, I, C, 0.05, 100), moselect.ibea_remove_reference(fit, I, C, 0.05, 100))
+    mask = torch.rand(200, generator=g).to(cuda) < 0.8
+    k = int(mask.sum()) - 60
+    assert torch.equal(moselect.spea2_truncate(obj, mask, k), moselect.spea2_truncate_reference(obj, mask, k))
+    I1, I2 = torch.rand(150, generator=g).to(cuda), torch.rand(150, generator=g).to(cuda)
+    u = torch.rand(150, generator=g).to(cuda)
+    assert torch.equal(moselect.stochastic_ranking(I1, I2, u, 0.45), moselect.stochastic_ranking_reference(I1, I2, u, 0.45))
+
+
+def test_mo_algorithm_runs_on_gpu(cuda):
+    import evox_amd as ex
+    from evox_amd import algorithms, metrics, workflows
+    from evox_amd.problems.numerical import DTLZ2
+    prob = DTLZ2(m=3)
+    algo = algorithms.NSGA2(lb=torch.zeros(12, device=cuda), ub=torch.ones(12, device=cuda), n_objs=3, pop_size=100)
+    wf = workflows.StdWorkflow(algo, prob)
+    state = wf.init(ex.PRNGKey(1))
+    for _ in range(60):
+        state = wf.step(state)
+    fit = state.get_child_state("algorithm").fitness
+    assert fit.is_cuda and float(metrics.IGD(prob.pf().to(cuda))(fit)) < 0.15
