@@ -178,11 +178,15 @@ class Stateful:
     # -- stacked modules -----------------------------------------------------------------
     @classmethod
     def stack(cls, stateful_objs, axis: int = 0):
-        """Stack dataclass modules leaf-wise into one module with a leading batch axis."""
-        for obj in stateful_objs:
-            if not dataclasses.is_dataclass(obj):
-                raise TypeError("only dataclass modules can be stacked")
-        return _tree.tree_map(lambda *xs: _stack_leaves(xs, axis), *stateful_objs)
+        """Group several modules of one kind.
+
+        Dataclass modules are stacked leaf-wise into one module with a leading batch axis (the
+        reference's behaviour, ``core/module.py:263-275``).  Ordinary modules are collected in
+        a :class:`ModuleStack`, whose members keep their own hyper-parameters and are driven one
+        after another by the containers that accept stacks."""
+        if all(dataclasses.is_dataclass(obj) for obj in stateful_objs):
+            return _tree.tree_map(lambda *xs: _stack_leaves(xs, axis), *stateful_objs)
+        return ModuleStack(stateful_objs)
 
     def __len__(self) -> int:
         if not dataclasses.is_dataclass(self):
@@ -195,3 +199,31 @@ def _stack_leaves(xs, axis: int = 0):
     if isinstance(x0, torch.Tensor):
         return torch.stack(list(xs), dim=axis)
     return torch.stack([torch.as_tensor(x) for x in xs], dim=axis)
+
+
+class ModuleStack(Stateful):
+    """An ordered group of modules initialised as children ``m0, m1, …`` (each with its own
+    PRNG key and state).  A module object listed twice is shallow-copied so that every member
+    has its own node id."""
+
+    def __init__(self, members):
+        super().__init__()
+        import copy
+        seen = set()
+        self._names = []
+        for i, m in enumerate(members):
+            if id(m) in seen:
+                m = copy.copy(m)
+            seen.add(id(m))
+            name = f"m{i:04d}"
+            setattr(self, name, m)
+            self._names.append(name)
+
+    def __len__(self) -> int:
+        return len(self._names)
+
+    def __getitem__(self, i):
+        return getattr(self, self._names[i])
+
+    def __iter__(self):
+        return (getattr(self, n) for n in self._names)

@@ -75,6 +75,7 @@ class EvalMonitor(Monitor):
 
     def record_fit_single_obj(self, cand_sol, fitness):
         self.eval_count += fitness.shape[0]
+        self.latest_fitness, self.latest_solution = fitness, cand_sol
         if self.full_sol_history:
             self.solution_history.append(self._archive(cand_sol))
         if self.full_fit_history:

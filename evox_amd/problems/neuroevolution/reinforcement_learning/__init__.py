@@ -1,0 +1,14 @@
+"""Policy-search problems.
+
+* ``TensorEnvProblem`` – rollouts of device-resident batched environments (the role Brax plays
+  for the reference); ``Brax`` resolves environment names through the same interface.
+* ``Gym`` – arbitrary ``gymnasium``-API environments stepped by a pool of worker processes.
+* ``EnvPool`` – a vectorised environment pool: the in-tree native C++ pool, or ``envpool`` when
+  that package is installed."""
+from .tensor_env import (Brax, SyntheticLocomotion, TensorEnv, TensorEnvProblem, make_tensor_env, register_tensor_env)
+from .classic_envs import CartPoleEnv, PendulumEnv
+from .gym import CapEpisode, Gym, Normalizer
+from .env_pool import EnvPool, NativeEnvPool
+
+__all__ = ["Brax", "SyntheticLocomotion", "TensorEnv", "TensorEnvProblem", "make_tensor_env", "register_tensor_env",
+           "CartPoleEnv", "PendulumEnv", "CapEpisode", "Gym", "Normalizer", "EnvPool", "NativeEnvPool"]
