@@ -81,3 +81,33 @@ def test_island_model(tmp_path):
     res = launch("island", 2, tmp_path)
     assert res[0]["first"] != res[1]["first"], "islands must start from different populations"
     assert all(r["best"] < 1e-2 for r in res)
+
+
+def test_process_distributed_workflow_cso():
+    """The reference's Ray scenario (``tests/test_workflows.py:93-118``): CSO on Ackley over two
+    workers, monitored from the driver."""
+    import warnings
+
+    import torch
+
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+    from evox_amd.monitors import StdSOMonitor
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monitor = StdSOMonitor()
+    wf = workflows.RayDistributedWorkflow(
+        algorithm=algorithms.CSO(lb=torch.full((2,), -32.0), ub=torch.full((2,), 32.0), pop_size=20),
+        problem=problems.numerical.Ackley(), num_workers=2, monitors=[monitor], options={"num_cpus": 1})
+    try:
+        state = wf.init(ex.PRNGKey(42))
+        for _ in range(100):
+            state = wf.step(state)
+        wf.flush(state)
+        assert float(monitor.get_best_fitness()) < 1e-4
+        assert len(monitor.get_history()) == 100
+        cands, state = wf.sample(state)
+        assert cands.shape[1] == 2
+    finally:
+        wf.close()
