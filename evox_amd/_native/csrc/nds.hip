@@ -1,0 +1,190 @@
+// Matrix-free non-dominated sorting.
+//
+//   count[i] = #{ j : j dominates i }              (nds_count)   O(N^2 m) pair tests, no N x N matrix
+//   repeat:  front = { i unranked : count[i] == 0 } -> compacted, rank[i] = k           (nds_front)
+//            count[i] -= #{ j in front : j dominates i } for every unranked i           (nds_peel)
+//
+// Each lane owns one point i (objectives in VGPRs) and walks the candidate dominators j in the same
+// order as every other lane, so a candidate's objectives are wave-uniform: they are fetched with
+// scalar loads into SGPRs and compared straight against the lane's VGPRs - no LDS staging and two
+// or three VALU instructions per pair test.
+//
+// Points are sorted by ascending first objective and stored objective-major (caller).  For block b
+// every candidate placed before the first row whose f0 equals the block's smallest f0 has a strictly
+// smaller f0 than all of the block's points, so for those the test shrinks to the remaining m-1
+// "<=" comparisons (phase A).  The short tail up to the last row with f0 <= the block's largest f0
+// gets the full test (phase B).  Candidates behind that can never dominate.  Narrow problems split
+// the candidate range over blockIdx.y and combine with integer atomics (exact, order-free).
+#include "hip_common.h"
+
+using namespace evox;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int CH = 16;          // candidates fetched per batch of scalar loads
+
+// Layout: objective-major ("SoA"), obj[k * ld + j], ld a multiple of CH.  One s_load_dwordx16 then
+// brings one objective of 16 consecutive candidates into SGPRs.
+template <int M, int K0, bool STRICT>
+__device__ __forceinline__ bool test1(const float* __restrict__ obj, int64_t ld, int j, const float (&b)[M]) {
+  bool le = true, lt = false;
+#pragma unroll
+  for (int k = K0; k < M; ++k) {
+    const float a = obj[k * ld + j];
+    le = le & (a <= b[k]);
+    lt = lt | (a < b[k]);
+  }
+  return STRICT ? (le & lt) : le;
+}
+
+// Number of candidates j in [lo, hi) passing the test against this lane's point: all-<= over
+// objectives K0..M-1, and with STRICT additionally "< in at least one".
+template <int M, int K0, bool STRICT>
+__device__ __forceinline__ int scan_rows(const float* __restrict__ obj, int64_t ld, int lo, int hi, const float (&b)[M]) {
+  int cnt = 0;
+  int j = lo;
+  const int head = min(hi, (lo + CH - 1) / CH * CH);
+  for (; j < head; ++j) cnt += test1<M, K0, STRICT>(obj, ld, j, b) ? 1 : 0;
+  for (; j + CH <= hi; j += CH) {
+    float a[M][CH];
+#pragma unroll
+    for (int k = K0; k < M; ++k) {
+      const float4* __restrict__ src = reinterpret_cast<const float4*>(obj + k * ld + j);
+#pragma unroll
+      for (int q = 0; q < CH / 4; ++q) {
+        const float4 v = src[q];
+        a[k][4 * q] = v.x; a[k][4 * q + 1] = v.y; a[k][4 * q + 2] = v.z; a[k][4 * q + 3] = v.w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      bool le = true, lt = false;
+#pragma unroll
+      for (int k = K0; k < M; ++k) { le = le & (a[k][u] <= b[k]); lt = lt | (a[k][u] < b[k]); }
+      cnt += (STRICT ? (le & lt) : le) ? 1 : 0;
+    }
+  }
+  for (; j < hi; ++j) cnt += test1<M, K0, STRICT>(obj, ld, j, b) ? 1 : 0;
+  return cnt;
+}
+
+// first position in [lo, hi) whose key is >= v (STRICT=false) or > v (STRICT=true); keys ascending,
+// NaN keys last
+template <bool STRICT>
+__device__ __forceinline__ int bound(const float* __restrict__ key, int lo, int hi, float v) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const float k = key[mid];
+    const bool before = STRICT ? (k <= v) : (k < v);
+    if (before) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// obj sorted by objective 0.  count must be zeroed by the caller.
+template <int M>
+__global__ __launch_bounds__(NT) void nds_count_kernel(const float* __restrict__ obj, int64_t ld, int n,
+                                                       int* __restrict__ count) {
+  const int first = blockIdx.x * NT;
+  const int last = min(n, first + NT) - 1;
+  const float key_lo = obj[first], key_hi = obj[last];
+  if (key_lo != key_lo) return;                       // a block of NaN keys: nothing dominates them
+  // uniform bounds (every lane computes the same values; the compiler keeps them scalar)
+  const int j_strict = bound<false>(obj, 0, first, key_lo);                      // f0 < every f0 of the block
+  const int j_end = (key_hi != key_hi) ? n : bound<true>(obj, last + 1, n, key_hi);
+
+  const int i = first + threadIdx.x;
+  float b[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) b[k] = i < n ? obj[k * ld + i] : 0.f;
+  const bool clean = b[0] == b[0];
+
+  // this y-slice's share of [0, j_end), in whole batches
+  int per = (j_end + gridDim.y - 1) / gridDim.y;
+  per = (per + CH - 1) / CH * CH;
+  const int lo = min(j_end, (int)blockIdx.y * per), hi = min(j_end, lo + per);
+  const int cnt_a = scan_rows<M, 1, false>(obj, ld, lo, min(hi, j_strict), b);
+  const int cnt_b = scan_rows<M, 0, true>(obj, ld, max(lo, j_strict), hi, b);
+  const int cnt = (clean ? cnt_a : 0) + cnt_b;
+  if (i < n && cnt) atomicAdd(&count[i], cnt);
+}
+
+// Collect the current front: unranked points whose count reached zero.  Their objectives are copied
+// into a compact objective-major array so that the peel pass streams them with scalar loads.
+template <int M>
+__global__ void nds_front_kernel(const float* __restrict__ obj, int64_t ld, const int* __restrict__ count,
+                                 int* __restrict__ rank, float* __restrict__ front_obj, int* __restrict__ nf, int n, int cur) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (rank[i] < 0 && count[i] == 0) {
+    const int pos = atomicAdd(nf, 1);
+#pragma unroll
+    for (int k = 0; k < M; ++k) front_obj[k * ld + pos] = obj[k * ld + i];
+    rank[i] = cur;
+  }
+}
+
+// A front member j and a still-unranked point i are never equal (equal points share their front),
+// so "j dominates i" is the all-<= test alone.
+template <int M>
+__global__ __launch_bounds__(NT) void nds_peel_kernel(const float* __restrict__ obj, int64_t ld, int n,
+                                                      const float* __restrict__ front_obj, const int* __restrict__ nf_ptr,
+                                                      int* __restrict__ count, const int* __restrict__ rank) {
+  const int nf = *nf_ptr;
+  if (nf == 0) return;
+  const int i = blockIdx.x * NT + threadIdx.x;
+  const bool live = i < n && rank[i] < 0;
+  if (__ballot(live) == 0) return;                    // wave-uniform exit
+  float b[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) b[k] = live ? obj[k * ld + i] : -INFINITY;
+  const int dec = scan_rows<M, 0, false>(front_obj, ld, 0, nf, b);
+  if (live && dec) count[i] -= dec;
+}
+
+template <int M>
+int launch_count(const float* obj, int64_t ld, int n, int* count, int ysplit, hipStream_t s) {
+  dim3 grid((n + NT - 1) / NT, ysplit);
+  nds_count_kernel<M><<<grid, NT, 0, s>>>(obj, ld, n, count);
+  return last_launch_status();
+}
+
+template <int M>
+int launch_round(const float* obj, int64_t ld, int n, int* count, int* rank, float* front_obj, int* nf, int cur,
+                 hipStream_t s) {
+  nds_front_kernel<M><<<(n + 255) / 256, 256, 0, s>>>(obj, ld, count, rank, front_obj, nf, n, cur);
+  int st = last_launch_status();
+  if (st) return st;
+  nds_peel_kernel<M><<<(n + NT - 1) / NT, NT, 0, s>>>(obj, ld, n, front_obj, nf, count, rank);
+  return last_launch_status();
+}
+
+}  // namespace
+
+#define EVOX_NDS_DISPATCH(FN, ...)                 \
+  switch (m) {                                     \
+    case 2: return FN<2>(__VA_ARGS__);             \
+    case 3: return FN<3>(__VA_ARGS__);             \
+    case 4: return FN<4>(__VA_ARGS__);             \
+    case 5: return FN<5>(__VA_ARGS__);             \
+    case 6: return FN<6>(__VA_ARGS__);             \
+    case 7: return FN<7>(__VA_ARGS__);             \
+    case 8: return FN<8>(__VA_ARGS__);             \
+    default: return (int)hipErrorInvalidValue;     \
+  }
+
+// obj: m x ld objective-major (ld >= n, a multiple of 16, 64-byte aligned base), columns sorted by
+// the first objective.
+EVOX_API int evox_hip_nds_count(const float* obj, int64_t ld, int n, int m, int* count, int ysplit, void* stream) {
+  if (n <= 0 || ysplit < 1 || ld < n || ld % 16) return (int)hipErrorInvalidValue;
+  EVOX_NDS_DISPATCH(launch_count, obj, ld, n, count, ysplit, (hipStream_t)stream)
+}
+
+// One peeling round: gather front `cur` (its size accumulates into *nf, which the caller zeroed) and
+// subtract its dominations from the counts of the points still unranked.
+EVOX_API int evox_hip_nds_round(const float* obj, int64_t ld, int n, int m, int* count, int* rank, float* front_obj,
+                                int* nf, int cur, void* stream) {
+  if (n <= 0 || ld < n || ld % 16) return (int)hipErrorInvalidValue;
+  EVOX_NDS_DISPATCH(launch_round, obj, ld, n, count, rank, front_obj, nf, cur, (hipStream_t)stream)
+}

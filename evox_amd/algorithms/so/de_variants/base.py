@@ -90,22 +90,30 @@ class DEBase(Algorithm):
         b = idx.shape[0]
         dev = pop.device
         k_sel, k_pb, k_x = rnd.split(key, 3)
+        # Host-known settings stay on the host: no scalar ever crosses to the device here, so the
+        # whole routine is free of synchronisations (and can be recorded into a graph).
+        static_nd = isinstance(num_diff, int)
+        n_picks = min(diff_padding_num, 2 * num_diff + 1) if static_nd else diff_padding_num
         if replace:
-            picks = rnd.randint(k_sel, (b, diff_padding_num), 0, self.pop_size)
+            picks = rnd.randint(k_sel, (b, n_picks), 0, self.pop_size)
             picks = torch.where(picks == idx[:, None], torch.full_like(picks, self.pop_size - 1), picks)
         else:
-            picks = rnd.choice_distinct(k_sel, self.pop_size, b, diff_padding_num, exclude=idx)
-        nd = torch.as_tensor(num_diff, device=dev).reshape(-1, 1)
-        pos = torch.arange(diff_padding_num, device=dev)[None, :]
-        live = (pos >= 1) & (pos < 2 * nd + 1)
-        sign = (torch.where(pos % 2 == 1, 1.0, -1.0) * live).to(pop.dtype)
-        diff = torch.einsum("bk,bkd->bd", sign.expand(b, -1), pop[picks])
+            picks = rnd.choice_distinct(k_sel, self.pop_size, b, n_picks, exclude=idx)
+        if static_nd:
+            diff = pop[picks[:, 1]] - pop[picks[:, 2]]
+            for t in range(1, num_diff):
+                diff = diff + (pop[picks[:, 2 * t + 1]] - pop[picks[:, 2 * t + 2]])
+        else:
+            nd = num_diff.to(dev).reshape(-1, 1)
+            pos = torch.arange(n_picks, device=dev)[None, :]
+            live = (pos >= 1) & (pos < 2 * nd + 1)
+            sign = (torch.where(pos % 2 == 1, 1.0, -1.0) * live).to(pop.dtype)
+            diff = torch.einsum("bk,bkd->bd", sign.expand(b, -1), pop[picks])
         current = pop[idx]
 
         def base_of(code):
-            code_t = torch.as_tensor(code, device=dev)
-            if code_t.dim() == 0:
-                c = int(code_t)
+            if isinstance(code, int):
+                c = code
                 if c == RAND:
                     return pop[picks[:, 0]]
                 if c == BEST:
@@ -113,17 +121,16 @@ class DEBase(Algorithm):
                 if c == PBEST:
                     return select_rand_pbest(k_pb, 0.05, pop, fit, num=b)
                 return current
+            code_t = code.to(dev)
             cands = torch.stack([pop[picks[:, 0]], pop[state.best_index].expand(b, -1),
                                  select_rand_pbest(k_pb, 0.05, pop, fit, num=b), current], dim=1)
             return cands[torch.arange(b, device=dev), code_t]
 
-        Fc = torch.as_tensor(F, device=dev, dtype=pop.dtype)
-        Fc = Fc[:, None] if Fc.dim() == 1 else Fc
+        Fc = F[:, None] if isinstance(F, torch.Tensor) and F.dim() == 1 else F
         p, s = base_of(prim), base_of(sec)
         mutant = p + Fc * (s - p) + Fc * diff
-        cross_t = torch.as_tensor(cross, device=dev)
-        if cross_t.dim() == 0:
-            c = int(cross_t)
+        if isinstance(cross, int):
+            c = cross
             if c == BIN:
                 trial = de_bin_cross(k_x, mutant, current, CR)
             elif c == EXP:
@@ -131,6 +138,7 @@ class DEBase(Algorithm):
             else:
                 trial = de_arith_recom(mutant, current, CR)
         else:
+            cross_t = cross.to(dev)
             kb, ke = rnd.split(k_x)
             t_bin = de_bin_cross(kb, mutant, current, CR)
             t_exp = de_exp_cross(ke, mutant, current, CR)

@@ -58,7 +58,7 @@ def de_bin_cross(key, mutation_vector, current_vect, CR):
     k_r, k_m = rnd.split(key)
     b, dim = mutation_vector.shape
     jrand = rnd.randint(k_r, (b, 1), 0, dim)
-    cr = torch.as_tensor(CR, device=mutation_vector.device, dtype=mutation_vector.dtype).reshape(-1, 1)
+    cr = CR.to(mutation_vector.dtype).reshape(-1, 1) if isinstance(CR, torch.Tensor) else float(CR)
     mask = rnd.uniform(k_m, (b, dim)) < cr
     mask = mask | (torch.arange(dim, device=mask.device)[None, :] == jrand)
     return torch.where(mask, mutation_vector, current_vect)
@@ -69,7 +69,10 @@ def de_exp_cross(key, mutation_vector, current_vect, CR):
     k_n, k_l = rnd.split(key)
     b, dim = mutation_vector.shape
     start = rnd.randint(k_n, (b, 1), 0, dim)
-    cr = torch.as_tensor(CR, device=mutation_vector.device, dtype=torch.float32).reshape(-1).expand(b)
+    if isinstance(CR, torch.Tensor):
+        cr = CR.to(torch.float32).reshape(-1).expand(b)
+    else:
+        cr = torch.full((b,), float(CR), dtype=torch.float32, device=mutation_vector.device)
     length = torch.clamp(rnd.geometric(k_l, cr), max=dim) - 1
     pos = (torch.arange(dim, device=start.device)[None, :] - start) % dim
     mask = pos < length[:, None]
@@ -77,7 +80,9 @@ def de_exp_cross(key, mutation_vector, current_vect, CR):
 
 
 def de_arith_recom(mutation_vector, current_vect, K):
-    k = torch.as_tensor(K, device=mutation_vector.device, dtype=mutation_vector.dtype)
-    if k.dim() == 1:
-        k = k[:, None]
+    k = K
+    if isinstance(K, torch.Tensor):
+        k = K.to(mutation_vector.dtype)
+        if k.dim() == 1:
+            k = k[:, None]
     return current_vect + k * (mutation_vector - current_vect)

@@ -49,12 +49,13 @@ def non_dominated_rank_reference(x: torch.Tensor, until: Optional[int] = None) -
 
 
 def non_dominated_rank(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
-    if on_gpu(x) and _has("evox_hip_nds_count"):
+    if on_gpu(x):
         from . import _nds_hip
 
-        return _nds_hip.rank(x, until)
+        if _nds_hip.supported(x):
+            return _nds_hip.rank(x, until)
     n = x.shape[0]
-    if n > 8192 and not x.is_cuda:
+    if n > 8192:
         return _blocked_reference(x, until)
     return non_dominated_rank_reference(x, until)
 

@@ -42,10 +42,10 @@ class ShardedWorkflow(StdWorkflow):
             return None
         return state.replace(rank=dist.get_process_id(), world_size=dist.get_world_size())
 
-    def _step(self, state):
+    def _step(self, state, hooks=None, aux=None):
         if not self.row_sharded or state.world_size == 1 and not self.row_sharded:
-            return super()._step(state)
-        hooks = self.registered_hooks
+            return super()._step(state, hooks, aux)
+        hooks = self.registered_hooks if hooks is None else hooks
         rank, world = state.rank, state.world_size
         for m in hooks["pre_step"]:
             m.pre_step(state)
@@ -68,6 +68,8 @@ class ShardedWorkflow(StdWorkflow):
         for m in hooks["pre_tell"]:
             m.pre_tell(state, cands, tcands, fitness, tfitness)
         state = use_state(self.algorithm.tell_sharded)(state, tfitness, rank, world)
+        if aux is not None:
+            aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
         for m in hooks["post_tell"]:
             m.post_tell(state)
         state = state.replace(generation=state.generation + 1, first_step=False)
@@ -117,8 +119,10 @@ class IslandWorkflow(StdWorkflow):
             src = flat[torch.topk(flat[:, -1], min(k, flat.shape[0]), largest=False).indices]
         return use_state(self.algorithm.migrate)(state, src[:, :-1].contiguous(), src[:, -1].contiguous())
 
-    def _step(self, state):
-        state = super()._step(state)
+    def step(self, state):
+        # migration stays outside the (optionally graph-replayed) generation: it is a collective
+        # driven by the host-side generation counter
+        state = super().step(state)
         if self.migrate_every > 0 and state.generation % self.migrate_every == 0:
             state = self._migrate(state)
         return state

@@ -39,6 +39,9 @@ class StdWorkflowState:
     world_size: int = pytree_field(static=True)
 
 
+_NO_HOOKS = {name: () for name in HOOK_NAMES}
+
+
 class StdWorkflow(Workflow):
     def __init__(
         self,
@@ -131,8 +134,10 @@ class StdWorkflow(Workflow):
         tell = self.algorithm.init_tell if first else self.algorithm.tell
         return use_state(tell)(state, fitness)
 
-    def _step(self, state):
-        hooks = self.registered_hooks
+    def _step(self, state, hooks=None, aux=None):
+        """One generation.  ``hooks`` overrides the registered monitor hooks (graph capture
+        records the step without them); ``aux`` (a dict) receives the intermediate tensors."""
+        hooks = self.registered_hooks if hooks is None else hooks
         for m in hooks["pre_step"]:
             m.pre_step(state)
         for m in hooks["pre_ask"]:
@@ -172,6 +177,8 @@ class StdWorkflow(Workflow):
             m.pre_tell(state, cands, tcands, fitness, tfitness)
 
         state = self._tell(state, tfitness)
+        if aux is not None:
+            aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
 
         for m in hooks["post_tell"]:
             m.post_tell(state)
@@ -190,14 +197,42 @@ class StdWorkflow(Workflow):
             m.post_step(state)
         return state
 
-    def step(self, state):
-        if self.graph_step and not state.first_step:
-            if self._graphed is None:
-                from ..utils.graph import GraphedStep
+    def _bare_step(self, state):
+        aux = {}
+        state = self._step(state, hooks=_NO_HOOKS, aux=aux)
+        return state, aux
 
-                self._graphed = GraphedStep(self._step)
-            return self._graphed(state)
-        return self._step(state)
+    def step(self, state):
+        if not (self.graph_step and not state.first_step):
+            return self._step(state)
+        # Steady-state generations replay a recording of the bare step; the monitors observe
+        # it from outside: pre_* hooks see the incoming state, post_* hooks the outgoing one,
+        # with the candidates / fitness the recording produced.
+        if self._graphed is None:
+            from ..utils.graph import GraphedStep
+
+            if self.migrate_helper is not None or self.external_problem:
+                raise ValueError("graph_step cannot record host-side evaluation or migration")
+            self._graphed = GraphedStep(self._bare_step, host_counters=("fields/generation",))
+        hooks = self.registered_hooks
+        for m in hooks["pre_step"]:
+            m.pre_step(state)
+        for m in hooks["pre_ask"]:
+            m.pre_ask(state)
+        new_state, aux = self._graphed(state)
+        for m in hooks["post_ask"]:
+            m.post_ask(new_state, aux["cands"])
+        for m in hooks["pre_eval"]:
+            m.pre_eval(new_state, aux["cands"], aux["tcands"])
+        for m in hooks["post_eval"]:
+            m.post_eval(new_state, aux["cands"], aux["tcands"], aux["fitness"])
+        for m in hooks["pre_tell"]:
+            m.pre_tell(new_state, aux["cands"], aux["tcands"], aux["fitness"], aux["tfitness"])
+        for m in hooks["post_tell"]:
+            m.post_tell(new_state)
+        for m in hooks["post_step"]:
+            m.post_step(new_state)
+        return new_state
 
     # ------------------------------------------------------------------------------------
     def enable_multi_devices(self, state: State, pmap_axis_name=POP_AXIS_NAME) -> State:

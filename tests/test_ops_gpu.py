@@ -160,3 +160,61 @@ def test_mo_algorithm_runs_on_gpu(cuda):
         state = wf.step(state)
     fit = state.get_child_state("algorithm").fitness
     assert fit.is_cuda and float(metrics.IGD(prob.pf().to(cuda))(fit)) < 0.15
+
+
+@pytest.mark.parametrize("algo_name", ["PSO", "OpenES"])
+def test_graph_step_replays_match_eager(cuda, algo_name):
+    """Every replay of the recorded step must equal the eager step: replays are interleaved with
+    eager work and synchronisations, and each one is checked."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+    from evox_amd.monitors import EvalMonitor
+
+    def build(graph):
+        if algo_name == "PSO":
+            algo = algorithms.PSO(lb=-torch.ones(64, device=cuda) * 5, ub=torch.ones(64, device=cuda) * 5, pop_size=512)
+        else:
+            algo = algorithms.OpenES(torch.ones(300, device=cuda), pop_size=256, learning_rate=0.05, noise_stdev=0.1)
+        mon = EvalMonitor()
+        return workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), monitors=[mon], graph_step=graph), mon
+
+    eager, mon_e = build(False)
+    graphed, mon_g = build(True)
+    se, sg = eager.init(ex.PRNGKey(9)), graphed.init(ex.PRNGKey(9))
+    for step in range(8):
+        se, sg = eager.step(se), graphed.step(sg)
+        torch.cuda.synchronize()
+        scratch = torch.randn(256, 256, device=cuda) @ torch.randn(256, 256, device=cuda)   # eager work in between
+        assert torch.isfinite(scratch).all()
+        assert sg.generation == se.generation == step + 1
+        fe, fg = mon_e.get_latest_fitness(), mon_g.get_latest_fitness()
+        assert torch.equal(fe, fg), (algo_name, step, (fe - fg).abs().max())
+    assert graphed._graphed is not None and graphed._graphed.replays >= 6
+    from evox_amd.core.tree import tree_leaves
+    for a, b in zip(tree_leaves(se), tree_leaves(sg)):
+        if isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,m", [(11, 2), (700, 2), (3000, 3), (2500, 5), (1500, 8), (5000, 3)])
+def test_nd_sort_kernel_matches_reference(cuda, n, m):
+    from evox_amd.ops import nds
+    g = torch.Generator().manual_seed(n + m)
+    x = torch.rand(n, m, generator=g)
+    x[: n // 10] = x[n // 2: n // 2 + n // 10]                  # exact duplicates
+    x[:, 0] = (x[:, 0] * 50).round() / 50                        # many ties in the sort key
+    want = nds.non_dominated_rank_reference(x)
+    got = nds.non_dominated_rank(x.to(cuda))
+    assert torch.equal(got.cpu(), want), (got.cpu() != want).sum()
+    for until in (1, n // 3, n):
+        want_u = nds.non_dominated_rank_reference(x, until=until)
+        got_u = nds.non_dominated_rank(x.to(cuda), until=until)
+        assert torch.equal(got_u.cpu(), want_u), until
+
+
+def test_nd_sort_kernel_golden_and_chain(cuda):
+    from evox_amd.ops import nds
+    x = torch.tensor([[0.5, 4], [1, 2], [2, 1], [3, 1], [4, 1], [5, 0.5], [1, 4], [2, 3], [3, 2], [3, 3], [4, 4]])
+    assert nds.non_dominated_rank(x.to(cuda)).tolist() == [0, 0, 0, 1, 2, 0, 1, 1, 2, 3, 4]
+    chain = torch.arange(300, dtype=torch.float32)[:, None].expand(300, 2).contiguous()   # 300 fronts of one point
+    assert nds.non_dominated_rank(chain.to(cuda)).tolist() == list(range(300))

@@ -93,3 +93,11 @@ def test_gp_regression_and_classification():
     clf.fit(xc, yc)
     _, p, _ = clf.predict(xc)
     assert ((p > 0.5).float() == yc).float().mean() > 0.9
+
+
+def test_graphed_step_refuses_cpu_state():
+    from evox_amd.utils.graph import GraphCaptureError, GraphedStep
+    import pytest
+    step = GraphedStep(lambda s: s)
+    with pytest.raises(GraphCaptureError):
+        step(ex.State(x=torch.zeros(3)))
