@@ -115,7 +115,8 @@ def openes_mlp(args):
     net = MLP([obs_dim, 1024, 720, act_dim])                     # ≈1.0 M parameters
     pop = args.pop or 4096
     dtype = torch.bfloat16 if args.param_dtype == "bf16" else torch.float32
-    policy = lambda w, o: net.batched_apply(w.to(dtype) if w.dtype != dtype else w, o)
+    policy = net.batched_apply
+    to_param_dtype = [] if dtype == torch.float32 else [lambda w: w.to(dtype)]     # once per generation
     prob = TensorEnvProblem(policy, SyntheticLocomotion(obs_dim, act_dim, seed=4), max_episode_length=args.episode_length,
                             num_episodes=1)
     center = net.init(ex.PRNGKey(0)).to(device)
@@ -125,9 +126,9 @@ def openes_mlp(args):
     else:
         algo = cls(center, pop_size=pop, learning_rate=0.01, noise_stdev=0.05, optimizer="adam", mirrored_sampling=True)
     if world > 1:
-        wf = workflows.ShardedWorkflow(algo, prob, opt_direction="max")
+        wf = workflows.ShardedWorkflow(algo, prob, opt_direction="max", candidate_transforms=to_param_dtype)
     else:
-        wf = workflows.StdWorkflow(algo, prob, opt_direction="max")
+        wf = workflows.StdWorkflow(algo, prob, opt_direction="max", candidate_transforms=to_param_dtype)
     state = wf.init(ex.PRNGKey(3).to(device))
     state, dt = _timed(wf, state, args.steps, args.warmup, device)
     _emit(rank, config=f"{cls.__name__} MLP {net.sizes} ({net.n_params} params) pop={pop} x{world} ranks, synthetic locomotion "

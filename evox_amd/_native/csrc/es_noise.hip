@@ -58,7 +58,71 @@ __global__ __launch_bounds__(256) void noise_wsum_kernel(const int32_t* __restri
   }
 }
 
+// out[r, c] = center[c] + sign(r) * scale[c] * z(noise_row(r), c): the population of an evolution
+// strategy written in one pass (no noise tensor, no temporaries), optionally as bf16 and with a
+// padded row pitch.  With half > 0 the logical population is [+z; -z] stacked (mirrored sampling):
+// logical row g >= half reuses noise row g - half with the opposite sign.
+template <typename T>
+__global__ __launch_bounds__(256) void es_perturb_kernel(const int32_t* __restrict__ key, const float* __restrict__ center,
+                                                         const float* __restrict__ scale, int scale_is_vec,
+                                                         T* __restrict__ out, int64_t pitch, int64_t n_rows, int64_t dim,
+                                                         int64_t row_offset, int64_t half) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const int64_t c0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (c0 >= dim) return;
+  float ctr[4], sc[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int64_t c = c0 + l < dim ? c0 + l : dim - 1;
+    ctr[l] = center[c];
+    sc[l] = scale_is_vec ? scale[c] : scale[0];
+  }
+  const bool aligned = (dim & 3) == 0;
+  for (int64_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
+    const int64_t g = row_offset + r;
+    const bool neg = half > 0 && g >= half;
+    const int64_t nr = neg ? g - half : g;
+    const uint64_t e = (uint64_t)nr * (uint64_t)dim + (uint64_t)c0;
+    float z[4];
+    const f32x4 a = normal4(philox_block(k0, k1, e >> 2, kStreamDraw));
+    if (aligned) {
+      z[0] = a.x; z[1] = a.y; z[2] = a.z; z[3] = a.w;
+    } else {
+      const int sh = (int)(e & 3);
+      const f32x4 b = normal4(philox_block(k0, k1, (e >> 2) + 1, kStreamDraw));
+#pragma unroll
+      for (int l = 0; l < 4; ++l) z[l] = (l + sh < 4) ? lane_of(a, l + sh) : lane_of(b, l + sh - 4);
+    }
+    T* o = out + r * pitch + c0;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (c0 + l < dim) {
+        // same rounding as center + scale * z / center - scale * z in two fp32 steps
+        const float v = neg ? ctr[l] - sc[l] * z[l] : ctr[l] + sc[l] * z[l];
+        if constexpr (sizeof(T) == 2) o[l] = (T)((__float_as_uint(v) + 0x7fffu + ((__float_as_uint(v) >> 16) & 1u)) >> 16);
+        else o[l] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+EVOX_API int evox_hip_es_perturb(const int32_t* key, const float* center, const float* scale, int scale_is_vec, void* out,
+                                 int out_dtype, int64_t pitch, int64_t n_rows, int64_t dim, int64_t row_offset,
+                                 int64_t half, void* stream) {
+  if (n_rows <= 0 || dim <= 0) return 0;
+  if (pitch < dim) return (int)hipErrorInvalidValue;
+  const int64_t quads = (dim + 3) / 4;
+  dim3 grid((unsigned)((quads + 255) / 256), (unsigned)(n_rows < 4096 ? n_rows : 4096));
+  if (out_dtype == 1)
+    es_perturb_kernel<uint16_t><<<grid, 256, 0, (hipStream_t)stream>>>(key, center, scale, scale_is_vec, (uint16_t*)out,
+                                                                        pitch, n_rows, dim, row_offset, half);
+  else
+    es_perturb_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(key, center, scale, scale_is_vec, (float*)out, pitch,
+                                                                     n_rows, dim, row_offset, half);
+  return last_launch_status();
+}
 
 EVOX_API int evox_hip_noise_wsum(const int32_t* key, const float* w, const float* v, float* gslab, float* hslab,
                                  void* reserved, int64_t n, int64_t dim, int64_t row_offset, int64_t splits, int flags,

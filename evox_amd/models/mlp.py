@@ -29,6 +29,9 @@ def batched_mlp_forward(flat: torch.Tensor, obs: torch.Tensor, sizes: Sequence[i
     squeeze = obs.dim() == 2
     h = obs[:, None, :] if squeeze else obs
     P = flat.shape[0]
+    if _hip_ok(flat, h, sizes, activation, final_activation):
+        out = _forward_hip(flat, h, sizes, activation, final_activation, bias)
+        return out[:, 0, :] if squeeze else out
     act = _ACT[activation] if isinstance(activation, str) else activation
     fin = _ACT[final_activation] if isinstance(final_activation, str) else final_activation
     dt = compute_dtype or flat.dtype
@@ -47,6 +50,37 @@ def batched_mlp_forward(flat: torch.Tensor, obs: torch.Tensor, sizes: Sequence[i
             h = torch.bmm(h, W.to(dt))
         h = fin(h) if li == n_layers - 1 else act(h)
     return h[:, 0, :] if squeeze else h
+
+
+_ACT_CODE = {"identity": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
+
+
+def _hip_ok(flat, obs, sizes, activation, final_activation) -> bool:
+    return (flat.is_cuda and obs.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1
+            and obs.shape[1] in (1, 2, 4) and isinstance(activation, str) and isinstance(final_activation, str)
+            and activation in _ACT_CODE and final_activation in _ACT_CODE and 1 <= len(sizes) - 1 <= 8
+            and 2 * obs.shape[1] * ((max(sizes) + 3) // 4 * 4) * 4 <= 64 * 1024)
+
+
+def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
+    """Fused kernel (``csrc/mlp.hip``): one workgroup per individual streams its parameters once."""
+    import ctypes
+
+    from .. import _native
+    from ..ops._util import check, hip, stream_of
+    P_, I_, I64_ = _native.P, _native.I, _native.I64
+    _native.register_hip_api({"evox_hip_mlp_forward": (I_, [P_, I_, I64_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
+    P, E = flat.shape[0], obs.shape[1]
+    n_layers = len(sizes) - 1
+    x = obs.to(torch.float32).contiguous()
+    out = torch.empty((P, E, sizes[-1]), dtype=torch.float32, device=flat.device)
+    c_sizes = (ctypes.c_int * (n_layers + 1))(*[int(s) for s in sizes])
+    acts = [_ACT_CODE[activation]] * (n_layers - 1) + [_ACT_CODE[final_activation]]
+    c_acts = (ctypes.c_int * n_layers)(*acts)
+    check(hip().evox_hip_mlp_forward(flat.data_ptr(), 1 if flat.dtype == torch.bfloat16 else 0, flat.stride(0), x.data_ptr(),
+                                     out.data_ptr(), P, E, ctypes.addressof(c_sizes), ctypes.addressof(c_acts), n_layers,
+                                     int(bool(bias)), stream_of(flat)), "mlp_forward")
+    return out
 
 
 class MLP:

@@ -23,6 +23,11 @@ _native.register_hip_api({
                                         _native.I64, _native.I64, _native.I64, _native.I, _native.P]),
 })
 
+_native.register_hip_api({
+    "evox_hip_es_perturb": (_native.I, [_native.P, _native.P, _native.P, _native.I, _native.P, _native.I, _native.I64,
+                                        _native.I64, _native.I64, _native.I64, _native.I64, _native.P]),
+})
+
 _CHUNK_ELEMS = 1 << 24
 
 
@@ -31,12 +36,39 @@ def noise_rows(key, n_rows: int, dim: int, row_offset: int = 0) -> torch.Tensor:
     return rnd.normal(key, (n_rows, dim), offset=row_offset * dim)
 
 
-def perturb(key, center, scale, n_rows: int, mirrored: bool = False, row_offset: int = 0, total_rows=None):
+def _perturb_hip(key, center, scale, n_rows, dim, row_offset, half, out_dtype):
+    """One fused pass: Philox normals → scale → add → (optional bf16) store.  Rows are padded to a
+    multiple of four elements so that consumers can use 16-byte loads; the returned tensor is the
+    ``[:, :dim]`` view of that buffer."""
+    dev = center.device
+    dt = torch.float32 if out_dtype is None else out_dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise ValueError("perturb writes float32 or bfloat16")
+    pitch = (dim + 3) // 4 * 4
+    buf = torch.empty((n_rows, pitch), dtype=dt, device=dev)
+    if isinstance(scale, torch.Tensor):
+        sc = scale.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+        if sc.numel() not in (1, dim):
+            raise ValueError("scale must be a scalar or have one entry per dimension")
+    else:
+        sc = torch.full((1,), float(scale), dtype=torch.float32, device=dev)
+    check(hip().evox_hip_es_perturb(key.contiguous().data_ptr(), center.contiguous().data_ptr(), sc.data_ptr(),
+                                    int(sc.numel() == dim and dim > 1), buf.data_ptr(), 1 if dt == torch.bfloat16 else 0,
+                                    pitch, n_rows, dim, int(row_offset), int(half), stream_of(center)), "es_perturb")
+    return buf if pitch == dim else buf[:, :dim]
+
+
+def perturb(key, center, scale, n_rows: int, mirrored: bool = False, row_offset: int = 0, total_rows=None,
+            out_dtype=None):
     """Population ``center + scale * z``; ``scale`` scalar or (dim,).  With ``mirrored`` the
     logical population of ``total_rows`` (default ``n_rows``) is ``[+z; −z]`` stacked and
     ``row_offset`` / ``n_rows`` address a window of it (for row-sharded sampling)."""
     dim = center.shape[0]
     total = n_rows if total_rows is None else total_rows
+    if on_gpu(center) and center.dtype == torch.float32:
+        return _perturb_hip(key, center, scale, n_rows, dim, row_offset, total // 2 if mirrored else 0, out_dtype)
+    if out_dtype not in (None, torch.float32):
+        return perturb(key, center, scale, n_rows, mirrored, row_offset, total_rows).to(out_dtype)
     if not mirrored:
         return center + scale * noise_rows(key, n_rows, dim, row_offset)
     half = total // 2

@@ -218,3 +218,47 @@ def test_nd_sort_kernel_golden_and_chain(cuda):
     assert nds.non_dominated_rank(x.to(cuda)).tolist() == [0, 0, 0, 1, 2, 0, 1, 1, 2, 3, 4]
     chain = torch.arange(300, dtype=torch.float32)[:, None].expand(300, 2).contiguous()   # 300 fronts of one point
     assert nds.non_dominated_rank(chain.to(cuda)).tolist() == list(range(300))
+
+
+@pytest.mark.parametrize("dim,mirrored", [(1000, True), (1001, True), (37, False), (4096, False)])
+def test_fused_perturb_matches_host_path(cuda, dim, mirrored):
+    from evox_amd.ops import es
+    key = rnd.PRNGKey(11)
+    center = torch.randn(dim)
+    scale = torch.rand(dim) + 0.1
+    for sc_host in (0.3, scale):
+        want = es.perturb(key, center, sc_host, 64, mirrored=mirrored, row_offset=8, total_rows=128)
+        sc_dev = sc_host.to(cuda) if isinstance(sc_host, torch.Tensor) else sc_host
+        got = es.perturb(key.to(cuda), center.to(cuda), sc_dev, 64, mirrored=mirrored, row_offset=8, total_rows=128)
+        assert got.shape == (64, dim)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-6, atol=1e-6)
+    got16 = es.perturb(key.to(cuda), center.to(cuda), 0.3, 64, mirrored=mirrored, row_offset=8, total_rows=128,
+                       out_dtype=torch.bfloat16)
+    want16 = es.perturb(key, center, 0.3, 64, mirrored=mirrored, row_offset=8, total_rows=128).bfloat16()
+    assert got16.dtype == torch.bfloat16
+    torch.testing.assert_close(got16.cpu().float(), want16.float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("sizes", [(244, 1024, 720, 17), (27, 64, 8), (5, 130, 3), (12, 256, 256, 6)])
+@pytest.mark.parametrize("E", [1, 2, 4])
+def test_mlp_kernel_matches_bmm(cuda, sizes, E):
+    from evox_amd.models import MLP
+    from evox_amd.models import mlp as mlp_mod
+    net = MLP(list(sizes), activation="tanh", final_activation="tanh")
+    g = torch.Generator().manual_seed(sum(sizes) + E)
+    P = 33
+    pop = (torch.randn(P, net.n_params, generator=g) * 0.1)
+    obs = torch.randn(P, E, sizes[0], generator=g)
+    want = net.batched_apply(pop, obs)                                      # host path: batched GEMMs
+    got = net.batched_apply(pop.to(cuda), obs.to(cuda))
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-5)
+    # padded pitch (16-byte loads) and bf16 parameters
+    pitch = (net.n_params + 3) // 4 * 4
+    buf = torch.zeros(P, pitch, device=cuda)
+    buf[:, :net.n_params] = pop.to(cuda)
+    got_p = net.batched_apply(buf[:, :net.n_params], obs.to(cuda))
+    torch.testing.assert_close(got_p.cpu(), want, rtol=2e-4, atol=2e-5)
+    want16 = net.batched_apply(pop.bfloat16().float(), obs)
+    got16 = net.batched_apply(buf[:, :net.n_params].bfloat16(), obs.to(cuda))
+    torch.testing.assert_close(got16.cpu(), want16, rtol=2e-3, atol=2e-3)
+    assert mlp_mod._hip_ok(buf[:, :net.n_params], obs.to(cuda), net.sizes, "tanh", "tanh")
