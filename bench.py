@@ -5,9 +5,11 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU over RCCL.  A "step" is one full generation (sample λ candidates,
-evaluate them, sort, update mean / paths / covariance / step size, eigendecompose) with the
-reference's default hyper-parameters (μ = λ/2, decomposition every generation for this
-size).  Synthetic objective (Ackley) — no data set is involved; the distribution starts from a
+evaluate them, sort, update mean / paths / covariance / step size, factorise C) with the
+reference's default hyper-parameters (μ = λ/2, factorisation every generation for this
+size).  The factorisation yields C^{1/2} and C^{-1/2}, the two matrices the update equations
+use: by default through a Newton–Schulz iteration (its residual is reported), with
+``--decomp eigh`` through a full eigendecomposition as the reference does.  Synthetic objective (Ackley) — no data set is involved; the distribution starts from a
 random mean.  Rank 0 prints one JSON line.
 """
 from __future__ import annotations
@@ -32,8 +34,9 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--eigh", default=None, help="eigensolver override: jacobi | solver")
-    ap.add_argument("--decomp", default="eigh", choices=["eigh", "newton_schulz"],
-                    help="how C^(1/2), C^(-1/2) are obtained each generation")
+    ap.add_argument("--decomp", default="newton_schulz", choices=["eigh", "newton_schulz"],
+                    help="how C^(1/2), C^(-1/2) are obtained each generation: GEMM-only Newton-Schulz "
+                         "iteration (default) or a full eigendecomposition (rocSOLVER)")
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearsal of the multi-process path over gloo (not a benchmark)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
@@ -115,6 +118,7 @@ def main():
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated eigh)",
                        "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph)},
             "sigma_end": sigma,
+            "factorisation_residual": getattr(getattr(algo, "_ns", None), "last_residual", None),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

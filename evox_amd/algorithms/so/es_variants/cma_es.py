@@ -76,6 +76,8 @@ class CMAES(Algorithm):
             if self.mu > self.pop_size:
                 raise ValueError("more recombination weights than individuals")
         self.weights = w.to(torch.float32).to(dev)
+        # non-negative weights allow the Gram form of the rank-μ term (S = sqrt(w)·Y, SᵀS)
+        self._sqrt_w = torch.sqrt(self.weights) if bool((w >= 0).all()) else None
         n = float(self.dim)
         self.mueff = float(w.sum() ** 2 / (w ** 2).sum())
         self.cc = (4 + self.mueff / n) / (n + 4 + 2 * self.mueff / n)
@@ -96,16 +98,33 @@ class CMAES(Algorithm):
             pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev), B=eye,
             D=torch.ones(self.dim, device=dev), C=eye.clone(), count_eigen=0, count_iter=0, invsqrtC=eye.clone(),
             mean=self.center_init, sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
-            population=torch.empty((self.pop_size, self.dim), device=dev))
+            population=torch.empty((self.pop_size, self.dim), device=dev),
+            # device-side copy of count_iter: lets the fused tell kernels (and a recorded graph of
+            # the step) read the generation number without a host value
+            count_iter_dev=torch.zeros((), device=dev))
 
     def graph_signature(self, state):
         """Host-side control flow of the next ``tell`` (which HIP graph variant applies)."""
         return ((state.count_iter + 1) % self.decomp_per_iter == 0,)
 
+    def graph_host_counters(self):
+        """State fields that only count on the host (a recorded step may advance them without
+        replaying host code).  Valid when every generation takes the same branch, i.e. the
+        factorisation runs every generation, and the device work reads ``count_iter_dev``."""
+        if self.decomp_per_iter == 1 and self._ns is not None and self._sqrt_w is not None:
+            return ("count_iter", "count_eigen")
+        return ()
+
+    def graph_check(self) -> bool:
+        """Polled by the workflow every few dozen replays: True asks for a new recording (the
+        Newton–Schulz iteration count frozen in the graph no longer reaches the tolerance)."""
+        return self._ns is not None and self._ns.needs_more_iterations()
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
         population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, self.pop_size, self.precision)
-        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
 
     # -- pieces of tell ------------------------------------------------------------------
     def _paths(self, state, mean, order=None):
@@ -124,12 +143,22 @@ class CMAES(Algorithm):
 
     def tell(self, state, fitness):
         order = _sort.argsort(fitness)
-        elite = state.population[order[: self.mu]]
-        mean = state.mean + self.cm * (self.weights @ (elite - state.mean))
-        ps, pc, hsig, sigma = self._paths(state, mean)
-        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
-        C = _cma.covariance_update(state.C, state.population, order, state.mean, state.sigma, self.weights, pc,
-                                   alpha, self.c1, self.cmu, self.precision)
+        if state.population.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
+            # one pass builds S = sqrt(w)·(X_sel − m)/σ; the mean shift is σ·Sᵀsqrt(w) and the
+            # rank-μ term SᵀS
+            S, step = _cma.elite_factor(state.population, order, state.mean, state.sigma, self._sqrt_w, self.precision)
+            from ....ops import gemm as _gemm
+            mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
+                state.mean, step, self._whiten(state, step), state.ps, state.pc, state.sigma, state.count_iter_dev,
+                (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
+            C = _cma.covariance_from_factor(state.C, S, pc, alpha, self.c1, self.cmu)
+        else:
+            elite = state.population[order[: self.mu]]
+            mean = state.mean + self.cm * (self.weights @ (elite - state.mean))
+            ps, pc, hsig, sigma = self._paths(state, mean)
+            alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+            C = _cma.covariance_update(state.C, state.population, order, state.mean, state.sigma, self.weights, pc,
+                                       alpha, self.c1, self.cmu, self.precision)
         if state.count_iter % self.decomp_per_iter == 0:
             if self._ns is not None:
                 B, invsqrtC = self._ns(C)
@@ -157,7 +186,8 @@ class CMAES(Algorithm):
         key, sample_key = rnd.split(state.key)
         population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, local, self.precision,
                                  row_offset=rank * local)
-        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
 
     def tell_sharded(self, state, fitness, rank: int, world: int):
         from ....core import distributed as dist
@@ -170,17 +200,32 @@ class CMAES(Algorithm):
         padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
         w_local = padded[my_rank]                                   # 0 for rows outside the best μ
         pop = state.population
-        step_sum = w_local @ (pop - state.mean)
-        ident = torch.arange(local, device=pop.device)
-        zero = torch.zeros(self.dim, device=pop.device)
-        gram = _cma.covariance_update(torch.zeros_like(state.C), pop, ident, state.mean, state.sigma, w_local, zero,
-                                      0.0, 0.0, 1.0, self.precision)
-        packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
-        step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
-        mean = state.mean + self.cm * step_sum
-        ps, pc, hsig, sigma = self._paths(state, mean)
-        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
-        C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
+        if pop.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
+            # local share of the sufficient statistics through the same kernels as the
+            # single-process tell: S = sqrt(w_local)(X_local − m)/σ (zero rows for unselected
+            # individuals), Gram matrix by one library GEMM, then ONE all-reduce of n + n² floats
+            from ....ops import gemm as _gemm
+            ident = torch.arange(local, device=pop.device)
+            S, step_sum = _cma.elite_factor(pop, ident, state.mean, state.sigma, torch.sqrt(w_local), self.precision)
+            gram = torch.mm(S.T, S, out_dtype=torch.float32) if S.dtype != torch.float32 else torch.mm(S.T, S)
+            packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
+            step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
+            mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
+                state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
+                (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
+            C = torch.addr(state.C * alpha, pc, pc, alpha=float(self.c1)).add_(gram, alpha=float(self.cmu))
+        else:
+            step_sum = w_local @ (pop - state.mean)
+            ident = torch.arange(local, device=pop.device)
+            zero = torch.zeros(self.dim, device=pop.device)
+            gram = _cma.covariance_update(torch.zeros_like(state.C), pop, ident, state.mean, state.sigma, w_local, zero,
+                                          0.0, 0.0, 1.0, self.precision)
+            packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
+            step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
+            mean = state.mean + self.cm * step_sum
+            ps, pc, hsig, sigma = self._paths(state, mean)
+            alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+            C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
         if state.count_iter % self.decomp_per_iter == 0:
             if self._ns is not None:
                 B, invsqrtC = self._ns(C)

@@ -57,6 +57,27 @@ def covariance_update(C, pop, order, mean, sigma, weights, pc, alpha, c1, cmu, p
     return covariance_update_reference(C, pop, order, mean, sigma, weights, pc, alpha, c1, cmu)
 
 
+def use_factor_form() -> bool:
+    """GPU covariance update through the explicit factor S (gather kernel + library GEMM), the
+    fastest measured form; ``EVOX_AMD_CMA_COV=fused`` selects the hand-written gathered-operand
+    MFMA kernel instead."""
+    import os
+
+    return os.environ.get("EVOX_AMD_CMA_COV", "factor") == "factor" and os.environ.get("EVOX_AMD_GEMM", "hip") != "torch"
+
+
+def elite_factor(pop, order, mean, sigma, sqrt_w, precision: str = "fp32"):
+    from . import gemm
+
+    return gemm.cma_elite_factor(pop, order, mean, sigma, sqrt_w, precision)
+
+
+def covariance_from_factor(C, S, pc, alpha, c1, cmu):
+    from . import gemm
+
+    return gemm.cma_covariance_from_factor(C, S, pc, alpha, c1, cmu)
+
+
 # --------------------------------------------------------------------------------------
 # eigendecomposition
 # --------------------------------------------------------------------------------------
@@ -110,6 +131,7 @@ class NewtonSchulzSqrt:
         self.iters = start_iters
         self._pending = None          # (event, pinned residual, iters used)
         self.last_residual = None
+        self._graph_residual = None
 
     def _poll(self):
         if self._pending is None:
@@ -125,10 +147,24 @@ class NewtonSchulzSqrt:
         elif r < self.tol * 1e-3 and used <= self.iters:
             self.iters = max(self.min_iters, used - 1)
 
+    def needs_more_iterations(self) -> bool:
+        """For recorded (graph-replayed) use: read the residual the last replay left on the
+        device (one synchronisation) and raise the iteration count if it misses the tolerance."""
+        if self._graph_residual is None:
+            return False
+        r = float(self._graph_residual)
+        self.last_residual = r
+        if not (r == r) or r > self.tol:
+            self.iters = min(self.max_iters, self.iters + (4 if (r != r or r > 1e-2) else 2))
+            return True
+        return False
+
     def __call__(self, C: torch.Tensor):
-        self._poll()
         n = C.shape[0]
         gpu = C.is_cuda
+        capturing = gpu and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self._poll()
         eye = torch.eye(n, device=C.device, dtype=C.dtype)
         # scale towards the centre of the spectrum when that is provably safe (λmax < 2s needs
         # ‖C‖∞ < 2s), else by the norm bound: a centred spectrum saves iterations
@@ -146,7 +182,11 @@ class NewtonSchulzSqrt:
         # residual is its square (quadratic convergence), so this bounds the final error
         res = 2.0 * torch.linalg.matrix_norm(T - eye) / (n ** 0.5)
         res = res * res
-        if gpu:
+        if capturing:
+            # a recording cannot hand data to the host: keep the residual in a tensor owned by
+            # the graph and let the driver look at it now and then (needs_more_iterations)
+            self._graph_residual = res
+        elif gpu:
             host = torch.empty(1, dtype=torch.float32, pin_memory=True)
             host.copy_(res.reshape(1), non_blocking=True)
             ev = torch.cuda.Event()

@@ -19,6 +19,9 @@ _native.register_hip_api({
     "evox_hip_gemm_f32": (I, [P, P, P, P, I, I, I, I64, I64, I64, I64, I, I, F, F, P]),
     "evox_hip_cma_sample": (I, [P, P, P, P, P, P, I, I, I64, P]),
     "evox_hip_cma_cov": (I, [P, P, P, P, P, P, P, P, F, F, P, I, I, I64, P, I, P]),
+    "evox_hip_cma_gather_scale": (I, [P, I64, P, P, P, P, P, I, P, I, I, I, P]),
+    "evox_hip_cma_affine": (I, [P, P, P, I64, I, P]),
+    "evox_hip_cma_paths": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P]),
 })
 
 
@@ -67,13 +70,39 @@ def matmul(a: torch.Tensor, b: torch.Tensor, **kw):
     return matmul_nt(a, b.T, **kw)
 
 
+def _sample_impl() -> str:
+    """How the sampling GEMM runs on the GPU.
+
+    ``library``  Z is drawn by the Philox kernel into a (λ, n) buffer, the product Z·(B∘d)ᵀ is a plain
+                 library GEMM and mean/σ are applied by one in-place pass.  Fastest measured form.
+    ``fused``    the hand-written MFMA kernel that draws Z inside its prologue (no Z buffer); it
+                 re-draws each Z tile once per column block of the output, which costs more than
+                 the buffer saves at n = 10³.
+    ``mfma``     Z buffer + the hand-written exact-fp32 MFMA GEMM."""
+    return os.environ.get("EVOX_AMD_CMA_SAMPLE", "library")
+
+
 def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0):
     n = mean.shape[0]
-    if _impl() == "torch" or precision == "bf16":
+    impl = "torch" if _impl() == "torch" else _sample_impl()
+    if impl == "torch":
         z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
         if precision == "bf16":
             return mean + sigma * ((z * D).bfloat16() @ B.T.bfloat16()).float()
         return mean + sigma * ((z * D) @ B.T)
+    if impl != "fused" or precision == "bf16":
+        z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
+        bd = B * D                                                # (n, n): column j of B scaled by d_j
+        if precision == "bf16":
+            g = torch.mm(z.bfloat16(), bd.bfloat16().T, out_dtype=torch.float32)
+        elif impl == "mfma":
+            g = matmul_nt(z, bd)
+        else:
+            g = torch.mm(z, bd.T)
+        sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
+        check(hip().evox_hip_cma_affine(g.data_ptr(), mean.contiguous().data_ptr(), sig.data_ptr(), pop_size, n,
+                                        stream_of(mean)), "cma_affine")
+        return g
     if tuple(B.shape) != (n, n) or D.shape[0] != n:
         raise ValueError("B must be (n, n) and D (n,)")
     B = B.contiguous()
@@ -83,6 +112,55 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
                                     B.data_ptr(), D.contiguous().data_ptr(), out.data_ptr(), pop_size, n,
                                     int(row_offset), stream_of(mean)), "cma_sample")
     return out
+
+
+def cma_elite_factor(pop, order, mean, sigma, sqrt_w, precision="fp32"):
+    """``(S, step)``: ``S[i] = sqrt(w_i) (x_{order[i]} − mean) / σ`` for the μ selected rows (fp32,
+    or bf16 when ``precision == "bf16"``) and the weighted mean shift ``step = Σ w_i (x_i − mean)``
+    (always accumulated in fp32 from the unrounded differences)."""
+    mu, n = sqrt_w.shape[0], mean.shape[0]
+    if pop.stride(1) != 1:
+        pop = pop.contiguous()
+    if order.dtype != torch.int64:
+        order = order.to(torch.int64)
+    dev = pop.device
+    sig = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(1)
+    bf16 = precision == "bf16"
+    out = torch.empty((mu, n), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
+    blocks = max(1, min(mu, 512))
+    colsum = torch.empty((blocks, n), dtype=torch.float32, device=dev)
+    check(hip().evox_hip_cma_gather_scale(pop.data_ptr(), pop.stride(0), order.contiguous().data_ptr(),
+                                          mean.contiguous().data_ptr(), sqrt_w.contiguous().data_ptr(), sig.data_ptr(),
+                                          out.data_ptr(), 1 if bf16 else 0, colsum.data_ptr(), blocks, mu, n,
+                                          stream_of(pop)), "cma_gather_scale")
+    return out, colsum.sum(0)
+
+
+def cma_paths(mean, step, whitened, ps, pc, sigma, iter_dev, consts):
+    """Fused path / step-size update (``csrc/cma_aux.hip``).  ``whitened = C^{-1/2} step``;
+    ``consts`` = (cs, cc, mueff, cm, damps, chiN, c1, cmu) as a host float array.
+    Returns ``(mean', ps', pc', sigma', alpha, hsig)`` — the last three as 0-d views."""
+    import ctypes
+
+    n = mean.shape[0]
+    dev = mean.device
+    mean_out, ps_out, pc_out = torch.empty_like(mean), torch.empty_like(ps), torch.empty_like(pc)
+    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    c_arr = (ctypes.c_float * 8)(*[float(v) for v in consts])
+    check(hip().evox_hip_cma_paths(mean.contiguous().data_ptr(), step.contiguous().data_ptr(),
+                                   whitened.contiguous().data_ptr(), ps.contiguous().data_ptr(), pc.contiguous().data_ptr(),
+                                   sigma.reshape(1).data_ptr(), iter_dev.reshape(1).data_ptr(), ctypes.addressof(c_arr), n,
+                                   mean_out.data_ptr(), ps_out.data_ptr(), pc_out.data_ptr(), scalars.data_ptr(),
+                                   stream_of(mean)), "cma_paths")
+    return mean_out, ps_out, pc_out, scalars[0], scalars[1], scalars[2]
+
+
+def cma_covariance_from_factor(C, S, pc, alpha, c1, cmu):
+    """``αC + c₁ pc pcᵀ + cμ SᵀS`` — one library GEMM with the scaled old matrix as its addend."""
+    base = torch.addr(C * alpha, pc, pc, alpha=float(c1))
+    if S.dtype == torch.bfloat16:
+        return base + float(cmu) * torch.mm(S.T, S, out_dtype=torch.float32)
+    return torch.addmm(base, S.T, S, alpha=float(cmu))
 
 
 def cma_covariance_update(C, pop, order, mean, sigma, weights, pc, alpha, c1, cmu, precision="fp32"):

@@ -213,13 +213,19 @@ class StdWorkflow(Workflow):
 
             if self.migrate_helper is not None or self.external_problem:
                 raise ValueError("graph_step cannot record host-side evaluation or migration")
-            self._graphed = GraphedStep(self._bare_step, host_counters=("fields/generation",))
+            extra = getattr(self.algorithm, "graph_host_counters", None)
+            counters = ["fields/generation"] + [f"children/algorithm/fields/{c}" for c in (extra() if extra else ())]
+            self._graphed = GraphedStep(self._bare_step, host_counters=counters)
         hooks = self.registered_hooks
         for m in hooks["pre_step"]:
             m.pre_step(state)
         for m in hooks["pre_ask"]:
             m.pre_ask(state)
         new_state, aux = self._graphed(state)
+        if self._graphed.replays % 64 == 0:
+            check = getattr(self.algorithm, "graph_check", None)
+            if check is not None and check():
+                self._graphed = None            # record again with the algorithm's updated settings
         for m in hooks["post_ask"]:
             m.post_ask(new_state, aux["cands"])
         for m in hooks["pre_eval"]:

@@ -20,11 +20,14 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_process_id(), dist.get_world_size()
     dim = 8
-    c = torch.full((dim,), 3.0)
-    lb, ub = torch.full((dim,), -10.0), torch.full((dim,), 10.0)
+    # EVOX_TEST_DEVICE=cuda: every rank computes on the one visible GPU while the collectives stay
+    # on gloo (device data is staged through host memory by evox_amd.core.distributed)
+    dev = torch.device(os.environ.get("EVOX_TEST_DEVICE", "cpu"))
+    c = torch.full((dim,), 3.0, device=dev)
+    lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}
     if case in ("cmaes", "openes", "pgpe", "pso_replicated"):
-        algo = {"cmaes": lambda: A.CMAES(c, 1.0, pop_size=16), "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
+        algo = {"cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")), "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
                 "pgpe": lambda: A.PGPE(16, c, "adam"), "pso_replicated": lambda: A.PSO(lb, ub, 16)}[case]()
         mon = monitors.EvalMonitor()
         wf = ShardedWorkflow(algo, problems.numerical.Ackley(), monitors=[mon])

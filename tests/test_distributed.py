@@ -18,13 +18,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch(case, world, tmp_path):
+def launch(case, world, tmp_path, extra_env=None):
     out = str(tmp_path / f"{case}_{world}.json")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), case, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
@@ -111,3 +111,17 @@ def test_process_distributed_workflow_cso():
         assert cands.shape[1] == 2
     finally:
         wf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cmaes", "openes"])
+def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
+    """The GPU code path of the row-sharded tell (gather kernel, Gram GEMM, fused path kernel): two
+    and four ranks share the one GPU of the test box and talk over gloo."""
+    env = {"EVOX_TEST_DEVICE": "cuda", "EVOX_TEST_DECOMP": "newton_schulz"}
+    base = launch(case, 1, tmp_path, env)[0]
+    for world in (2, 4):
+        res = launch(case, world, tmp_path, env)
+        for r in res:
+            assert r["row_sharded"] and r["world"] == world
+            assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)

@@ -101,3 +101,23 @@ def test_graphed_step_refuses_cpu_state():
     step = GraphedStep(lambda s: s)
     with pytest.raises(GraphCaptureError):
         step(ex.State(x=torch.zeros(3)))
+
+
+def test_every_registered_hip_entry_point_is_exported():
+    """The op wrappers declare their kernels' C entry points; each must exist in the built library
+    (catches a kernel that was declared in Python but never made it into a .hip file)."""
+    import ctypes
+    import importlib
+    import os
+
+    import pytest
+    from evox_amd import _native
+    for mod in ("gemm", "es", "_nds_hip", "moselect", "fitness", "swarm"):
+        importlib.import_module(f"evox_amd.ops.{mod}")
+    importlib.import_module("evox_amd.core.random")
+    path = os.path.join(os.path.dirname(_native.__file__), "libevox_hip.so")
+    if not os.path.exists(path):
+        pytest.skip("libevox_hip.so has not been built")
+    lib = ctypes.CDLL(path)
+    missing = [name for name in _native._HIP_API if not hasattr(lib, name)]
+    assert not missing, missing
