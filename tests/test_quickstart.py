@@ -33,3 +33,17 @@ def test_quickstart_gpu_matches_cpu_trajectory(cuda):
     b = s_cpu.get_child_state("algorithm")
     # same Philox stream on both sides: trajectories agree up to transcendental rounding
     assert torch.allclose(a.population.cpu(), b.population, atol=1e-2, rtol=1e-2)
+
+
+def test_examples_run():
+    """The scripts under examples/ are part of the documentation: they must run end to end."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    for name in ("pso_ackley.py",):
+        out = subprocess.run([sys.executable, os.path.join(root, "examples", name)], env=env, capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "best fitness" in out.stdout
