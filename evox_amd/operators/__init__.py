@@ -1,2 +1,2 @@
-from . import crossover, mutation, sampling, selection
+from . import crossover, gaussian_process, mutation, sampling, selection
 from .selection import crowding_distance, crowding_distance_sort, non_dominated_sort

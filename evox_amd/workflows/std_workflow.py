@@ -24,6 +24,7 @@ from ..core.algorithm import Algorithm, has_init_ask, has_init_tell
 from ..core.distributed import (POP_AXIS_NAME, all_gather, get_process_id, get_world_size, is_dist_initialized)
 from ..core.module import use_state
 from ..core.monitor import HOOK_NAMES, Monitor
+from ..utils import profiling as _prof
 from ..core.problem import Problem
 from ..core.state import State
 from ..core.struct import dataclass, pytree_field
@@ -143,7 +144,8 @@ class StdWorkflow(Workflow):
         for m in hooks["pre_ask"]:
             m.pre_ask(state)
 
-        cands, state = self._ask(state)
+        with _prof.scope("ask"):
+            cands, state = self._ask(state)
 
         for m in hooks["post_ask"]:
             m.post_ask(state, cands)
@@ -164,7 +166,8 @@ class StdWorkflow(Workflow):
         for m in hooks["pre_eval"]:
             m.pre_eval(state, cands, tcands)
 
-        fitness, state = self._evaluate(state, tcands)
+        with _prof.scope("evaluate"):
+            fitness, state = self._evaluate(state, tcands)
 
         for m in hooks["post_eval"]:
             m.post_eval(state, cands, tcands, fitness)
@@ -176,7 +179,8 @@ class StdWorkflow(Workflow):
         for m in hooks["pre_tell"]:
             m.pre_tell(state, cands, tcands, fitness, tfitness)
 
-        state = self._tell(state, tfitness)
+        with _prof.scope("tell"):
+            state = self._tell(state, tfitness)
         if aux is not None:
             aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
 

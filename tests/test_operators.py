@@ -124,3 +124,24 @@ def test_reference_vector_guided_selection():
     p, f = selection.ReferenceVectorGuided()(pop, fit, v, torch.tensor(0.5))
     assert p.shape == (v.shape[0], 5)
     assert torch.isfinite(f).all(1).sum() > 10
+
+
+def test_crowding_distance_against_loop_oracle():
+    """The reference pins a 128×8 case drawn with jax.random (``tests/test_crowding_distance.py:25-124``);
+    those bits cannot be regenerated here, so the same scenario is checked against an independent
+    loop implementation of the textbook definition."""
+    import numpy as np
+    g = torch.Generator().manual_seed(314)
+    x = torch.randn(128, 8, generator=g)
+    front = x[operators.non_dominated_sort(x) == 0]
+    got = operators.crowding_distance(front).numpy()
+    f = front.numpy().astype(np.float64)
+    n, m = f.shape
+    want = np.zeros(n)
+    for j in range(m):
+        order = np.argsort(f[:, j], kind="stable")
+        span = f[order[-1], j] - f[order[0], j]
+        want[order[0]] = want[order[-1]] = np.inf
+        for k in range(1, n - 1):
+            want[order[k]] += (f[order[k + 1], j] - f[order[k - 1], j]) / span
+    np.testing.assert_allclose(got, want, rtol=1e-5)
