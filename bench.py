@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearsal of the multi-process path over gloo (not a benchmark)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
+                         "rehearses the multi-rank path on a single GPU")
     args = ap.parse_args()
 
     import torch
@@ -54,10 +57,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     on_gpu = args.device == "cuda"
     if world > 1:
-        dist.init_process_group("nccl" if on_gpu else "gloo")
+        dist.init_process_group(args.backend or ("nccl" if on_gpu else "gloo"))
     rank = dist.get_process_id()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if on_gpu:
+        local = local % max(torch.cuda.device_count(), 1)
         dev = torch.device("cuda", local)
         torch.cuda.set_device(dev)
     else:

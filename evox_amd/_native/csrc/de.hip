@@ -1,0 +1,114 @@
+// Differential-evolution variation in one pass: parent picks, mutation, binomial crossover, bounds.
+//
+//   picks   k distinct indices != row, drawn like evox_amd.core.random.choice_distinct:
+//           r_j = mulhi(bits(key_sel, row * k + j), N - 1 - j), shifted past the already taken values
+//           in ascending order (exact sampling without replacement, O(k^2) per row, k <= 9)
+//   base    primary / secondary base vectors: rand (= pick 0), best, pbest (given row), current
+//   mutant  p + F (s - p) + F * sum_t (x[pick 2t+1] - x[pick 2t+2])
+//   trial   mutant where u(key_mask, row * D + c) < CR or c == jrand(key_jrand, row), else current;
+//           clipped to [lb, ub]
+//
+// The random numbers are the same Philox elements the PyTorch formulation draws, so both produce the
+// same trial vectors (up to floating-point association).  A row is handled by LPR lanes of a
+// wavefront (coalesced row gathers); the picks are recomputed by each lane - a few dozen integer ops.
+#include "hip_common.h"
+#include "philox.h"
+
+using namespace evox;
+
+namespace {
+
+constexpr int kMaxPicks = 9;
+enum Base { kRand = 0, kBest = 1, kPbest = 2, kCurrent = 3 };
+
+__device__ __forceinline__ uint32_t bits_at(uint32_t k0, uint32_t k1, uint64_t e) {
+  const u32x4 b = philox_block(k0, k1, e >> 2, kStreamDraw);
+  switch ((int)(e & 3)) { case 0: return b.x; case 1: return b.y; case 2: return b.z; default: return b.w; }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void de_trial_kernel(
+    const float* __restrict__ pop, int64_t ldpop, int n_pop, int dim, const int64_t* __restrict__ rows, int b,
+    const int64_t* __restrict__ best_index, const int64_t* __restrict__ pbest_rows, const float* __restrict__ F, int f_is_vec,
+    const float* __restrict__ CR, int cr_is_vec, int prim, int sec, int num_diff, int n_picks,
+    const int32_t* __restrict__ key_sel, const int32_t* __restrict__ key_jrand, const int32_t* __restrict__ key_mask,
+    const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out) {
+  constexpr int RPB = 256 / LPR;                       // rows per block
+  const int sub = threadIdx.x % LPR;
+  const int r = blockIdx.x * RPB + threadIdx.x / LPR;
+  if (r >= b) return;
+  const int64_t self = rows ? rows[r] : r;
+
+  // ---- distinct picks (ascending list `taken` starts with the row itself) -------------------
+  const uint32_t s0 = (uint32_t)key_sel[0], s1 = (uint32_t)key_sel[1];
+  int picks[kMaxPicks];
+  int taken[kMaxPicks + 1];
+  taken[0] = (int)self;
+  int n_taken = 1;
+  for (int j = 0; j < n_picks; ++j) {
+    const uint32_t m = (uint32_t)(n_pop - 1 - j);
+    int v = (int)bits_to_range(bits_at(s0, s1, (uint64_t)r * n_picks + j), m);
+    for (int t = 0; t < n_taken; ++t) v += (v >= taken[t]) ? 1 : 0;
+    picks[j] = v;
+    int pos = n_taken;                                 // insert, keeping `taken` ascending
+    while (pos > 0 && taken[pos - 1] > v) { taken[pos] = taken[pos - 1]; --pos; }
+    taken[pos] = v;
+    ++n_taken;
+  }
+
+  const uint32_t j0 = (uint32_t)key_jrand[0], j1 = (uint32_t)key_jrand[1];
+  const int jrand = (int)bits_to_range(bits_at(j0, j1, (uint64_t)r), (uint32_t)dim);
+  const uint32_t m0 = (uint32_t)key_mask[0], m1 = (uint32_t)key_mask[1];
+  const float f = f_is_vec ? F[r] : F[0];
+  const float cr = cr_is_vec ? CR[r] : CR[0];
+
+  auto base_row = [&](int code) -> const float* {
+    switch (code) {
+      case kRand: return pop + (int64_t)picks[0] * ldpop;
+      case kBest: return pop + best_index[0] * ldpop;
+      case kPbest: return pop + pbest_rows[r] * ldpop;
+      default: return pop + self * ldpop;
+    }
+  };
+  const float* p_row = base_row(prim);
+  const float* s_row = base_row(sec);
+  const float* cur = pop + self * ldpop;
+  const float* d1a = pop + (int64_t)picks[1] * ldpop;
+  const float* d1b = pop + (int64_t)picks[2] * ldpop;
+  const float* d2a = num_diff > 1 ? pop + (int64_t)picks[3] * ldpop : cur;
+  const float* d2b = num_diff > 1 ? pop + (int64_t)picks[4] * ldpop : cur;
+
+  for (int c = sub; c < dim; c += LPR) {
+    const float p = p_row[c];
+    float diff = d1a[c] - d1b[c];
+    if (num_diff > 1) diff = diff + (d2a[c] - d2b[c]);
+    const float mutant = p + f * (s_row[c] - p) + f * diff;
+    const float u = bits_to_unit(bits_at(m0, m1, (uint64_t)r * dim + c));
+    const float x = (u < cr || c == jrand) ? mutant : cur[c];
+    out[(int64_t)r * dim + c] = fminf(fmaxf(x, lb[c]), ub[c]);
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int dim, const int64_t* rows, int b,
+                               const int64_t* best_index, const int64_t* pbest_rows, const float* F, int f_is_vec,
+                               const float* CR, int cr_is_vec, int prim, int sec, int num_diff, int n_picks,
+                               const int32_t* key_sel, const int32_t* key_jrand, const int32_t* key_mask, const float* lb,
+                               const float* ub, float* out, void* stream) {
+  if (b <= 0 || dim <= 0) return 0;
+  if (n_picks > kMaxPicks || n_picks < 2 * num_diff + 1 || num_diff < 1 || num_diff > 2 || n_pop <= n_picks)
+    return (int)hipErrorInvalidValue;
+  if ((prim == kPbest || sec == kPbest) && pbest_rows == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+#define EVOX_DE_LAUNCH(LPR)                                                                                            \
+  de_trial_kernel<LPR><<<(b + 256 / LPR - 1) / (256 / LPR), 256, 0, s>>>(                                              \
+      pop, ldpop, n_pop, dim, rows, b, best_index, pbest_rows, F, f_is_vec, CR, cr_is_vec, prim, sec, num_diff, n_picks, \
+      key_sel, key_jrand, key_mask, lb, ub, out)
+  if (dim <= 8) EVOX_DE_LAUNCH(8);
+  else if (dim <= 16) EVOX_DE_LAUNCH(16);
+  else if (dim <= 32) EVOX_DE_LAUNCH(32);
+  else EVOX_DE_LAUNCH(64);
+#undef EVOX_DE_LAUNCH
+  return last_launch_status();
+}

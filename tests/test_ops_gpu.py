@@ -333,3 +333,24 @@ def test_cmaes_graph_step_matches_eager(cuda):
     ae, ag = se.get_child_state("algorithm"), sg.get_child_state("algorithm")
     assert ae.count_iter == ag.count_iter == 10 and ae.count_eigen == ag.count_eigen
     torch.testing.assert_close(ae.C, ag.C, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("algo_name,dim,pop", [("SHADE", 20, 5000), ("JaDE", 7, 300), ("DE_rand", 33, 1000),
+                                               ("DE_best2", 100, 500)])
+def test_de_trial_kernel_matches_batched_formulation(cuda, algo_name, dim, pop, monkeypatch):
+    import evox_amd as ex
+    from evox_amd import algorithms
+    from evox_amd.ops import de as de_ops
+    lb, ub = torch.full((dim,), -5.0, device=cuda), torch.full((dim,), 5.0, device=cuda)
+    make = {"SHADE": lambda: algorithms.SHADE(lb, ub, pop), "JaDE": lambda: algorithms.JaDE(lb, ub, pop),
+            "DE_rand": lambda: algorithms.DE(lb, ub, pop, base_vector="rand", num_difference_vectors=1),
+            "DE_best2": lambda: algorithms.DE(lb, ub, pop, base_vector="best", num_difference_vectors=2)}[algo_name]
+    algo = make()
+    state = algo.init(ex.PRNGKey(4))
+    state = state.replace(fitness=torch.rand(pop, device=cuda))
+    fused, _ = algo.ask(state)
+    monkeypatch.setattr(de_ops, "supported", lambda *a, **k: False)
+    plain, _ = algo.ask(state)
+    assert fused.shape == plain.shape and fused.shape[1] == dim      # DE varies a window of batch_size rows
+    torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-5)
+    assert (fused >= -5).all() and (fused <= 5).all()
