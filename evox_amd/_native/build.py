@@ -34,6 +34,7 @@ HIP_FLAGS = [
     "-fPIC",
     "-fvisibility=hidden",
     "-Wno-unused-result",
+    "-Wno-unused-value",
     # keep hipcc from forming packed-fp32 VALU ops out of scalar float code
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]

@@ -1,0 +1,468 @@
+// Direct hipBLASLt dispatch with cached, timed plans, and the native driver of the coupled
+// Newton–Schulz square-root iteration that is built on it.
+//
+// Why not the tensor library's matmul: its host path costs 13–26 µs per product (descriptor
+// construction, heuristic cache lookup, allocator traffic).  The CMA-ES generation at
+// λ=10⁴, n=10³ issues ~30 GEMMs of 20–200 µs, so that dispatch cost — not the matrix cores —
+// bounded the step.  Here a plan (descriptors + algorithm) is built once per shape, the
+// candidate algorithms the heuristic returns are timed on the device once, and a product
+// afterwards costs one hipblasLtMatmul call.
+//
+// The library is not linked: the process already holds one hipBLASLt (the tensor library's),
+// and a second copy from another ROCm release must not be mixed in.  evox_hip_blas_init()
+// receives the path of the copy to use and resolves the entry points with dlsym.
+#include <dlfcn.h>
+#include <hipblaslt/hipblaslt.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "hip_common.h"
+
+namespace {
+
+struct LtApi {
+  void* lib = nullptr;
+  decltype(&hipblasLtCreate) create = nullptr;
+  decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
+  decltype(&hipblasLtMatmulDescSetAttribute) desc_set = nullptr;
+  decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
+  decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
+  decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
+  decltype(&hipblasLtMatmulPreferenceDestroy) pref_destroy = nullptr;
+  decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
+  decltype(&hipblasLtMatmul) matmul = nullptr;
+};
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+  int candidates = 0;
+  float best_us = -1.f;
+};
+
+struct Key {
+  int64_t v[11];
+  bool operator==(const Key& o) const { return std::memcmp(v, o.v, sizeof(v)) == 0; }
+};
+struct KeyHash {
+  size_t operator()(const Key& k) const {
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < 11; ++i) { h ^= (uint64_t)k.v[i]; h *= 1099511628211ull; }
+    return (size_t)h;
+  }
+};
+
+constexpr int kMaxDev = 16;
+constexpr size_t kWorkspace = 64ull << 20;
+
+LtApi g_lt;
+std::mutex g_mu;
+hipblasLtHandle_t g_handle[kMaxDev] = {};
+void* g_ws[kMaxDev] = {};
+std::unordered_map<Key, Plan, KeyHash> g_plans[kMaxDev];
+
+template <class F>
+bool resolve(F& slot, const char* name) {
+  slot = (F)dlsym(g_lt.lib, name);
+  return slot != nullptr;
+}
+
+int ensure_device(int dev) {
+  if (dev < 0 || dev >= kMaxDev) return (int)hipErrorInvalidDevice;
+  if (!g_handle[dev]) {
+    if (g_lt.create(&g_handle[dev]) != HIPBLAS_STATUS_SUCCESS) return (int)hipErrorUnknown;
+    hipError_t e = hipMalloc(&g_ws[dev], kWorkspace);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// Row-major D(M×N) = alpha·op(A)·op(B) + beta·C is issued as the column-major product
+// Dᵀ = op(B)ᵀ·op(A)ᵀ: a row-major matrix IS its transpose in column-major storage, so the
+// operands only swap places and keep their transposition flags.
+int make_plan(int dev, const Key& key, int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+              int64_t lda, int64_t ldb, int64_t ldc, int64_t ldd, bool has_bias, bool dev_scalars, Plan& p) {
+  hipDataType in_t = in_dtype == 1 ? HIP_R_16BF : HIP_R_32F;
+  if (g_lt.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return (int)hipErrorUnknown;
+  int32_t opA = transB ? HIPBLAS_OP_T : HIPBLAS_OP_N;   // library's A is our B
+  int32_t opB = transA ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+  g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opA, sizeof(opA));
+  g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opB, sizeof(opB));
+  // stored shapes (column-major): our B row-major (K×N | N×K if transB) is (N×K | K×N)
+  bool ok = true;
+  ok &= g_lt.layout_create(&p.a, in_t, transB ? K : N, transB ? N : K, ldb) == HIPBLAS_STATUS_SUCCESS;
+  ok &= g_lt.layout_create(&p.b, in_t, transA ? M : K, transA ? K : M, lda) == HIPBLAS_STATUS_SUCCESS;
+  ok &= g_lt.layout_create(&p.c, HIP_R_32F, N, M, ldc) == HIPBLAS_STATUS_SUCCESS;
+  ok &= g_lt.layout_create(&p.d, HIP_R_32F, N, M, ldd) == HIPBLAS_STATUS_SUCCESS;
+  if (!ok) return (int)hipErrorUnknown;
+  if (has_bias) {
+    // bias of length N (our columns = the library's rows of D), added to every row of our D
+    uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    int32_t bias_t = HIP_R_32F;
+    ok &= g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS;
+    ok &= g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bias_t, sizeof(bias_t)) == HIPBLAS_STATUS_SUCCESS;
+  }
+  if (dev_scalars) {
+    // alpha: device vector with one scale per row of the library's D (= per column of ours)
+    int32_t mode = HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST;
+    ok &= g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_POINTER_MODE, &mode, sizeof(mode)) == HIPBLAS_STATUS_SUCCESS;
+  }
+  if (!ok) return (int)hipErrorNotSupported;
+  (void)key;
+  (void)dev;
+  return 0;
+}
+
+int pick_algorithm(int dev, Plan& p, int tune, int64_t M, int64_t N, const void* alpha, const void* A, const void* B,
+                   const void* beta, const void* C, hipStream_t stream) {
+  hipblasLtMatmulPreference_t pref;
+  if (g_lt.pref_create(&pref) != HIPBLAS_STATUS_SUCCESS) return (int)hipErrorUnknown;
+  uint64_t ws = kWorkspace;
+  g_lt.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws));
+  constexpr int kReq = 32;
+  hipblasLtMatmulHeuristicResult_t res[kReq];
+  int got = 0;
+  hipblasStatus_t st = g_lt.heuristic(g_handle[dev], p.desc, p.a, p.b, p.c, p.d, pref, kReq, res, &got);
+  g_lt.pref_destroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || got <= 0) return (int)hipErrorNotSupported;
+  p.candidates = got;
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  hipStreamIsCapturing(stream, &cap);
+  if (!tune || got == 1 || cap != hipStreamCaptureStatusNone) return 0;
+  // time every candidate into a scratch output (the caller's D may alias C)
+  float* scratch = nullptr;
+  if (hipMalloc((void**)&scratch, sizeof(float) * (size_t)M * (size_t)N) != hipSuccess) return 0;
+  hipblasLtMatrixLayout_t dl = nullptr;
+  if (g_lt.layout_create(&dl, HIP_R_32F, N, M, N) != HIPBLAS_STATUS_SUCCESS) { hipFree(scratch); return 0; }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float best = 1e30f;
+  const bool verbose = getenv("EVOX_AMD_BLAS_VERBOSE") != nullptr;
+  for (int i = 0; i < got; ++i) {
+    if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kWorkspace) continue;
+    bool fine = true;
+    for (int w = 0; w < 2 && fine; ++w)
+      fine = g_lt.matmul(g_handle[dev], p.desc, alpha, B, p.a, A, p.b, beta, C, p.c, scratch, dl, &res[i].algo,
+                         g_ws[dev], kWorkspace, stream) == HIPBLAS_STATUS_SUCCESS;
+    if (!fine) continue;
+    constexpr int kRuns = 10;
+    hipEventRecord(e0, stream);
+    for (int r = 0; r < kRuns; ++r)
+      g_lt.matmul(g_handle[dev], p.desc, alpha, B, p.a, A, p.b, beta, C, p.c, scratch, dl, &res[i].algo, g_ws[dev],
+                  kWorkspace, stream);
+    hipEventRecord(e1, stream);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    if (verbose) fprintf(stderr, "[evox blas] M=%ld N=%ld candidate %d: %.1f us (workspace %zu)\n", (long)M, (long)N, i, ms * 1000.f / kRuns, res[i].workspaceSize);
+    if (ms < best) { best = ms; p.algo = res[i].algo; p.ws = res[i].workspaceSize; }
+  }
+  p.best_us = best < 1e29f ? best * 1000.f / 10.f : -1.f;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipStreamSynchronize(stream);
+  hipFree(scratch);
+  return 0;
+}
+
+// bias (optional): fp32 vector of length N added to every row of D.  alpha_dev (optional): a
+// device vector of N per-column scales that replaces `alpha` (read when the kernel runs).
+int gemm(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const void* A,
+         int64_t lda, const void* B, int64_t ldb, float beta, const float* C, int64_t ldc, float* D, int64_t ldd,
+         int tune, hipStream_t stream, const float* bias = nullptr, const float* alpha_dev = nullptr) {
+  if (!g_lt.matmul) return (int)hipErrorNotInitialized;
+  if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  int e = ensure_device(dev);
+  if (e) return e;
+  const void* pa = alpha_dev ? (const void*)alpha_dev : (const void*)&alpha;
+  const void* pb = (const void*)&beta;
+  const int64_t flags = (int64_t)(beta != 0.f) | ((int64_t)(C != D) << 1) | ((int64_t)(bias != nullptr) << 2) |
+                        ((int64_t)(alpha_dev != nullptr) << 3);
+  Key key{{in_dtype, transA, transB, M, N, K, lda, ldb, ldc, ldd, flags}};
+  auto it = g_plans[dev].find(key);
+  if (it == g_plans[dev].end()) {
+    Plan p;
+    e = make_plan(dev, key, in_dtype, transA, transB, M, N, K, lda, ldb, ldc, ldd, bias != nullptr,
+                  alpha_dev != nullptr, p);
+    if (e) return e;
+    if (bias) g_lt.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+    e = pick_algorithm(dev, p, tune, M, N, pa, A, B, pb, C, stream);
+    if (e) return e;
+    it = g_plans[dev].emplace(key, p).first;
+  }
+  Plan* plan = &it->second;
+  if (bias) g_lt.desc_set(plan->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias));
+  hipblasStatus_t st = g_lt.matmul(g_handle[dev], plan->desc, pa, B, plan->a, A, plan->b, pb, C, plan->c, D, plan->d,
+                                   &plan->algo, g_ws[dev], kWorkspace, stream);
+  return st == HIPBLAS_STATUS_SUCCESS ? 0 : 1000 + (int)st;
+}
+
+// ---------------------------------------------------------------------------------------
+// Newton–Schulz helper kernels
+// ---------------------------------------------------------------------------------------
+// scal: float[kScalFloats].  [13] scale s, [14] residual, [15] 1 if the guarded outputs were
+// replaced; from [16] on, rows of 256 per-block partial results (no atomics: a thousand waves
+// adding into one address serialise for tens of µs, while every later kernel can re-reduce
+// 256 partials in its prologue for nothing):
+//   rows 0..7 ‖w_j‖² of the power steps, row 8 max row-abs-sum, row 9 Σ diag, row 10 Σ (T−I)²
+constexpr int kMaxPow = 8, kPartRow = 256, kRowInf = 8, kRowDiag = 9, kRowRes = 10;
+constexpr int kScalFloats = 16 + 11 * kPartRow;
+__device__ __forceinline__ float* part_row(float* scal, int k) { return scal + 16 + k * kPartRow; }
+__device__ __forceinline__ const float* part_row(const float* scal, int k) { return scal + 16 + k * kPartRow; }
+
+// every thread of a 256-thread block receives the sum / max of `count` (≤ 256) partials
+__device__ __forceinline__ float block_reduce(const float* parts, int count, bool take_max, float* red) {
+  float v = (int)threadIdx.x < count ? parts[threadIdx.x] : 0.f;
+  v = take_max ? evox::wave_max(v) : evox::wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return take_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one wave per row: w = C·(v/‖v‖); the first step also collects ‖C‖∞ and the trace
+__global__ __launch_bounds__(256) void ns_matvec_kernel(const float* __restrict__ C, int n,
+                                                        const float* __restrict__ vin, float* __restrict__ vout,
+                                                        float* scal, int step) {
+  __shared__ float red[4];
+  __shared__ float wsq[4], wmx[4], wdg[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float inv = 1.f;
+  if (step > 0) inv = rsqrtf(fmaxf(block_reduce(part_row(scal, step - 1), gridDim.x, false, red), 1e-38f));
+  float sq = 0.f, mx = 0.f, dg = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+    const float* r = C + (size_t)row * n;
+    float acc = 0.f, asum = 0.f;
+    if ((n & 3) == 0) {                              // rows are 16-byte aligned: four columns per load
+      const float4* r4 = reinterpret_cast<const float4*>(r);
+      const float4* v4 = reinterpret_cast<const float4*>(vin);
+      for (int j = lane; j < (n >> 2); j += 64) {
+        const float4 c = r4[j], v = v4[j];
+        acc += (c.x * v.x + c.y * v.y) + (c.z * v.z + c.w * v.w);
+        asum += (fabsf(c.x) + fabsf(c.y)) + (fabsf(c.z) + fabsf(c.w));
+      }
+    } else {
+      for (int j = lane; j < n; j += 64) {
+        const float c = r[j];
+        acc += c * vin[j];
+        asum += fabsf(c);
+      }
+    }
+    acc = evox::wave_sum(acc) * inv;
+    if (lane == 0) vout[row] = acc;
+    sq += acc * acc;
+    if (step == 0) {
+      mx = fmaxf(mx, evox::wave_sum(asum));
+      dg += r[row];
+    }
+  }
+  if (lane == 0) { wsq[wave] = sq; wmx[wave] = mx; wdg[wave] = dg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part_row(scal, step)[blockIdx.x] = (wsq[0] + wsq[1]) + (wsq[2] + wsq[3]);
+    if (step == 0) {
+      part_row(scal, kRowInf)[blockIdx.x] = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+      part_row(scal, kRowDiag)[blockIdx.x] = (wdg[0] + wdg[1]) + (wdg[2] + wdg[3]);
+    }
+  }
+}
+
+// Y0 = C/s, T = 1.5 I − 0.5 Y0; block 0 also stores s and the normalised power vector.
+// safe: s = max(tr C/n, ‖C‖∞/1.9) (spectrum of Y0 provably inside (0, 1.9]); otherwise s is the
+// power-iteration estimate ‖C v‖ (‖v‖ = 1), which never exceeds λmax — iterates with eigenvalues
+// up to 3 still converge, so an under-estimate by less than that factor is harmless.
+__global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__ C, int n, float* __restrict__ Y,
+                                                       float* __restrict__ T, float* scal, float* vec, int steps,
+                                                       int safe, int mv_blocks) {
+  __shared__ float red[4];
+  const float inf_norm = block_reduce(part_row(scal, kRowInf), mv_blocks, true, red);
+  const float trace = block_reduce(part_row(scal, kRowDiag), mv_blocks, false, red);
+  const float last = block_reduce(part_row(scal, steps - 1), mv_blocks, false, red);
+  const float safe_s = fmaxf(trace / (float)n, inf_norm / 1.9f);
+  const float lam = sqrtf(last) * 1.02f;
+  const float s = (!safe && lam > 0.f && lam < 3.0e38f) ? fminf(lam, safe_s * 1.9f) : safe_s;
+  const float is = 1.f / s;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float y = C[i] * is;
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    Y[i] = y;
+    T[i] = (r == c ? 1.5f : 0.f) - 0.5f * y;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) scal[13] = s;
+    const float* w = vec + (steps & 1) * n;        // step j writes buffer (j+1)&1
+    const float inv = rsqrtf(fmaxf(last, 1e-38f));
+    for (int j = threadIdx.x; j < n; j += blockDim.x) vec[j] = w[j] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void ns_residual_kernel(const float* __restrict__ T, int n, float* scal) {
+  const int64_t total = (int64_t)n * n;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    const float d = T[i] - (r == c ? 1.f : 0.f);
+    acc += d * d;
+  }
+  acc = evox::wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part_row(scal, kRowRes)[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// sqrtC = ½(Y+Yᵀ)√s, invsqrtC = ½(Z+Zᵀ)/√s through 32×32 LDS tiles; when the residual shows the
+// iteration has not contracted (or is not finite) the previous factors are passed on instead
+__global__ __launch_bounds__(256) void ns_finish_kernel(const float* __restrict__ Y, const float* __restrict__ Z, int n,
+                                                        float* scal, const float* __restrict__ prev_sqrt,
+                                                        const float* __restrict__ prev_inv, float* __restrict__ out_sqrt,
+                                                        float* __restrict__ out_inv, int res_blocks) {
+  __shared__ float ty[32][33], tz[32][33];
+  __shared__ float red[4];
+  const float res = 4.f * block_reduce(part_row(scal, kRowRes), res_blocks, false, red) / (float)n;  // (2‖T−I‖_F/√n)²
+  const bool good = res < 0.25f;                       // also false for NaN
+  const bool keep = !good && prev_sqrt != nullptr;
+  const float s = scal[13];
+  const float rs = sqrtf(s), irs = 1.f / rs;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, tyi = threadIdx.x >> 5;   // 32 × 8
+  for (int k = tyi; k < 32; k += 8) {
+    const int r = bx + k, c = by + tx;                 // the mirrored tile
+    if (r < n && c < n) {
+      ty[k][tx] = Y[(size_t)r * n + c];
+      tz[k][tx] = Z[(size_t)r * n + c];
+    }
+  }
+  __syncthreads();
+  for (int k = tyi; k < 32; k += 8) {
+    const int r = by + k, c = bx + tx;
+    if (r < n && c < n) {
+      const size_t i = (size_t)r * n + c;
+      if (keep) {
+        out_sqrt[i] = prev_sqrt[i];
+        out_inv[i] = prev_inv[i];
+      } else {
+        out_sqrt[i] = 0.5f * (Y[i] + ty[tx][k]) * rs;
+        out_inv[i] = 0.5f * (Z[i] + tz[tx][k]) * irs;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    scal[14] = res;
+    scal[15] = keep ? 1.f : 0.f;
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_blas_init(const char* path) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_lt.matmul) return 0;
+  g_lt.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!g_lt.lib) return 1;
+  bool ok = true;
+  ok &= resolve(g_lt.create, "hipblasLtCreate");
+  ok &= resolve(g_lt.desc_create, "hipblasLtMatmulDescCreate");
+  ok &= resolve(g_lt.desc_set, "hipblasLtMatmulDescSetAttribute");
+  ok &= resolve(g_lt.layout_create, "hipblasLtMatrixLayoutCreate");
+  ok &= resolve(g_lt.pref_create, "hipblasLtMatmulPreferenceCreate");
+  ok &= resolve(g_lt.pref_set, "hipblasLtMatmulPreferenceSetAttribute");
+  ok &= resolve(g_lt.pref_destroy, "hipblasLtMatmulPreferenceDestroy");
+  ok &= resolve(g_lt.heuristic, "hipblasLtMatmulAlgoGetHeuristic");
+  decltype(&hipblasLtMatmul) mm = nullptr;
+  ok &= resolve(mm, "hipblasLtMatmul");
+  if (!ok) return 2;
+  g_lt.matmul = mm;
+  return 0;
+}
+
+// in_dtype: 0 = fp32 operands, 1 = bf16 operands (fp32 accumulate and output either way)
+EVOX_API int evox_hip_gemm(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha,
+                           const void* A, int64_t lda, const void* B, int64_t ldb, float beta, const float* C,
+                           int64_t ldc, float* D, int64_t ldd, const float* bias, const float* alpha_dev, int tune,
+                           void* stream) {
+  return gemm(in_dtype, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C ? C : D, C ? ldc : ldd, D, ldd, tune,
+              (hipStream_t)stream, bias, alpha_dev);
+}
+
+// info[0] = number of candidate algorithms, info[1] = best timed µs (−1 when not timed)
+EVOX_API int evox_hip_gemm_plan_info(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K,
+                                     int64_t lda, int64_t ldb, int64_t ldc, int64_t ldd, int flags, float* info) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(g_mu);
+  Key key{{in_dtype, transA, transB, M, N, K, lda, ldb, ldc, ldd, (int64_t)flags}};
+  auto it = g_plans[dev].find(key);
+  if (it == g_plans[dev].end()) return 1;
+  info[0] = (float)it->second.candidates;
+  info[1] = it->second.best_us;
+  return 0;
+}
+
+// Coupled Newton–Schulz iteration for C^{±1/2} (C symmetric positive definite, n×n, dense):
+//   Y₀ = C/s, Z₀ = I;  T = (3I − Z Y)/2;  Y ← Y T;  Z ← T Z
+// work: 6·n² floats (Y, Z, T ping-pong); eye: n×n identity; vec: 2n floats, vec[0:n] holds the
+// unit power-iteration vector carried between calls; scal: evox_hip_ns_scal_floats() floats.
+// power_steps matvecs refine the λmax estimate that sets s; safe != 0 uses the norm bound
+// max(tr C/n, ‖C‖∞/1.9) instead (always convergent, more iterations).
+EVOX_API int evox_hip_ns_scal_floats() { return kScalFloats; }
+
+EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps, int safe, float* work,
+                              const float* eye, float* vec, float* scal, const float* prev_sqrt,
+                              const float* prev_inv, float* out_sqrt, float* out_inv, int tune, void* stream_) {
+  if (n <= 0 || iters < 1 || power_steps < 1 || power_steps > kMaxPow) return (int)hipErrorInvalidValue;
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nn = (size_t)n * n;
+  float* Yb[2] = {work, work + nn};
+  float* Zb[2] = {work + 2 * nn, work + 3 * nn};
+  float* Tb[2] = {work + 4 * nn, work + 5 * nn};
+  int mv_blocks = (n + 3) / 4;
+  if (mv_blocks > kPartRow) mv_blocks = kPartRow;
+  for (int j = 0; j < power_steps; ++j)
+    ns_matvec_kernel<<<mv_blocks, 256, 0, stream>>>(C, n, vec + (j & 1) * n, vec + ((j + 1) & 1) * n, scal, j);
+  ns_scale_kernel<<<evox::stream_grid((int64_t)nn, 256), 256, 0, stream>>>(C, n, Yb[0], Tb[0], scal, vec, power_steps,
+                                                                            safe, mv_blocks);
+  int e = evox::last_launch_status();
+  if (e) return e;
+  // iteration 1 with Z₀ = I: Y₁ = Y₀ T, Z₁ = T
+  e = gemm(0, 0, 0, n, n, n, 1.f, Yb[0], n, Tb[0], n, 0.f, Yb[1], n, Yb[1], n, tune, stream);
+  if (e) return e;
+  const float* Y = Yb[1];
+  const float* Z = Tb[0];
+  const float* Tlast = Tb[0];
+  int yi = 0, zi = 0;
+  for (int it = 1; it < iters; ++it) {
+    float* Tn = Tb[it & 1];
+    e = gemm(0, 0, 0, n, n, n, -0.5f, Z, n, Y, n, 1.5f, eye, n, Tn, n, tune, stream);
+    if (e) return e;
+    float* Yn = Yb[yi];
+    float* Zn = Zb[zi];
+    e = gemm(0, 0, 0, n, n, n, 1.f, Y, n, Tn, n, 0.f, Yn, n, Yn, n, tune, stream);
+    if (e) return e;
+    e = gemm(0, 0, 0, n, n, n, 1.f, Tn, n, Z, n, 0.f, Zn, n, Zn, n, tune, stream);
+    if (e) return e;
+    Y = Yn; Z = Zn; Tlast = Tn;
+    yi ^= 1; zi ^= 1;
+  }
+  int res_blocks = evox::stream_grid((int64_t)nn, 256);
+  if (res_blocks > kPartRow) res_blocks = kPartRow;
+  ns_residual_kernel<<<res_blocks, 256, 0, stream>>>(Tlast, n, scal);
+  dim3 grid((n + 31) / 32, (n + 31) / 32);
+  ns_finish_kernel<<<grid, 256, 0, stream>>>(Y, Z, n, scal, prev_sqrt, prev_inv, out_sqrt, out_inv, res_blocks);
+  return evox::last_launch_status();
+}

@@ -124,6 +124,27 @@ EVOX_API int evox_hip_cma_gather_scale(const float* pop, int64_t ldpop, const in
   return last_launch_status();
 }
 
+namespace {
+// base = alpha·C + c1·pc pcᵀ (alpha on the device: it depends on the stall indicator)
+__global__ __launch_bounds__(256) void cov_base_kernel(const float* __restrict__ C, const float* __restrict__ pc,
+                                                       const float* __restrict__ alpha, float c1,
+                                                       float* __restrict__ out, int n) {
+  const float a = alpha[0];
+  const int64_t total = (int64_t)n * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    out[i] = a * C[i] + c1 * pc[r] * pc[c];
+  }
+}
+}  // namespace
+
+EVOX_API int evox_hip_cma_cov_base(const float* C, const float* pc, const float* alpha, float c1, float* out, int n,
+                                   void* stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  cov_base_kernel<<<evox::stream_grid((int64_t)n * n, 256), 256, 0, (hipStream_t)stream>>>(C, pc, alpha, c1, out, n);
+  return evox::last_launch_status();
+}
+
 EVOX_API int evox_hip_cma_affine(float* x, const float* mean, const float* sigma, int64_t rows, int n, void* stream) {
   if (rows <= 0 || n <= 0) return 0;
   affine_kernel<<<stream_grid(rows * n, 256), 256, 0, (hipStream_t)stream>>>(x, mean, sigma, rows, n);

@@ -120,9 +120,14 @@ class CMAES(Algorithm):
         Newton–Schulz iteration count frozen in the graph no longer reaches the tolerance)."""
         return self._ns is not None and self._ns.needs_more_iterations()
 
+    def _sample_scale(self, state):
+        # the Newton–Schulz mode stores the whole factor C^{1/2} in B and leaves D at ones
+        return None if self._ns is not None else state.D
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
-        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, self.pop_size, self.precision)
+        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), self.pop_size,
+                                 self.precision)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
@@ -161,7 +166,7 @@ class CMAES(Algorithm):
                                        alpha, self.c1, self.cmu, self.precision)
         if state.count_iter % self.decomp_per_iter == 0:
             if self._ns is not None:
-                B, invsqrtC = self._ns(C)
+                B, invsqrtC = self._ns(C, prev=(state.B, state.invsqrtC))
                 D = state.D
             else:
                 B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
@@ -184,7 +189,7 @@ class CMAES(Algorithm):
             raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
         local = self.pop_size // world
         key, sample_key = rnd.split(state.key)
-        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, state.D, local, self.precision,
+        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), local, self.precision,
                                  row_offset=rank * local)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
@@ -193,9 +198,7 @@ class CMAES(Algorithm):
         from ....core import distributed as dist
 
         local = self.pop_size // world
-        order = _sort.argsort(fitness)
-        ranking = torch.empty_like(order)
-        ranking[order] = torch.arange(self.pop_size, device=order.device)
+        order, ranking = _sort.argsort_with_rank(fitness)
         my_rank = ranking[rank * local:(rank + 1) * local]
         padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
         w_local = padded[my_rank]                                   # 0 for rows outside the best μ
@@ -228,7 +231,7 @@ class CMAES(Algorithm):
             C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
         if state.count_iter % self.decomp_per_iter == 0:
             if self._ns is not None:
-                B, invsqrtC = self._ns(C)
+                B, invsqrtC = self._ns(C, prev=(state.B, state.invsqrtC))
                 D = state.D
             else:
                 B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)

@@ -27,11 +27,12 @@ from ._util import check, hip, on_gpu, stream_of
 def sample_reference(key, mean, sigma, B, D, pop_size: int, row_offset: int = 0):
     n = mean.shape[0]
     z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
-    return mean + sigma * ((z * D) @ B.T)
+    return mean + sigma * ((z if D is None else z * D) @ B.T)
 
 
 def sample(key, mean, sigma, B, D, pop_size: int, precision: str = "fp32", row_offset: int = 0):
-    """``pop_size`` rows starting at logical row ``row_offset`` of the generation's sample."""
+    """``pop_size`` rows starting at logical row ``row_offset`` of the generation's sample.
+    ``D=None`` means ``B`` already is the full factor (``B Bᵀ = C``), saving the column scaling."""
     if on_gpu(mean):
         from . import gemm
 
@@ -129,9 +130,15 @@ class NewtonSchulzSqrt:
     def __init__(self, tol: float = 2e-6, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6):
         self.tol, self.min_iters, self.max_iters = tol, min_iters, max_iters
         self.iters = start_iters
-        self._pending = None          # (event, pinned residual, iters used)
+        self._pending = None          # (event, host residual record, iters used)
         self.last_residual = None
         self._graph_residual = None
+        self._host = None
+        self._event = None
+        self._eye = None
+        self._ws = None               # native driver scratch (GPU)
+        self.safe_calls = 0           # > 0: scale by the norm bound instead of the λmax estimate
+        self.fallbacks = 0            # times the guarded outputs passed the previous factors on
 
     def _poll(self):
         if self._pending is None:
@@ -141,10 +148,19 @@ class NewtonSchulzSqrt:
             return
         self._pending = None
         r = float(host[0])
+        failed = host.numel() > 1 and float(host[1]) != 0.0
         self.last_residual = r
+        if failed or not (r == r) or r >= 0.25:
+            # the estimate-scaled iteration did not contract: go back to the provably
+            # convergent scaling for a while (it needs more iterations)
+            self.fallbacks += int(failed)
+            self.safe_calls = 64
+        # convergence is quadratic: one more iteration squares the residual, one fewer takes its
+        # root — raise by as many as the tolerance needs, lower only when the root still passes
         if not (r == r) or r > self.tol:
-            self.iters = min(self.max_iters, max(self.iters, used) + (4 if (r != r or r > 1e-2) else 2))
-        elif r < self.tol * 1e-3 and used <= self.iters:
+            more = 1 if r * r < self.tol else (2 if r < 0.19 else 4)
+            self.iters = min(self.max_iters, max(self.iters, used) + (more if r == r else 4))
+        elif r ** 0.5 < 0.25 * self.tol and used <= self.iters:
             self.iters = max(self.min_iters, used - 1)
 
     def needs_more_iterations(self) -> bool:
@@ -159,22 +175,57 @@ class NewtonSchulzSqrt:
             return True
         return False
 
-    def __call__(self, C: torch.Tensor):
+    def _native_ok(self, C) -> bool:
+        if not (C.is_cuda and C.dtype == torch.float32 and os.environ.get("EVOX_AMD_NS", "native") == "native"):
+            return False
+        from . import blas as _blas
+        return _blas.available()
+
+    def _call_native(self, C, prev, capturing):
+        from . import blas as _blas
+        n = C.shape[0]
+        if self._ws is None or self._ws.n != n or self._ws.work.device != C.device:
+            self._ws = _blas.NSWorkspace(n, C.device)
+        safe = self.safe_calls > 0
+        if safe and not capturing:
+            self.safe_calls -= 1
+        out = _blas.ns_sqrt(C, self._ws, max(1, self.iters), power_steps=1, safe=safe, prev=prev)
+        if capturing:
+            self._graph_residual = self._ws.scal[14]
+        elif self._pending is None:
+            if self._host is None or self._host.numel() != 2:
+                self._host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+                self._event = torch.cuda.Event()
+            self._host.copy_(self._ws.scal[14:16], non_blocking=True)
+            self._event.record(torch.cuda.current_stream(C.device))
+            self._pending = (self._event, self._host, self.iters)
+        return out
+
+    def __call__(self, C: torch.Tensor, prev=None):
+        """``prev``: the previous ``(sqrtC, invsqrtC)``; the GPU driver passes them on when an
+        iteration fails to contract instead of returning garbage."""
         n = C.shape[0]
         gpu = C.is_cuda
         capturing = gpu and torch.cuda.is_current_stream_capturing()
         if not capturing:
             self._poll()
-        eye = torch.eye(n, device=C.device, dtype=C.dtype)
+        if self._native_ok(C):
+            return self._call_native(C, prev, capturing)
+        eye = self._eye
+        if eye is None or eye.shape[0] != n or eye.device != C.device or eye.dtype != C.dtype:
+            eye = self._eye = torch.eye(n, device=C.device, dtype=C.dtype)
         # scale towards the centre of the spectrum when that is provably safe (λmax < 2s needs
         # ‖C‖∞ < 2s), else by the norm bound: a centred spectrum saves iterations
         s = torch.maximum(torch.diagonal(C).mean(), C.abs().sum(1).max() / 1.9)
         Y = C / s
-        Z = eye
-        T = eye
+        # first iteration with Z₀ = I written out: T = (3I − Y)/2, Z₁ = T (saves two GEMMs)
+        T = torch.add(eye, Y, alpha=-0.5).add_(eye, alpha=0.5) if self.iters > 0 else eye
+        Z = T
+        if self.iters > 0:
+            Y = Y @ T
         # the multiplication ORDER below is the numerically stable coupled form; products are
         # plain dense GEMMs and go to the vendor library (rocBLAS/hipBLASLt through torch)
-        for _ in range(self.iters):
+        for _ in range(self.iters - 1):
             T = torch.addmm(eye, Z, Y, beta=1.5, alpha=-0.5)
             Y = Y @ T
             Z = T @ Z
@@ -187,11 +238,15 @@ class NewtonSchulzSqrt:
             # the graph and let the driver look at it now and then (needs_more_iterations)
             self._graph_residual = res
         elif gpu:
-            host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-            host.copy_(res.reshape(1), non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(C.device))
-            self._pending = (ev, host, self.iters)
+            if self._pending is None:
+                # one residual in flight at a time; pinned buffer and event are allocated once
+                # (a pinned allocation per call costs more host time than the whole iteration)
+                if self._host is None or self._host.numel() != 1:
+                    self._host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+                    self._event = torch.cuda.Event()
+                self._host.copy_(res.reshape(1), non_blocking=True)
+                self._event.record(torch.cuda.current_stream(C.device))
+                self._pending = (self._event, self._host, self.iters)
         else:
             self._pending = (None, res.reshape(1), self.iters)
         rs = torch.sqrt(s)

@@ -12,6 +12,7 @@ import torch
 
 from .. import _native
 from ..core import random as rnd
+from . import blas as _blas
 from ._util import check, hip, stream_of
 
 P, I, I64, F = _native.P, _native.I, _native.I64, _native.F
@@ -22,6 +23,7 @@ _native.register_hip_api({
     "evox_hip_cma_gather_scale": (I, [P, I64, P, P, P, P, P, I, P, I, I, I, P]),
     "evox_hip_cma_affine": (I, [P, P, P, I64, I, P]),
     "evox_hip_cma_paths": (I, [P, P, P, P, P, P, P, P, I, P, P, P, P, P]),
+    "evox_hip_cma_cov_base": (I, [P, P, P, F, P, I, P]),
 })
 
 
@@ -87,22 +89,31 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
     impl = "torch" if _impl() == "torch" else _sample_impl()
     if impl == "torch":
         z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
+        zd = z if D is None else z * D
         if precision == "bf16":
-            return mean + sigma * ((z * D).bfloat16() @ B.T.bfloat16()).float()
-        return mean + sigma * ((z * D) @ B.T)
+            return mean + sigma * (zd.bfloat16() @ B.T.bfloat16()).float()
+        return mean + sigma * (zd @ B.T)
     if impl != "fused" or precision == "bf16":
         z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
-        bd = B * D                                                # (n, n): column j of B scaled by d_j
+        bd = B if D is None else B * D                            # (n, n): column j of B scaled by d_j
+        sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
+        if impl != "mfma" and _blas.available():
+            # mean + σ·Z·(B∘d)ᵀ from the GEMM alone: σ is read on the device, the mean is the
+            # epilogue's bias vector
+            if precision == "bf16":
+                return _blas.gemm(z.bfloat16(), bd.bfloat16(), trans_b=True, alpha=sig, bias=mean)
+            return _blas.gemm(z, bd, trans_b=True, alpha=sig, bias=mean)
         if precision == "bf16":
             g = torch.mm(z.bfloat16(), bd.bfloat16().T, out_dtype=torch.float32)
         elif impl == "mfma":
             g = matmul_nt(z, bd)
         else:
             g = torch.mm(z, bd.T)
-        sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
         check(hip().evox_hip_cma_affine(g.data_ptr(), mean.contiguous().data_ptr(), sig.data_ptr(), pop_size, n,
                                         stream_of(mean)), "cma_affine")
         return g
+    if D is None:
+        D = torch.ones(n, dtype=torch.float32, device=mean.device)
     if tuple(B.shape) != (n, n) or D.shape[0] != n:
         raise ValueError("B must be (n, n) and D (n,)")
     B = B.contiguous()
@@ -156,8 +167,18 @@ def cma_paths(mean, step, whitened, ps, pc, sigma, iter_dev, consts):
 
 
 def cma_covariance_from_factor(C, S, pc, alpha, c1, cmu):
-    """``αC + c₁ pc pcᵀ + cμ SᵀS`` — one library GEMM with the scaled old matrix as its addend."""
-    base = torch.addr(C * alpha, pc, pc, alpha=float(c1))
+    """``αC + c₁ pc pcᵀ + cμ SᵀS``: one pass forms the first two terms (α is a device scalar),
+    the library GEMM accumulates the Gram matrix onto them."""
+    n = C.shape[0]
+    if isinstance(alpha, torch.Tensor) and C.dtype == torch.float32:
+        base = torch.empty_like(C, memory_format=torch.contiguous_format)
+        check(hip().evox_hip_cma_cov_base(C.contiguous().data_ptr(), pc.contiguous().data_ptr(),
+                                          alpha.reshape(1).data_ptr(), float(c1), base.data_ptr(), n, stream_of(C)),
+              "cma_cov_base")
+    else:
+        base = torch.addr(C * alpha, pc, pc, alpha=float(c1))
+    if _blas.available():
+        return _blas.gemm(S, S, trans_a=True, alpha=float(cmu), beta=1.0, out=base)
     if S.dtype == torch.bfloat16:
         return base + float(cmu) * torch.mm(S.T, S, out_dtype=torch.float32)
     return torch.addmm(base, S.T, S, alpha=float(cmu))

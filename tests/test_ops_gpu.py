@@ -354,3 +354,109 @@ def test_de_trial_kernel_matches_batched_formulation(cuda, algo_name, dim, pop, 
     assert fused.shape == plain.shape and fused.shape[1] == dim      # DE varies a window of batch_size rows
     torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-5)
     assert (fused >= -5).all() and (fused <= 5).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1000, 1000), (130, 70, 33), (257, 1024, 515), (10000, 1000, 1000)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_native_library_gemm(cuda, M, N, K, ta, tb):
+    from evox_amd.ops import blas
+
+    assert blas.available(), "hipBLASLt entry points were not resolved"
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N * 5 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    c = torch.randn(M, N, generator=g)
+    ref = ((a.T if ta else a).double() @ (b.T if tb else b).double())
+    got = blas.gemm(a.to(cuda), b.to(cuda), trans_a=ta, trans_b=tb)
+    assert torch.allclose(got.cpu().double(), ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+    # epilogue with a separate C operand, then in place
+    out = torch.empty(M, N, device=cuda)
+    got = blas.gemm(a.to(cuda), b.to(cuda), trans_a=ta, trans_b=tb, alpha=-0.5, beta=1.5, c=c.to(cuda), out=out)
+    assert torch.allclose(got.cpu().double(), -0.5 * ref + 1.5 * c.double(), rtol=1e-4, atol=1e-4 * math.sqrt(K))
+    acc = c.to(cuda).clone()
+    blas.gemm(a.to(cuda), b.to(cuda), trans_a=ta, trans_b=tb, alpha=2.0, beta=1.0, out=acc)
+    assert torch.allclose(acc.cpu().double(), 2.0 * ref + c.double(), rtol=1e-4, atol=1e-4 * math.sqrt(K))
+
+
+def test_native_library_gemm_bf16_operands(cuda):
+    from evox_amd.ops import blas
+
+    a = torch.randn(512, 300, device=cuda).bfloat16()
+    b = torch.randn(200, 300, device=cuda).bfloat16()
+    got = blas.gemm(a, b, trans_b=True)
+    ref = a.double() @ b.double().T
+    assert got.dtype == torch.float32
+    assert torch.allclose(got.double(), ref, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("n,cond", [(1000, 1.3), (257, 50.0), (64, 1e3)])
+def test_native_newton_schulz_driver(cuda, n, cond):
+    from evox_amd.ops import blas
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    ev = torch.logspace(0.3, 0.3 - math.log10(cond), n, dtype=torch.float64)
+    C64 = (q * ev) @ q.T
+    C = C64.float().to(cuda)
+    eye = torch.eye(n, dtype=torch.float64)
+    for safe in (False, True):
+        ws = blas.NSWorkspace(n, cuda)
+        for call in range(3):                    # repeated calls reuse the carried power vector
+            s, zi = blas.ns_sqrt(C, ws, 18, safe=safe)
+        sc = ws.scal.cpu()
+        assert sc[15] == 0 and sc[14] < 1e-6
+        if not safe:
+            assert 0.8 * ev.max() <= sc[13] <= 1.05 * ev.max(), (float(sc[13]), float(ev.max()))
+        s64, z64 = s.double().cpu(), zi.double().cpu()
+        assert ((s64 @ s64 - C64).norm() / C64.norm()) < 5e-5
+        assert ((z64 @ C64 @ z64 - eye).norm() / math.sqrt(n)) < 2e-3 * max(1.0, cond / 50)
+        assert torch.allclose(s64, s64.T) and torch.allclose(z64, z64.T)
+
+
+def test_native_newton_schulz_guard_passes_previous_factors_on(cuda):
+    """One iteration on an ill-conditioned matrix cannot contract: the guarded outputs must be the
+    previous factors, and the flag must say so."""
+    from evox_amd.ops import blas
+
+    n = 96
+    q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64))
+    C = ((q * torch.logspace(0, -6, n, dtype=torch.float64)) @ q.T).float().to(cuda)
+    ws = blas.NSWorkspace(n, cuda)
+    prev = (torch.full((n, n), 3.0, device=cuda), torch.full((n, n), 7.0, device=cuda))
+    s, zi = blas.ns_sqrt(C, ws, 1, prev=prev)
+    assert float(ws.scal[15]) == 1.0
+    assert torch.equal(s, prev[0]) and torch.equal(zi, prev[1])
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 1000, 8192, 8193, 10000, 16384])
+def test_rank_sort_kernel_matches_stable_argsort(cuda, n):
+    from evox_amd.ops import sort
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    keys = torch.randn(n, generator=g)
+    keys = (keys * 4).round() / 4 if n > 64 else keys            # many ties: stability is visible
+    if n >= 64:
+        keys[3], keys[17], keys[40] = float("inf"), float("-inf"), float("nan")
+        keys[5], keys[6] = 0.0, -0.0
+    dkeys = keys.to(cuda)
+    order, rank = sort.argsort_with_rank(dkeys)
+    ref = torch.argsort(keys, stable=True)
+    assert torch.equal(order.cpu(), ref)
+    assert torch.equal(rank.cpu()[ref], torch.arange(n))
+    assert torch.equal(sort.argsort(dkeys).cpu(), ref)
+
+
+def test_sampling_gemm_with_device_scale_and_bias(cuda):
+    from evox_amd.ops import blas
+
+    z = torch.randn(700, 130, device=cuda)
+    b = torch.randn(130, 130, device=cuda)
+    mean = torch.randn(130, device=cuda)
+    sigma = torch.tensor(0.37, device=cuda)
+    got = blas.gemm(z, b, trans_b=True, alpha=sigma, bias=mean)
+    ref = (mean.double() + 0.37 * (z.double() @ b.double().T))
+    assert torch.allclose(got.double(), ref, rtol=1e-4, atol=1e-4)
+    # the scale is read at run time: changing the tensor changes the result without a new plan
+    sigma.fill_(2.0)
+    got = blas.gemm(z, b, trans_b=True, alpha=sigma, bias=mean)
+    assert torch.allclose(got.double(), mean.double() + 2.0 * (z.double() @ b.double().T), rtol=1e-4, atol=1e-4)

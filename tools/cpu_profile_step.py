@@ -1,0 +1,32 @@
+"""Host-side cost of one headline generation: cProfile over 300 steps (GPU work is asynchronous,
+so this is the launch/bookkeeping path that bounds the step once the kernels are fast)."""
+import cProfile, io, os, pstats, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import evox_amd as ex
+from evox_amd import algorithms, problems, workflows
+
+dev = torch.device("cuda")
+center = torch.zeros(1000, device=dev) + 2.0
+algo = algorithms.CMAES(center_init=center, init_stdev=1.0, pop_size=10000, decomposition="newton_schulz")
+wf = workflows.StdWorkflow(algo, problems.numerical.Ackley())
+state = wf.init(ex.PRNGKey(0))
+for _ in range(20):
+    state = wf.step(state)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+    state = wf.step(state)
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_total = time.perf_counter() - t0
+print(f"issue time per step {t_issue*1e4:.1f} us, total per step {t_total*1e4:.1f} us (100 steps)")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(300):
+    state = wf.step(state)
+pr.disable()
+torch.cuda.synchronize()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+print(s.getvalue()[:9000])
