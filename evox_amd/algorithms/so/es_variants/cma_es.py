@@ -210,13 +210,13 @@ class CMAES(Algorithm):
             from ....ops import gemm as _gemm
             ident = torch.arange(local, device=pop.device)
             S, step_sum = _cma.elite_factor(pop, ident, state.mean, state.sigma, torch.sqrt(w_local), self.precision)
-            gram = torch.mm(S.T, S, out_dtype=torch.float32) if S.dtype != torch.float32 else torch.mm(S.T, S)
+            gram = _gemm.gram(S)
             packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
             step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
             mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
                 state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
                 (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
-            C = torch.addr(state.C * alpha, pc, pc, alpha=float(self.c1)).add_(gram, alpha=float(self.cmu))
+            C = _gemm.cma_covariance_base(state.C, pc, alpha, self.c1).add_(gram, alpha=float(self.cmu))
         else:
             step_sum = w_local @ (pop - state.mean)
             ident = torch.arange(local, device=pop.device)

@@ -166,17 +166,31 @@ def cma_paths(mean, step, whitened, ps, pc, sigma, iter_dev, consts):
     return mean_out, ps_out, pc_out, scalars[0], scalars[1], scalars[2]
 
 
-def cma_covariance_from_factor(C, S, pc, alpha, c1, cmu):
-    """``αC + c₁ pc pcᵀ + cμ SᵀS``: one pass forms the first two terms (α is a device scalar),
-    the library GEMM accumulates the Gram matrix onto them."""
+def cma_covariance_base(C, pc, alpha, c1):
+    """``αC + c₁ pc pcᵀ`` in one pass (α may be a device scalar: it depends on the stall indicator)."""
     n = C.shape[0]
-    if isinstance(alpha, torch.Tensor) and C.dtype == torch.float32:
+    if isinstance(alpha, torch.Tensor) and C.dtype == torch.float32 and C.is_cuda:
         base = torch.empty_like(C, memory_format=torch.contiguous_format)
         check(hip().evox_hip_cma_cov_base(C.contiguous().data_ptr(), pc.contiguous().data_ptr(),
                                           alpha.reshape(1).data_ptr(), float(c1), base.data_ptr(), n, stream_of(C)),
               "cma_cov_base")
-    else:
-        base = torch.addr(C * alpha, pc, pc, alpha=float(c1))
+        return base
+    return torch.addr(C * alpha, pc, pc, alpha=float(c1))
+
+
+def gram(S):
+    """``SᵀS`` in fp32 (``S`` fp32 or bf16)."""
+    if S.is_cuda and _blas.available():
+        return _blas.gemm(S, S, trans_a=True)
+    if S.dtype == torch.bfloat16:
+        return torch.mm(S.T, S, out_dtype=torch.float32)
+    return torch.mm(S.T, S)
+
+
+def cma_covariance_from_factor(C, S, pc, alpha, c1, cmu):
+    """``αC + c₁ pc pcᵀ + cμ SᵀS``: one pass forms the first two terms, the library GEMM
+    accumulates the Gram matrix onto them."""
+    base = cma_covariance_base(C, pc, alpha, c1)
     if _blas.available():
         return _blas.gemm(S, S, trans_a=True, alpha=float(cmu), beta=1.0, out=base)
     if S.dtype == torch.bfloat16:
