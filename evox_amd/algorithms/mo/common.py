@@ -10,6 +10,7 @@ from ...core.algorithm import Algorithm
 from ...core.state import State
 from ...operators import crossover, mutation
 from ...operators.selection.non_dominate import crowding_distance, non_dominated_sort
+from ...ops import variation as _variation
 
 
 class MOAlgorithm(Algorithm):
@@ -48,7 +49,13 @@ class MOAlgorithm(Algorithm):
         return state.replace(fitness=fitness)
 
     def _vary(self, x_key, mut_key, parents):
-        off = self.mutation(mut_key, self.crossover(x_key, parents))
+        cx, mt = self.crossover, self.mutation
+        if (type(cx) is crossover.SimulatedBinary and cx.type == 1 and type(mt) is mutation.Polynomial
+                and mt.boundary[0] is self.lb and mt.boundary[1] is self.ub
+                and _variation.sbx_pm_supported(parents, self.lb, self.ub)):
+            # the default operator pair on the GPU: one fused launch, same random draws
+            return _variation.sbx_pm(x_key, mut_key, parents, self.lb, self.ub, cx.pro_c, cx.dis_c, mt.pro_m, mt.dis_m)
+        off = mt(mut_key, cx(x_key, parents))
         return torch.clamp(off, self.lb, self.ub)
 
     def _merged(self, state, fitness):

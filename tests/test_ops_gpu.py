@@ -460,3 +460,22 @@ def test_sampling_gemm_with_device_scale_and_bias(cuda):
     sigma.fill_(2.0)
     got = blas.gemm(z, b, trans_b=True, alpha=sigma, bias=mean)
     assert torch.allclose(got.double(), mean.double() + 2.0 * (z.double() @ b.double().T), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 12), (1001, 7), (2, 1), (64, 130), (5000, 30)])
+def test_fused_sbx_pm_matches_operator_chain(cuda, n, d):
+    from evox_amd.operators import crossover, mutation
+    from evox_amd.ops import variation
+
+    lb = torch.full((d,), -1.0, device=cuda)
+    ub = torch.linspace(1.0, 3.0, d, device=cuda)
+    x = lb + (ub - lb) * torch.rand(n, d, device=cuda)
+    x[0, 0] = 5.0                                         # out-of-bounds parent: the clamp order matters
+    kx, km = rnd.PRNGKey(11).to(cuda), rnd.PRNGKey(12).to(cuda)
+    for pro_c, pro_m in ((1.0, 1.0), (0.6, 3.0)):
+        ref = mutation.polynomial(km, crossover.simulated_binary(kx, x, pro_c, 20.0), (lb, ub), pro_m, 15.0)
+        ref = torch.clamp(ref, lb, ub)
+        got = variation.sbx_pm(kx, km, x, lb, ub, pro_c, 20.0, pro_m, 15.0)
+        assert got.shape == ref.shape
+        # identical draws: the same genes are crossed / mutated; values agree to pow rounding
+        assert torch.allclose(got, ref, rtol=2e-4, atol=2e-5), (got - ref).abs().max()
