@@ -111,36 +111,92 @@ __global__ __launch_bounds__(NT) void nds_count_kernel(const float* __restrict__
 }
 
 // Collect the current front: unranked points whose count reached zero.  Their objectives are copied
-// into a compact objective-major array so that the peel pass streams them with scalar loads.
+// into a compact objective-major array so that the peel pass streams them with scalar loads.  The
+// copy keeps the sorted order (two passes: per-block counts, then offsets + ballot ranks), and
+// blockend[b] = number of front members among the points of blocks 0..b, which lets the peel pass
+// skip every member that sits behind a block's points and drop the first-objective comparison
+// for the members in front of them.
+__global__ __launch_bounds__(NT) void nds_mark_kernel(const int* __restrict__ count, int* __restrict__ rank,
+                                                      int* __restrict__ blockcnt, int n, int cur) {
+  __shared__ int wcnt[NT / 64];
+  const int i = blockIdx.x * NT + threadIdx.x;
+  const bool flag = i < n && rank[i] < 0 && count[i] == 0;
+  if (flag) rank[i] = cur;
+  const unsigned long long bal = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(bal);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
 template <int M>
-__global__ void nds_front_kernel(const float* __restrict__ obj, int64_t ld, const int* __restrict__ count,
-                                 int* __restrict__ rank, float* __restrict__ front_obj, int* __restrict__ nf, int n, int cur) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (rank[i] < 0 && count[i] == 0) {
-    const int pos = atomicAdd(nf, 1);
+__global__ __launch_bounds__(NT) void nds_compact_kernel(const float* __restrict__ obj, int64_t ld,
+                                                         const int* __restrict__ rank, const int* __restrict__ blockcnt,
+                                                         int* __restrict__ blockend, float* __restrict__ front_obj,
+                                                         int* __restrict__ nf, int n, int cur) {
+  __shared__ int red[NT / 64];
+  __shared__ int wcnt[NT / 64];
+  int part = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += NT) part += blockcnt[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  const int i = blockIdx.x * NT + threadIdx.x;
+  const bool flag = i < n && rank[i] == cur;
+  const unsigned long long bal = __ballot(flag);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave] = part; wcnt[wave] = __popcll(bal); }
+  __syncthreads();
+  const int offset = red[0] + red[1] + red[2] + red[3];
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wcnt[w];
+  if (flag) {
+    const int pos = offset + before + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
     for (int k = 0; k < M; ++k) front_obj[k * ld + pos] = obj[k * ld + i];
-    rank[i] = cur;
+  }
+  if (threadIdx.x == 0) {
+    const int end = offset + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    blockend[blockIdx.x] = end;
+    if (blockIdx.x == gridDim.x - 1) *nf = end;
   }
 }
 
 // A front member j and a still-unranked point i are never equal (equal points share their front),
-// so "j dominates i" is the all-<= test alone.
+// so "j dominates i" is the all-<= test alone.  Members are in sorted order: those before the first
+// row with the block's smallest f0 need no f0 comparison, those behind the last row with the
+// block's largest f0 cannot dominate.  A small population leaves most CUs idle with one block per
+// 256 points, so the member range is also split over blockIdx.y (integer atomics: exact).
 template <int M>
 __global__ __launch_bounds__(NT) void nds_peel_kernel(const float* __restrict__ obj, int64_t ld, int n,
-                                                      const float* __restrict__ front_obj, const int* __restrict__ nf_ptr,
-                                                      int* __restrict__ count, const int* __restrict__ rank) {
-  const int nf = *nf_ptr;
-  if (nf == 0) return;
-  const int i = blockIdx.x * NT + threadIdx.x;
+                                                      const float* __restrict__ front_obj,
+                                                      const int* __restrict__ blockend, int* __restrict__ count,
+                                                      const int* __restrict__ rank) {
+  const int first = blockIdx.x * NT;
+  const int last = min(n, first + NT) - 1;
+  const int i = first + threadIdx.x;
   const bool live = i < n && rank[i] < 0;
-  if (__ballot(live) == 0) return;                    // wave-uniform exit
+  if (__syncthreads_or(live) == 0) return;            // block-uniform exit
+  const float key_lo = obj[first], key_hi = obj[last];
+  if (key_lo != key_lo) return;                       // a block of NaN keys: nothing dominates them
+  const int j_strict = bound<false>(obj, 0, first, key_lo);
+  const int j_end = (key_hi != key_hi) ? n : bound<true>(obj, last + 1, n, key_hi);
+  const int m_strict = j_strict >= NT ? blockend[j_strict / NT - 1] : 0;   // members wholly in front of j_strict
+  const int m_end = blockend[(j_end - 1) / NT];                           // members of every block touching [0, j_end)
+  if (m_end == 0) return;
   float b[M];
 #pragma unroll
   for (int k = 0; k < M; ++k) b[k] = live ? obj[k * ld + i] : -INFINITY;
-  const int dec = scan_rows<M, 0, false>(front_obj, ld, 0, nf, b);
-  if (live && dec) count[i] -= dec;
+  const bool clean = b[0] == b[0];
+  int per = (m_end + (int)gridDim.y - 1) / (int)gridDim.y;
+  per = (per + CH - 1) / CH * CH;
+  const int lo = min(m_end, (int)blockIdx.y * per), hi = min(m_end, lo + per);
+  if (lo >= hi) return;
+  const int dec_a = scan_rows<M, 1, false>(front_obj, ld, lo, min(hi, m_strict), b);
+  const int dec_b = scan_rows<M, 0, false>(front_obj, ld, max(lo, m_strict), hi, b);
+  const int dec = (clean ? dec_a : 0) + dec_b;
+  if (live && dec) {
+    if (gridDim.y > 1) atomicSub(&count[i], dec);
+    else count[i] -= dec;
+  }
 }
 
 template <int M>
@@ -151,12 +207,16 @@ int launch_count(const float* obj, int64_t ld, int n, int* count, int ysplit, hi
 }
 
 template <int M>
-int launch_round(const float* obj, int64_t ld, int n, int* count, int* rank, float* front_obj, int* nf, int cur,
-                 hipStream_t s) {
-  nds_front_kernel<M><<<(n + 255) / 256, 256, 0, s>>>(obj, ld, count, rank, front_obj, nf, n, cur);
+int launch_round(const float* obj, int64_t ld, int n, int* count, int* rank, float* front_obj, int* nf, int* blockcnt,
+                 int* blockend, int cur, hipStream_t s) {
+  const int bx = (n + NT - 1) / NT;
+  nds_mark_kernel<<<bx, NT, 0, s>>>(count, rank, blockcnt, n, cur);
+  nds_compact_kernel<M><<<bx, NT, 0, s>>>(obj, ld, rank, blockcnt, blockend, front_obj, nf, n, cur);
   int st = last_launch_status();
   if (st) return st;
-  nds_peel_kernel<M><<<(n + NT - 1) / NT, NT, 0, s>>>(obj, ld, n, front_obj, nf, count, rank);
+  int by = 1;
+  while (bx * by < 1024 && by < 16) by *= 2;
+  nds_peel_kernel<M><<<dim3(bx, by), NT, 0, s>>>(obj, ld, n, front_obj, blockend, count, rank);
   return last_launch_status();
 }
 
@@ -181,10 +241,10 @@ EVOX_API int evox_hip_nds_count(const float* obj, int64_t ld, int n, int m, int*
   EVOX_NDS_DISPATCH(launch_count, obj, ld, n, count, ysplit, (hipStream_t)stream)
 }
 
-// One peeling round: gather front `cur` (its size accumulates into *nf, which the caller zeroed) and
-// subtract its dominations from the counts of the points still unranked.
+// One peeling round: gather front `cur` in sorted order (its size is written to *nf) and subtract its
+// dominations from the counts of the points still unranked.  blockcnt / blockend: ceil(n/256) ints each.
 EVOX_API int evox_hip_nds_round(const float* obj, int64_t ld, int n, int m, int* count, int* rank, float* front_obj,
-                                int* nf, int cur, void* stream) {
+                                int* nf, int* blockcnt, int* blockend, int cur, void* stream) {
   if (n <= 0 || ld < n || ld % 16) return (int)hipErrorInvalidValue;
-  EVOX_NDS_DISPATCH(launch_round, obj, ld, n, count, rank, front_obj, nf, cur, (hipStream_t)stream)
+  EVOX_NDS_DISPATCH(launch_round, obj, ld, n, count, rank, front_obj, nf, blockcnt, blockend, cur, (hipStream_t)stream)
 }

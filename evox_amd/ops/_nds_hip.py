@@ -11,7 +11,7 @@ from ._util import check, hip, stream_of
 P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_nds_count": (I, [P, _native.I64, I, I, P, I, P]),
-    "evox_hip_nds_round": (I, [P, _native.I64, I, I, P, P, P, P, I, P]),
+    "evox_hip_nds_round": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, P]),
 })
 
 MAX_OBJECTIVES = 8
@@ -42,12 +42,14 @@ def rank(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
     rk = torch.full((n,), -1, dtype=torch.int32, device=dev)
     front = torch.empty((m, ld), dtype=torch.float32, device=dev)                  # objectives of the current front
     sizes = torch.zeros(n + _ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)     # size of front k
+    blockcnt = torch.empty(2 * blocks, dtype=torch.int32, device=dev)             # per-block counts | running totals
     target = n if until is None else min(int(until), n)
     cur = 0
     while True:
         for _ in range(_ROUNDS_PER_CHECK):
             check(lib.evox_hip_nds_round(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), front.data_ptr(),
-                                         sizes[cur:].data_ptr(), cur, s), "nds_round")
+                                         sizes[cur:].data_ptr(), blockcnt.data_ptr(), blockcnt[blocks:].data_ptr(),
+                                         cur, s), "nds_round")
             cur += 1
         done = sizes[:cur].cumsum(0)
         host = done.cpu()                                   # one small read-back per batch of rounds
