@@ -1,0 +1,167 @@
+// One-shot collectives over peer-mapped device memory (xGMI between GPUs of one node).
+//
+// The messages this framework exchanges every generation are small (fitness slices of a few KB,
+// migrants) or mid-sized (the n + n² sufficient statistics of CMA-ES, 4 MB at n = 10³).  A ring
+// serialises W−1 hops over single links; xGMI is point-to-point with a link to every peer, so the
+// direct form is: every rank WRITES its contribution straight into every peer's receive slot (all
+// links busy at once, one kernel launch), raises a flag there, and each rank then waits for the W
+// flags of its own slot and copies (all-gather) or sums (all-reduce) what arrived.
+//
+// Each rank owns one buffer, exported through hipIpc and mapped by every peer:
+//     flags[2][kMaxWorld] (sequence numbers)  |  data[2][W][max_bytes]
+// Two slots alternate.  Reuse is safe without an extra barrier: a rank starts collective s+1 only
+// after it has seen every peer's flag for s, and a peer raises its flag for s only after its own
+// stream has finished consuming slot (s−1)&1 — the slot that s+1 overwrites.
+//
+// Waiting is bounded: the wait kernel polls a limited number of times, then records a time-out in
+// an error word and finishes, so a missing peer can never leave waves spinning on the GPU.
+#include <cstring>
+
+#include "hip_common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 64;
+constexpr int kHeaderBytes = 2 * kMaxWorld * 4;          // flags of both slots
+
+__device__ __forceinline__ unsigned int* flag_ptr(char* base, int slot, int rank) {
+  return reinterpret_cast<unsigned int*>(base) + slot * kMaxWorld + rank;
+}
+
+// grid (blocks, W): column p copies this rank's message into peer p's slot and, once every block of
+// the column has finished, publishes the sequence number there.
+__global__ __launch_bounds__(256) void p2p_put_kernel(const unsigned int* __restrict__ src, int64_t n_words,
+                                                      char* const* __restrict__ peer_base, int rank, int slot,
+                                                      int64_t slot_stride, int64_t max_bytes, unsigned int seq,
+                                                      unsigned int* __restrict__ done) {
+  const int p = blockIdx.y;
+  char* base = peer_base[p];
+  unsigned int* dst = reinterpret_cast<unsigned int*>(base + kHeaderBytes + slot * slot_stride + (int64_t)rank * max_bytes);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if ((n_words & 3) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n_words >> 2); i += stride) d4[i] = s4[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] = src[i];
+  }
+  __threadfence_system();                               // the data is visible to the peer before the flag
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int finished = atomicAdd(&done[p], 1u) + 1u;
+    if (finished == gridDim.x) {
+      done[p] = 0u;                                     // ready for the next collective (stream-ordered)
+      __threadfence_system();
+      __hip_atomic_store(flag_ptr(base, slot, rank), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// Every block waits (bounded) for the W flags of this rank's slot, then takes part in the copy-out.
+// reduce == 0: out[r·n_words + i] = slot[r][i] (all-gather); reduce == 1: out[i] = Σ_r slot[r][i] as fp32.
+__global__ __launch_bounds__(256) void p2p_collect_kernel(char* __restrict__ base, int world, int slot,
+                                                          int64_t slot_stride, int64_t max_bytes, int64_t n_words,
+                                                          unsigned int seq, unsigned int* __restrict__ out, int reduce,
+                                                          long long max_polls, int* __restrict__ err) {
+  __shared__ int timed_out;
+  if (threadIdx.x == 0) timed_out = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < world) {
+    unsigned int* f = flag_ptr(base, slot, threadIdx.x);
+    long long polls = 0;
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if (++polls >= max_polls) { timed_out = 1; break; }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  __syncthreads();
+  if (timed_out) {                                      // finish without touching the data; the host raises
+    if (threadIdx.x == 0) atomicExch(err, 1);
+    return;
+  }
+  __threadfence_system();
+  const char* data = base + kHeaderBytes + slot * slot_stride;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (reduce) {
+    float* o = reinterpret_cast<float*>(out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+      float acc = 0.f;
+      for (int r = 0; r < world; ++r)
+        acc += __builtin_nontemporal_load(reinterpret_cast<const float*>(data + (int64_t)r * max_bytes) + i);
+      o[i] = acc;
+    }
+  } else {
+    for (int r = 0; r < world; ++r) {
+      const unsigned int* s = reinterpret_cast<const unsigned int*>(data + (int64_t)r * max_bytes);
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        out[(int64_t)r * n_words + i] = __builtin_nontemporal_load(s + i);
+    }
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_p2p_header_bytes() { return kHeaderBytes; }
+EVOX_API int evox_hip_p2p_max_world() { return kMaxWorld; }
+
+// Receive buffers are uncached device memory when the runtime offers it (a peer's writes must not be
+// hidden by this GPU's L2); plain device memory otherwise.  Zero-filled: flags start at sequence 0.
+EVOX_API int evox_hip_p2p_alloc(void** ptr, int64_t bytes) {
+  hipError_t e = hipExtMallocWithFlags(ptr, (size_t)bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc(ptr, (size_t)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = hipMemset(*ptr, 0, (size_t)bytes);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipDeviceSynchronize();
+}
+
+EVOX_API int evox_hip_p2p_free(void* ptr) { return (int)hipFree(ptr); }
+
+EVOX_API int evox_hip_p2p_export(void* ptr, void* handle_out, int handle_bytes) {
+  if (handle_bytes < (int)sizeof(hipIpcMemHandle_t)) return (int)hipErrorInvalidValue;
+  hipIpcMemHandle_t h;
+  hipError_t e = hipIpcGetMemHandle(&h, ptr);
+  if (e != hipSuccess) return (int)e;
+  memcpy(handle_out, &h, sizeof(h));
+  return 0;
+}
+
+EVOX_API int evox_hip_p2p_handle_bytes() { return (int)sizeof(hipIpcMemHandle_t); }
+
+EVOX_API int evox_hip_p2p_import(const void* handle, void** ptr) {
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  return (int)hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess);
+}
+
+EVOX_API int evox_hip_p2p_close(void* ptr) { return (int)hipIpcCloseMemHandle(ptr); }
+
+// peer_base: device array of W buffer addresses as seen from this process (own buffer at [rank])
+EVOX_API int evox_hip_p2p_put(const void* src, int64_t n_words, void* peer_base, int world, int rank, int slot,
+                              int64_t slot_stride, int64_t max_bytes, unsigned int seq, void* done, void* stream) {
+  if (n_words <= 0 || world < 1 || world > kMaxWorld || n_words * 4 > max_bytes) return (int)hipErrorInvalidValue;
+  int blocks = (int)((n_words / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 64) blocks = 64;                         // W columns share the chip
+  p2p_put_kernel<<<dim3(blocks, world), 256, 0, (hipStream_t)stream>>>(
+      (const unsigned int*)src, n_words, (char* const*)peer_base, rank, slot, slot_stride, max_bytes, seq,
+      (unsigned int*)done);
+  return evox::last_launch_status();
+}
+
+EVOX_API int evox_hip_p2p_collect(void* own_base, int world, int slot, int64_t slot_stride, int64_t max_bytes,
+                                  int64_t n_words, unsigned int seq, void* out, int reduce, long long max_polls,
+                                  void* err, void* stream) {
+  if (n_words <= 0 || world < 1 || world > kMaxWorld || max_polls < 1) return (int)hipErrorInvalidValue;
+  const int64_t work = reduce ? n_words : n_words * world;
+  int blocks = (int)((work + 1023) / 1024);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 512) blocks = 512;
+  p2p_collect_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, world, slot, slot_stride, max_bytes,
+                                                             n_words, seq, (unsigned int*)out, reduce, max_polls,
+                                                             (int*)err);
+  return evox::last_launch_status();
+}

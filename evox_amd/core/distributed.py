@@ -80,6 +80,19 @@ def init_process_group(backend: Optional[str] = None, device: Optional[torch.dev
     d.init_process_group(backend=backend, **kw)
 
 
+def _p2p_group(x: torch.Tensor):
+    """The one-shot peer-to-peer group when it is switched on (``EVOX_AMD_P2P=1``) and ``x`` is a
+    device tensor of 4-byte elements that fits its buffers; None otherwise (RCCL / gloo path)."""
+    if not x.is_cuda or x.element_size() != 4 or x.numel() == 0:
+        return None
+    from ..parallel import p2p
+
+    if not p2p.enabled():
+        return None
+    g = p2p.default_group()
+    return g if x.numel() * 4 <= g.max_bytes else None
+
+
 def _via_host(x: torch.Tensor) -> bool:
     # gloo collectives are given CPU tensors only; device data is staged through host memory
     return x.is_cuda and _dist().get_backend() == "gloo"
@@ -96,6 +109,10 @@ def all_gather(x: torch.Tensor, axis_name: Optional[str] = POP_AXIS_NAME, axis: 
     d = _dist()
     w = d.get_world_size(group)
     src = x.contiguous()
+    if group is None and axis == 0 and tiled and src.dim() >= 1:
+        p2p_group = _p2p_group(src)
+        if p2p_group is not None:
+            return p2p_group.all_gather(src)
     stage = _via_host(src)
     if stage:
         src = src.cpu()
@@ -117,6 +134,11 @@ def all_reduce(x: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
         return x
     d = _dist()
     ops = {"sum": d.ReduceOp.SUM, "max": d.ReduceOp.MAX, "min": d.ReduceOp.MIN, "mean": d.ReduceOp.SUM}
+    if group is None and op in ("sum", "mean") and x.dtype == torch.float32:
+        p2p_group = _p2p_group(x)
+        if p2p_group is not None:
+            y = p2p_group.all_reduce(x.detach())
+            return y / d.get_world_size() if op == "mean" else y
     y = x.detach().clone().contiguous()
     stage = _via_host(y)
     if stage:

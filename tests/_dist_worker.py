@@ -65,6 +65,55 @@ def main():
         g2 = dist.all_gather(x.reshape(1, 3), axis=1)
         result = {"gather": g.tolist(), "sum": s.tolist(), "max": m.tolist(), "bcast": b.tolist(),
                   "gather_axis1": list(g2.shape)}
+    elif case == "p2p":
+        # one-shot collectives over IPC-mapped device memory: the ranks share the one visible GPU
+        from evox_amd.parallel.p2p import P2PGroup
+
+        torch.cuda.set_device(0)
+        g = P2PGroup(max_bytes=1 << 20, timeout_s=10.0)
+        ok = True
+        gen = torch.Generator().manual_seed(1234)
+        for it, n in enumerate([3, 1000, 4096, 65536, 7, 262144, 12, 1001]):
+            full = torch.randn(world, n, generator=gen)              # same on every rank
+            mine = full[rank].to(dev)
+            got = g.all_gather(mine)
+            ok &= bool(torch.equal(got.cpu(), full.reshape(-1)))
+            red = g.all_reduce(mine)
+            ok &= bool(torch.allclose(red.cpu(), full.sum(0), rtol=1e-5, atol=1e-5))
+            ints = g.all_gather(torch.full((5,), rank + 10 * it, dtype=torch.int32, device=dev))
+            ok &= ints.cpu().tolist() == [r + 10 * it for r in range(world) for _ in range(5)]
+        g.check()
+        # routed through the framework's collectives
+        os.environ["EVOX_AMD_P2P"] = "1"
+        x = torch.arange(6, dtype=torch.float32, device=dev) + 100 * rank
+        ok &= dist.all_gather(x).cpu().tolist() == [float(v + 100 * r) for r in range(world) for v in range(6)]
+        ok &= dist.all_reduce(x).cpu().tolist() == [float(world * v + 100 * sum(range(world))) for v in range(6)]
+        os.environ["EVOX_AMD_P2P"] = "0"
+        g.close()
+        result = {"ok": ok}
+    elif case == "p2p_timeout":
+        # rank 1 joins the collective late; rank 0 polls a few times only, so its wait kernel gives up,
+        # finishes, and the host reports the time-out (no wave is left spinning)
+        import time
+
+        from evox_amd.parallel.p2p import P2PGroup, P2PTimeout
+
+        torch.cuda.set_device(0)
+        g = P2PGroup(max_bytes=4096, timeout_s=10.0)
+        if rank == 0:
+            g._max_polls = 50
+        else:
+            time.sleep(2.0)
+        x = torch.ones(8, device=dev) * (rank + 1)
+        out = g.all_reduce(x)
+        timed_out = False
+        try:
+            g.check()
+        except P2PTimeout:
+            timed_out = True
+        result = {"timed_out": timed_out, "sum": out.cpu().tolist() if not timed_out else None}
+        dist.barrier()
+        g.close()
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump(result, f)
     dist.barrier()

@@ -125,3 +125,19 @@ def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
         for r in res:
             assert r["row_sharded"] and r["world"] == world
             assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_p2p_collectives(world, tmp_path):
+    """all_gather / all_reduce through IPC-mapped receive buffers with flag hand-shakes, ranks sharing
+    the one GPU of the test box (handles are exchanged over gloo)."""
+    res = launch("p2p", world, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    assert all(r["ok"] for r in res)
+
+
+@pytest.mark.gpu
+def test_one_shot_p2p_wait_is_bounded(tmp_path):
+    res = launch("p2p_timeout", 2, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    assert res[0]["timed_out"] is True
+    assert res[1]["timed_out"] is False and res[1]["sum"] == [3.0] * 8
