@@ -479,3 +479,34 @@ def test_fused_sbx_pm_matches_operator_chain(cuda, n, d):
         assert got.shape == ref.shape
         # identical draws: the same genes are crossed / mutated; values agree to pow rounding
         assert torch.allclose(got, ref, rtol=2e-4, atol=2e-5), (got - ref).abs().max()
+
+
+def test_cmaes_newton_schulz_on_ill_conditioned_problem(cuda):
+    """A 10⁶-conditioned ellipsoid drives cond(C) up by orders of magnitude during the run: the native
+    factorisation (power-iteration scale, lagged iteration control, guarded outputs) must keep up
+    with the exact eigendecomposition mode."""
+    import evox_amd as ex
+    from evox_amd import algorithms, monitors, problems, workflows
+    from evox_amd.core.problem import Problem
+
+    n = 24
+    scale = torch.logspace(0, 6, n, device=cuda)
+
+    class Ellipsoid(Problem):
+        def evaluate(self, state, x):
+            return (scale * x * x).sum(1), state
+
+    best = {}
+    for mode in ("newton_schulz", "eigh"):
+        algo = algorithms.CMAES(center_init=torch.full((n,), 3.0, device=cuda), init_stdev=1.0, pop_size=48,
+                                decomposition=mode)
+        mon = monitors.EvalMonitor()
+        wf = workflows.StdWorkflow(algo, Ellipsoid(), monitors=[mon])
+        state = wf.init(ex.PRNGKey(7))
+        for _ in range(900):
+            state = wf.step(state)
+        best[mode] = float(mon.get_best_fitness())
+        if mode == "newton_schulz":
+            assert algo._ns.fallbacks <= 2, algo._ns.fallbacks
+    assert best["eigh"] < 1e-6
+    assert best["newton_schulz"] < 1e-5, best
