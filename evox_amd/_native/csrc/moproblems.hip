@@ -1,0 +1,81 @@
+// DTLZ1–7 evaluated in one pass: a lane owns one individual, accumulates the distance function g
+// over the last d−m+1 variables and unrolls the triangular product over the first m−1.
+// (The tensor formulation is a dozen launches with a cumulative-product scan in the middle.)
+#include "hip_common.h"
+
+namespace {
+
+constexpr int kMaxObj = 16;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kPi = 3.14159265358979323846f;
+
+// kind: 1..7 = DTLZ1..DTLZ7
+__global__ __launch_bounds__(256) void dtlz_kernel(const float* __restrict__ x, int64_t ldx, int n, int d, int m,
+                                                   int kind, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = x + (int64_t)i * ldx;
+  const int k = d - m + 1;                       // distance variables x[m−1 .. d)
+  float g = 0.f;
+  if (kind == 1 || kind == 3) {
+    for (int j = m - 1; j < d; ++j) {
+      const float t = r[j] - 0.5f;
+      g += t * t - cosf(20.f * kPi * t);
+    }
+    g = 100.f * ((float)k + g);
+  } else if (kind == 6) {
+    for (int j = m - 1; j < d; ++j) g += powf(r[j], 0.1f);
+  } else if (kind == 7) {
+    for (int j = m - 1; j < d; ++j) g += r[j];
+    g = 1.f + 9.f * g / (float)k;
+  } else {
+    for (int j = m - 1; j < d; ++j) {
+      const float t = r[j] - 0.5f;
+      g += t * t;
+    }
+  }
+  float* o = out + (int64_t)i * m;
+  if (kind == 7) {
+    float s = 0.f;
+    for (int j = 0; j < m - 1; ++j) {
+      const float h = r[j];
+      o[j] = h;
+      s += h / (1.f + g) * (1.f + sinf(3.f * kPi * h));
+    }
+    o[m - 1] = (1.f + g) * ((float)m - s);
+    return;
+  }
+  // f_j = scale · Π_{i < m−1−j} head_i · tail_{m−1−j}  (no tail factor for j = 0)
+  float head[kMaxObj], tail[kMaxObj];
+  for (int j = 0; j < m - 1; ++j) {
+    float p = r[j];
+    if (kind == 1) {
+      head[j] = p;
+      tail[j] = 1.f - p;
+    } else {
+      if (kind == 4) p = powf(p, 100.f);
+      if ((kind == 5 || kind == 6) && j > 0) p = (1.f + 2.f * g * p) / (2.f + 2.f * g);
+      const float a = p * kHalfPi;
+      head[j] = fmaxf(cosf(a), 0.f);
+      tail[j] = sinf(a);
+    }
+  }
+  const float scale = (kind == 1 ? 0.5f : 1.f) * (1.f + g);
+  float prod = 1.f;
+  // walk j from m−1 down to 0: prefix products grow one head factor at a time
+  for (int q = 0; q < m; ++q) {
+    const int j = m - 1 - q;                      // objective index; uses heads 0..q−1 and tail_q
+    float f = prod;
+    if (j > 0) f *= tail[q];
+    o[j] = scale * f;
+    if (q < m - 1) prod *= head[q];
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_dtlz(const float* x, int64_t ldx, int n, int d, int m, int kind, float* out, void* stream) {
+  if (n <= 0 || m < 2 || m > kMaxObj || d < m || kind < 1 || kind > 7) return (int)hipErrorInvalidValue;
+  dtlz_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, ldx, n, d, m, kind, out);
+  return evox::last_launch_status();
+}

@@ -8,9 +8,30 @@ import math
 
 import torch
 
+from ... import _native
 from ...core.problem import Problem
 from ...core.state import State
 from ...operators.sampling import GridSampling, UniformSampling
+from ...ops._util import check, hip, on_gpu, stream_of
+
+_native.register_hip_api({"evox_hip_dtlz": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.I, _native.I,
+                                                       _native.P, _native.P])})
+_KIND = {}        # class -> kernel variant; filled below (subclasses that override pieces use the tensor path)
+
+
+def _fused(problem, X):
+    """Objectives from the one-pass kernel (``csrc/moproblems.hip``) when ``problem`` is one of the
+    seven stock classes and ``X`` is an fp32 device matrix; None otherwise."""
+    kind = _KIND.get(type(problem))
+    if kind is None or not on_gpu(X) or X.dtype != torch.float32 or X.dim() != 2 or problem.m > 16 \
+            or X.shape[1] < problem.m or X.shape[0] == 0:
+        return None
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    out = torch.empty((X.shape[0], problem.m), dtype=torch.float32, device=X.device)
+    check(hip().evox_hip_dtlz(X.data_ptr(), X.stride(0), X.shape[0], X.shape[1], problem.m, kind, out.data_ptr(),
+                              stream_of(X)), "dtlz")
+    return out
 
 
 def _chain(head, tail):
@@ -44,6 +65,9 @@ class DTLZTestSuit(Problem):
         return X[:, : self.m - 1]
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = self._g(X[:, m - 1:])
         pos = self._position(X) if not hasattr(self, "_position_with_g") else self._position_with_g(X, g)
@@ -68,6 +92,9 @@ class DTLZ1(DTLZTestSuit):
         super().__init__(d, m, ref_num)
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = _multimodal_g(X[:, m - 1:])
         pos = X[:, : m - 1]
@@ -121,6 +148,9 @@ class DTLZ7(DTLZTestSuit):
         self.sample = GridSampling(self.ref_num * self.m, self.m - 1)
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = 1 + 9 * X[:, m - 1:].mean(1, keepdim=True)
         head = X[:, : m - 1]
@@ -134,3 +164,6 @@ class DTLZ7(DTLZTestSuit):
         x = torch.where(x <= median, x * (b - a) / median + a, (x - median) * (d - c) / (1 - median) + c)
         last = 2 * (self.m - (x / 2 * (1 + torch.sin(3 * math.pi * x))).sum(1, keepdim=True))
         return torch.cat([x, last], dim=1)
+
+
+_KIND.update({DTLZ1: 1, DTLZ2: 2, DTLZ3: 3, DTLZ4: 4, DTLZ5: 5, DTLZ6: 6, DTLZ7: 7})
