@@ -26,8 +26,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pop", type=int, default=10000, help="population per GPU (weak) or total (strong)")
     ap.add_argument("--dim", type=int, default=1000)
     ap.add_argument("--problem", default="ackley", choices=["ackley", "sphere"])
