@@ -162,8 +162,8 @@ CONFIGS = {f.__name__: f for f in (pso_quickstart, cmaes_sphere_bf16, nsga2_dtlz
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("config", choices=sorted(CONFIGS))
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pop", type=int, default=0)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--device", default="cuda")

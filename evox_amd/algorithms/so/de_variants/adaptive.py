@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 from ....core import random as rnd
+from ....ops import de_adapt as _adapt
 from .base import ARITH, BEST, BIN, CURRENT, EXP, PBEST, RAND, DEBase
 
 
@@ -40,15 +41,27 @@ class JaDE(DEBase):
         CR = torch.clamp(rnd.cauchy(kCR, (self.pop_size,)) * 0.1 + loc_CR, 0.0, 1.0)
         return F, CR
 
+    def _fused_tell_ok(self, state):
+        # the fused kernels replace the whole population at once
+        return (_adapt.supported(state.population) and self.batch_size == self.pop_size and state.start_index == 0)
+
     def ask(self, state):
         key, k_var, kF, kCR = rnd.split(state.key, 4)
-        F, CR = self._draw_params(state, kF, kCR, state.F_u, state.CR_u)
+        if _adapt.supported(state.population):
+            F, CR = _adapt.draw_params(kF, kF, kCR, state.F_u, state.CR_u, self.pop_size)
+        else:
+            F, CR = self._draw_params(state, kF, kCR, state.F_u, state.CR_u)
         idx = self._window(state)
         trial = self._strategy_trials(k_var, state, idx, CURRENT, PBEST, self.num_diff_vects, BIN, F, CR,
                                       self.diff_padding_num)
         return trial, state.replace(trial_vectors=trial, key=key, F_vect=F, CR_vect=CR)
 
     def tell(self, state, trial_fitness):
+        if self._fused_tell_ok(state):
+            population, fitness, best_index, F_u, CR_u, _ = _adapt.select_and_adapt(
+                state.population, state.trial_vectors, state.fitness, trial_fitness, state.F_vect, state.CR_vect,
+                state.F_u, state.CR_u, strict=self.strict_improvement, weight_by_gain=False, mode="jade", c=self.c)
+            return state.replace(population=population, fitness=fitness, best_index=best_index, F_u=F_u, CR_u=CR_u)
         population, fitness, best_index, start, ok, _ = self._select(state, state.trial_vectors, trial_fitness)
         okf = ok.to(torch.float32)
         n_ok = okf.sum()
@@ -85,14 +98,24 @@ class SHADE(JaDE):
 
     def ask(self, state):
         key, k_var, k_slot, kF, kCR = rnd.split(state.key, 5)
-        slot = rnd.randint(k_slot, (self.pop_size,), 0, self.H)
-        F, CR = self._draw_params(state, kF, kCR, state.Memory_FCR[0, slot], state.Memory_FCR[1, slot])
+        if _adapt.supported(state.population):
+            F, CR = _adapt.draw_params(k_slot, kF, kCR, state.Memory_FCR[0], state.Memory_FCR[1], self.pop_size)
+        else:
+            slot = rnd.randint(k_slot, (self.pop_size,), 0, self.H)
+            F, CR = self._draw_params(state, kF, kCR, state.Memory_FCR[0, slot], state.Memory_FCR[1, slot])
         idx = self._window(state)
         trial = self._strategy_trials(k_var, state, idx, CURRENT, PBEST, self.num_diff_vects, BIN, F, CR,
                                       self.diff_padding_num)
         return trial, state.replace(trial_vectors=trial, key=key, F_vect=F, CR_vect=CR)
 
     def tell(self, state, trial_fitness):
+        if self._fused_tell_ok(state):
+            population, fitness, best_index, _, _, memory = _adapt.select_and_adapt(
+                state.population, state.trial_vectors, state.fitness, trial_fitness, state.F_vect, state.CR_vect,
+                state.Memory_FCR[0], state.Memory_FCR[1], strict=self.strict_improvement, weight_by_gain=True,
+                mode="shade")
+            return state.replace(population=population, fitness=fitness, best_index=best_index,
+                                 Memory_FCR=memory)
         population, fitness, best_index, start, ok, parent_fit = self._select(state, state.trial_vectors, trial_fitness)
         delta = torch.where(ok, parent_fit - trial_fitness, torch.zeros_like(trial_fitness))
         delta = torch.where(torch.isfinite(delta), delta, torch.zeros_like(delta))
