@@ -79,3 +79,43 @@ EVOX_API int evox_hip_dtlz(const float* x, int64_t ldx, int n, int d, int m, int
   dtlz_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, ldx, n, d, m, kind, out);
   return evox::last_launch_status();
 }
+
+// CEC-style prologue z = M·((x − o)·rate), optionally with the output coordinates permuted
+// (z'_j = z_{perm[j]}): three tensor ops and a K = d ≤ 128 GEMM that the library runs far below its
+// rate, as one pass with the rotation matrix staged in LDS.
+namespace {
+
+constexpr int kMaxRotDim = 128;
+
+__global__ __launch_bounds__(256) void shift_rotate_kernel(const float* __restrict__ x, int64_t ldx,
+                                                           const float* __restrict__ o, const float* __restrict__ M,
+                                                           const int64_t* __restrict__ perm, float rate, int n, int d,
+                                                           float* __restrict__ out) {
+  extern __shared__ float lds[];                // M (d × (d+1), padded rows) then o·rate pre-scaled? no: o (d)
+  float* sm = lds;
+  float* so = lds + d * (d + 1);
+  for (int t = threadIdx.x; t < d * d; t += blockDim.x) sm[(t / d) * (d + 1) + (t % d)] = M[t];
+  for (int t = threadIdx.x; t < d; t += blockDim.x) so[t] = o[t];
+  __syncthreads();
+  const int64_t total = (int64_t)n * d;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / d), j = (int)(e - (int64_t)r * d);
+    const int row = perm ? (int)perm[j] : j;
+    const float* xr = x + (int64_t)r * ldx;
+    const float* mr = sm + row * (d + 1);
+    float acc = 0.f;
+    for (int k = 0; k < d; ++k) acc += (xr[k] - so[k]) * rate * mr[k];
+    out[e] = acc;
+  }
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_shift_rotate(const float* x, int64_t ldx, const float* o, const float* M, const int64_t* perm,
+                                   float rate, int n, int d, float* out, void* stream) {
+  if (n <= 0 || d <= 0 || d > kMaxRotDim) return (int)hipErrorInvalidValue;
+  const size_t lds = sizeof(float) * ((size_t)d * (d + 1) + d);
+  shift_rotate_kernel<<<evox::stream_grid((int64_t)n * d, 256), 256, lds, (hipStream_t)stream>>>(x, ldx, o, M, perm, rate,
+                                                                                               n, d, out);
+  return evox::last_launch_status();
+}

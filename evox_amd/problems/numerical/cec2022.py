@@ -3,7 +3,7 @@
 Reference: ``src/evox/problems/numerical/cec2022_so.py:10-766``.
 
 Every function is evaluated for the whole population at once: shift/scale/rotate is one small
-GEMM ``((X − o)·s) Mᵀ``, the basic functions are row-wise reductions over (N, D) tensors.  The
+GEMM ``((X − o)·s) Mᵀ`` (on the GPU a single kernel with the matrix in LDS, ``csrc/moproblems.hip``), the basic functions are row-wise reductions over (N, D) tensors.  The
 benchmark constants (shift vectors, rotation matrices, shuffles) are the official ones, packed
 in ``data/cec2022.npz`` (see ``tools/pack_cec2022.py``).
 
@@ -20,7 +20,14 @@ from pathlib import Path
 import numpy as np
 import torch
 
+from ... import _native
 from ...core.problem import Problem
+from ...ops._util import check as _check
+from ...ops._util import hip as _hip
+from ...ops._util import stream_of as _stream_of
+
+_native.register_hip_api({"evox_hip_shift_rotate": (_native.I, [_native.P, _native.I64, _native.P, _native.P, _native.P,
+                                                               _native.F, _native.I, _native.I, _native.P, _native.P])})
 
 _DATA = Path(__file__).parent / "data" / "cec2022.npz"
 
@@ -176,6 +183,18 @@ class CEC2022Function(Problem):
 
     @staticmethod
     def _ssr(x, o, M, rate=1.0, shuffle=None):
+        """Shift, scale, rotate (and permute): ``z = ((x − o)·rate) Mᵀ``, then ``z[:, shuffle]``."""
+        d = x.shape[1]
+        if x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and d <= 128 and x.shape[0] > 0 \
+                and M.dtype == torch.float32 and (shuffle is None or shuffle.dtype == torch.int64):
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            out = torch.empty((x.shape[0], d), dtype=torch.float32, device=x.device)
+            _check(_hip().evox_hip_shift_rotate(x.data_ptr(), x.stride(0), o.contiguous().data_ptr(),
+                                                M.contiguous().data_ptr(),
+                                                shuffle.contiguous().data_ptr() if shuffle is not None else None,
+                                                float(rate), x.shape[0], d, out.data_ptr(), _stream_of(x)), "shift_rotate")
+            return out
         z = ((x - o) * rate) @ M.T
         return z if shuffle is None else z[:, shuffle]
 

@@ -562,3 +562,17 @@ def test_fused_adaptive_de_bookkeeping_matches_tensor_formulation(cuda, algo_nam
             else:
                 assert torch.allclose(sh.F_u, st.F_u, rtol=1e-4) and torch.allclose(sh.CR_u, st.CR_u, rtol=1e-4)
         state = st
+
+
+@pytest.mark.parametrize("func", list(range(1, 13)))
+@pytest.mark.parametrize("d", [10, 20])
+def test_cec2022_gpu_matches_cpu(cuda, func, d):
+    """The device path (shift-rotate kernel) against the host tensor formulation."""
+    from evox_amd import problems
+
+    prob = problems.numerical.CEC2022TestSuit.create(func)
+    x = (torch.rand(513, d) * 200 - 100)
+    ref, _ = prob.evaluate(None, x)
+    got, _ = prob.evaluate(None, x.to(cuda))
+    assert torch.allclose(got.cpu(), ref, rtol=2e-3, atol=1e-2 * float(ref.abs().median()) + 1e-3), \
+        ((got.cpu() - ref).abs() / (ref.abs() + 1)).max()
