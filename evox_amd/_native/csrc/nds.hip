@@ -248,3 +248,40 @@ EVOX_API int evox_hip_nds_round(const float* obj, int64_t ld, int n, int m, int*
   if (n <= 0 || ld < n || ld % 16) return (int)hipErrorInvalidValue;
   EVOX_NDS_DISPATCH(launch_round, obj, ld, n, count, rank, front_obj, nf, blockcnt, blockend, cur, (hipStream_t)stream)
 }
+
+// Crowding distance of one front from per-objective orders.  The caller ranks every objective with
+// the counting-rank kernel (order and inverse permutation in one launch each); a member's neighbours
+// in objective k are then order_k[rank_k[i] ± 1]:
+//     dist_i = Σ_k (v_k[next] − v_k[prev]) / (max_k − min_k),   +inf at either end of any objective
+// (the boundary points of NSGA-II).  vals / order / rank: m × count, objective-major.
+namespace {
+
+__global__ __launch_bounds__(256) void crowding_kernel(const float* __restrict__ vals,
+                                                       const int64_t* __restrict__ order,
+                                                       const int64_t* __restrict__ rank, int count, int m,
+                                                       float* __restrict__ dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  float total = 0.f;
+  for (int k = 0; k < m; ++k) {
+    const float* v = vals + (size_t)k * count;
+    const int64_t* o = order + (size_t)k * count;
+    const int64_t r = rank[(size_t)k * count + i];
+    if (r == 0 || r == count - 1) {
+      total = INFINITY;
+      break;
+    }
+    const float span = v[o[count - 1]] - v[o[0]];
+    total += (v[o[r + 1]] - v[o[r - 1]]) / span;
+  }
+  dist[i] = total;
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_crowding(const float* vals, const int64_t* order, const int64_t* rank, int count, int m,
+                               float* dist, void* stream) {
+  if (count <= 0 || m <= 0) return 0;
+  crowding_kernel<<<(count + 255) / 256, 256, 0, (hipStream_t)stream>>>(vals, order, rank, count, m, dist);
+  return last_launch_status();
+}

@@ -10,6 +10,7 @@ from ...core.algorithm import Algorithm
 from ...core.state import State
 from ...operators import crossover, mutation
 from ...operators.selection.non_dominate import crowding_distance, non_dominated_sort
+from ...ops import nds as _nds
 from ...ops import variation as _variation
 
 
@@ -66,11 +67,4 @@ class MOAlgorithm(Algorithm):
 def rank_crowding_truncate(pop, fit, k):
     """Indices of the ``k`` survivors by (front index, then larger crowding distance in the
     front that straddles the cut)."""
-    rank = non_dominated_sort(fit, until=k)
-    order = torch.argsort(rank, stable=True)
-    worst = rank[order[k - 1]]
-    mask = rank == worst
-    dist = crowding_distance(fit, mask)
-    key2 = torch.where(mask, -dist, torch.zeros_like(dist))
-    idx = torch.argsort(key2, stable=True)
-    return idx[torch.argsort(rank[idx], stable=True)][:k]
+    return _nds.rank_crowding_select(fit, k)

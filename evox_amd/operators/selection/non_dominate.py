@@ -55,15 +55,8 @@ def non_dominate(population, fitness, topk: int, deduplicate: bool = False):
     if deduplicate:
         keep = _dedup_first(population)
         fit_for_rank = torch.where(keep[:, None], fitness, torch.full_like(fitness, float("inf")))
-    rank = non_dominated_sort(fit_for_rank, until=topk)
-    order = torch.argsort(rank, stable=True)
-    worst = rank[order[topk - 1]]
-    mask = rank == worst
-    dist = crowding_distance(fit_for_rank, mask)
-    # composite key: front index first, larger distance first inside the cut front
-    key2 = torch.where(mask, -dist, torch.zeros_like(dist))
-    idx = torch.argsort(key2, stable=True)
-    idx = idx[torch.argsort(rank[idx], stable=True)][:topk]
+    # composite order: front index first, larger crowding distance first inside the cut front
+    idx = _nds.rank_crowding_select(fit_for_rank, topk)
     return population[idx], fitness[idx]
 
 

@@ -12,6 +12,7 @@ P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_nds_count": (I, [P, _native.I64, I, I, P, I, P]),
     "evox_hip_nds_round": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, P]),
+    "evox_hip_crowding": (I, [P, P, P, I, I, P, P]),
 })
 
 MAX_OBJECTIVES = 8
@@ -22,9 +23,12 @@ def supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dim() == 2 and 2 <= x.shape[1] <= MAX_OBJECTIVES and x.shape[0] > 0
 
 
-def rank(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
+def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     """Front index of every row (int64).  With ``until`` peeling stops after the front that brings
-    the number of ranked points to at least ``until``; all later points share the next index."""
+    the number of ranked points to at least ``until``; all later points share the next index.
+    ``with_info``: also return ``(cut, n_before, cut_size)`` — the index of the last front that was
+    kept apart, how many points the fronts before it hold, and its own size (host integers that the
+    peeling loop has read anyway)."""
     n, m = x.shape
     dev = x.device
     # ascending first objective: a dominator never sits behind the point it dominates
@@ -67,4 +71,25 @@ def rank(x: torch.Tensor, until: Optional[int] = None) -> torch.Tensor:
         pass
     out = torch.empty_like(rk64)
     out[order] = rk64
+    if with_info:
+        n_before = int(host_sizes[cut - 1]) if cut > 0 else 0
+        return out, (cut, n_before, int(host_sizes[cut]) - n_before)
     return out
+
+
+def crowding(vals: torch.Tensor) -> torch.Tensor:
+    """Crowding distance of the rows of ``vals`` (count ≤ 16384, m), all of one front: one
+    counting-rank launch per objective and one pass that reads each member's two neighbours."""
+    from . import sort as _sort
+
+    count, m = vals.shape
+    soa = vals.float().T.contiguous()                                   # (m, count)
+    order = torch.empty((m, count), dtype=torch.int64, device=vals.device)
+    rnk = torch.empty((m, count), dtype=torch.int64, device=vals.device)
+    lib, s = hip(), stream_of(soa)
+    for k in range(m):
+        check(lib.evox_hip_rank_sort(soa[k].data_ptr(), count, order[k].data_ptr(), rnk[k].data_ptr(), s), "rank_sort")
+    dist = torch.empty(count, dtype=torch.float32, device=vals.device)
+    check(lib.evox_hip_crowding(soa.data_ptr(), order.data_ptr(), rnk.data_ptr(), count, m, dist.data_ptr(), s),
+          "crowding")
+    return dist

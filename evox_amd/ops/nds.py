@@ -120,3 +120,45 @@ def crowding_distance_reference(costs: torch.Tensor, mask: Optional[torch.Tensor
 
 def crowding_distance(costs: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     return crowding_distance_reference(costs, mask)
+
+
+_CROWD_KERNEL_MAX = 16384        # front sizes up to which the scan-based crowding kernel is used
+
+
+def rank_crowding_select(fit: torch.Tensor, k: int) -> torch.Tensor:
+    """Indices of the ``k`` survivors of NSGA-II truncation: whole fronts in order of their index
+    (population order inside a front), then the members of the front that straddles the cut by
+    decreasing crowding distance (ties: population order).
+
+    On the GPU the front sizes come back from the peeling loop, so only the straddling front is
+    touched afterwards: its members are gathered, their crowding distances come from a sort-free
+    kernel and one small counting sort picks the most isolated ones — two sorts of the merged
+    population in total instead of five."""
+    n = fit.shape[0]
+    if on_gpu(fit):
+        from . import _nds_hip
+        from . import sort as _sort
+
+        if _nds_hip.supported(fit) and k < n:
+            rank, (cut, n_before, cut_size) = _nds_hip.rank(fit, until=k, with_info=True)
+            need = k - n_before
+            if 0 < need <= cut_size <= _CROWD_KERNEL_MAX:
+                order = torch.argsort(rank, stable=True)
+                head = order[:n_before]
+                members = order[n_before:n_before + cut_size]          # the cut front, in population order
+                dist = _nds_hip.crowding(fit[members])
+                chosen = members[_sort.argsort(-dist)[:need]]
+                return torch.cat([head, chosen])
+            return _truncate_from_rank(fit, rank, k)
+    rank = non_dominated_rank(fit, until=k)
+    return _truncate_from_rank(fit, rank, k)
+
+
+def _truncate_from_rank(fit, rank, k):
+    order = torch.argsort(rank, stable=True)
+    worst = rank[order[k - 1]]
+    mask = rank == worst
+    dist = crowding_distance(fit, mask)
+    key2 = torch.where(mask, -dist, torch.zeros_like(dist))
+    idx = torch.argsort(key2, stable=True)
+    return idx[torch.argsort(rank[idx], stable=True)][:k]

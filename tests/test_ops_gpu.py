@@ -576,3 +576,35 @@ def test_cec2022_gpu_matches_cpu(cuda, func, d):
     got, _ = prob.evaluate(None, x.to(cuda))
     assert torch.allclose(got.cpu(), ref, rtol=2e-3, atol=1e-2 * float(ref.abs().median()) + 1e-3), \
         ((got.cpu() - ref).abs() / (ref.abs() + 1)).max()
+
+
+@pytest.mark.parametrize("n,m,k", [(2000, 3, 1000), (20000, 3, 10000), (500, 2, 100), (3000, 5, 1500), (64, 2, 63)])
+def test_fused_rank_crowding_truncation_matches_sort_formulation(cuda, n, m, k):
+    from evox_amd.ops import _nds_hip, nds
+
+    g = torch.Generator(device="cpu").manual_seed(n + m)
+    fit = torch.rand(n, m, generator=g)
+    fit = (fit * 50).round() / 50 if n <= 3000 else fit          # ties in every objective
+    fit = fit.to(cuda)
+    got = nds.rank_crowding_select(fit, k)
+    rank, (cut, n_before, cut_size) = _nds_hip.rank(fit, until=k, with_info=True)
+    ref = nds._truncate_from_rank(fit, rank, k)
+    assert got.shape == (k,)
+    assert int((rank < cut).sum()) == n_before and int((rank == cut).sum()) == cut_size
+    assert torch.equal(got[:n_before], ref[:n_before])                 # whole fronts: identical, same order
+    # inside the cut front the two forms add the per-objective gaps in a different order, so members
+    # whose distances agree to the last bits may swap: compare the distances of the chosen members
+    d_all = nds.crowding_distance_reference(fit, rank == cut)
+    assert bool((rank[got[n_before:]] == cut).all())
+    dg, dr = d_all[got[n_before:]], d_all[ref[n_before:]]
+    fin = torch.isfinite(dg) & torch.isfinite(dr)
+    assert torch.equal(torch.isinf(dg), torch.isinf(dr))
+    assert torch.allclose(dg[fin], dr[fin], rtol=1e-4, atol=1e-6)
+    assert len(set(got.tolist())) == k
+    # the sort-free crowding distance against the sort-based one on a single front
+    front = fit[rank == 0]
+    d_ref = nds.crowding_distance_reference(front)
+    d_got = _nds_hip.crowding(front)
+    both_inf = torch.isinf(d_ref) & torch.isinf(d_got)
+    assert torch.allclose(d_got[~both_inf], d_ref[~both_inf], rtol=1e-5, atol=1e-6)
+    assert torch.equal(torch.isinf(d_ref), torch.isinf(d_got))
