@@ -194,30 +194,45 @@ class CMAES(Algorithm):
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
+    def _shard_consts(self, local: int, device):
+        """Per-process constants of the sharded tell (built once): sqrt of the recombination weights
+        padded with zeros to the population size, and the identity permutation of the local rows."""
+        key = (local, str(device))
+        cache = self.__dict__.setdefault("_shard_cache", {})
+        if key not in cache:
+            padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)]).to(device)
+            cache[key] = {"sqrt_w_padded": torch.sqrt(padded), "ident": torch.arange(local, device=device)}
+        return cache[key]
+
     def tell_sharded(self, state, fitness, rank: int, world: int):
         from ....core import distributed as dist
 
         local = self.pop_size // world
         order, ranking = _sort.argsort_with_rank(fitness)
         my_rank = ranking[rank * local:(rank + 1) * local]
-        padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
-        w_local = padded[my_rank]                                   # 0 for rows outside the best μ
         pop = state.population
         if pop.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
             # local share of the sufficient statistics through the same kernels as the
             # single-process tell: S = sqrt(w_local)(X_local − m)/σ (zero rows for unselected
-            # individuals), Gram matrix by one library GEMM, then ONE all-reduce of n + n² floats
+            # individuals), Gram matrix by one library GEMM written straight into the message,
+            # then ONE in-place all-reduce of n + n² floats
             from ....ops import gemm as _gemm
-            ident = torch.arange(local, device=pop.device)
-            S, step_sum = _cma.elite_factor(pop, ident, state.mean, state.sigma, torch.sqrt(w_local), self.precision)
-            gram = _gemm.gram(S)
-            packed = dist.all_reduce(torch.cat([step_sum, gram.reshape(-1)]))
-            step_sum, gram = packed[: self.dim], packed[self.dim:].reshape(self.dim, self.dim)
+            consts = self._shard_consts(local, pop.device)
+            sqrt_w_local = consts["sqrt_w_padded"][my_rank]          # 0 for rows outside the best μ
+            S, step_sum = _cma.elite_factor(pop, consts["ident"], state.mean, state.sigma, sqrt_w_local, self.precision)
+            nn = self.dim * self.dim
+            packed = torch.empty(nn + self.dim, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
+            packed[nn:] = step_sum
+            _gemm.gram(S, out=packed[:nn].view(self.dim, self.dim))
+            packed = dist.all_reduce_(packed)
+            step_sum, gram = packed[nn:], packed[:nn].view(self.dim, self.dim)
             mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
                 state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
                 (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
             C = _gemm.cma_covariance_base(state.C, pc, alpha, self.c1).add_(gram, alpha=float(self.cmu))
         else:
+            padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
+            w_local = padded[my_rank]
             step_sum = w_local @ (pop - state.mean)
             ident = torch.arange(local, device=pop.device)
             zero = torch.zeros(self.dim, device=pop.device)

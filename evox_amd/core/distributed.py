@@ -149,6 +149,23 @@ def all_reduce(x: torch.Tensor, op: str = "sum", group=None) -> torch.Tensor:
     return y.to(x.device) if stage else y
 
 
+def all_reduce_(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum all-reduce that may overwrite ``x`` (a message buffer the caller owns) and returns the
+    reduced tensor: no defensive copy on the RCCL path."""
+    if not is_dist_initialized() or get_world_size() == 1:
+        return x
+    p2p_group = _p2p_group(x) if (group is None and x.dtype == torch.float32) else None
+    if p2p_group is not None:
+        return p2p_group.all_reduce(x)
+    if _via_host(x):
+        y = x.cpu()
+        _dist().all_reduce(y, group=group)
+        return y.to(x.device)
+    x = x if x.is_contiguous() else x.contiguous()
+    _dist().all_reduce(x, group=group)
+    return x
+
+
 def broadcast(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if not is_dist_initialized() or get_world_size() == 1:
         return x

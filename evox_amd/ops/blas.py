@@ -94,6 +94,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, trans_b: bo
             raise ValueError("c must be a row-major fp32 (M, N) tensor")
     else:
         c = None
+    if any(t is not None and t.data_ptr() % 16 for t in (a, b, c, out)):
+        # plans are cached per shape and were timed on 16-byte aligned operands: a view that starts
+        # elsewhere could be handed to a kernel that assumes vector-aligned rows
+        raise ValueError("gemm operands must start on a 16-byte boundary")
     alpha_dev = None
     if isinstance(alpha, torch.Tensor):
         if alpha.dtype != torch.float32 or alpha.numel() not in (1, N) or alpha.device != a.device:

@@ -178,13 +178,15 @@ def cma_covariance_base(C, pc, alpha, c1):
     return torch.addr(C * alpha, pc, pc, alpha=float(c1))
 
 
-def gram(S):
-    """``SᵀS`` in fp32 (``S`` fp32 or bf16)."""
-    if S.is_cuda and _blas.available():
-        return _blas.gemm(S, S, trans_a=True)
-    if S.dtype == torch.bfloat16:
-        return torch.mm(S.T, S, out_dtype=torch.float32)
-    return torch.mm(S.T, S)
+def gram(S, out=None):
+    """``SᵀS`` in fp32 (``S`` fp32 or bf16), optionally into a given row-major fp32 matrix."""
+    if S.is_cuda and _blas.available() and S.data_ptr() % 16 == 0 and (out is None or out.data_ptr() % 16 == 0):
+        return _blas.gemm(S, S, trans_a=True, out=out)
+    g = torch.mm(S.T, S, out_dtype=torch.float32) if S.dtype == torch.bfloat16 else torch.mm(S.T, S)
+    if out is not None:
+        out.copy_(g)
+        return out
+    return g
 
 
 def cma_covariance_from_factor(C, S, pc, alpha, c1, cmu):
