@@ -201,7 +201,10 @@ class CMAES(Algorithm):
         cache = self.__dict__.setdefault("_shard_cache", {})
         if key not in cache:
             padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)]).to(device)
-            cache[key] = {"sqrt_w_padded": torch.sqrt(padded), "ident": torch.arange(local, device=device)}
+            expect = local * self.mu / self.pop_size
+            keep = int(min(local, -(-(expect + 6.0 * math.sqrt(local) + 1) // 64) * 64))
+            cache[key] = {"sqrt_w_padded": torch.sqrt(padded), "ident": torch.arange(local, device=device),
+                          "keep": keep, "overflow": torch.zeros((), dtype=torch.bool, device=device), "calls": 0}
         return cache[key]
 
     def tell_sharded(self, state, fitness, rank: int, world: int):
@@ -218,8 +221,23 @@ class CMAES(Algorithm):
             # then ONE in-place all-reduce of n + n² floats
             from ....ops import gemm as _gemm
             consts = self._shard_consts(local, pop.device)
-            sqrt_w_local = consts["sqrt_w_padded"][my_rank]          # 0 for rows outside the best μ
-            S, step_sum = _cma.elite_factor(pop, consts["ident"], state.mean, state.sigma, sqrt_w_local, self.precision)
+            keep = consts["keep"]
+            if keep < local:
+                # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the
+                # ranks, so that number is hypergeometric with a standard deviation of at most
+                # √local / 2: the local rows are put in rank order and the first `keep` (mean + 12
+                # standard deviations) go through the gather and the Gram GEMM.  A count beyond
+                # `keep` would drop rows, so it is recorded and raised (checked every 64 calls).
+                local_order = _sort.argsort(my_rank.to(torch.float32))[:keep]
+                consts["overflow"] |= (my_rank < self.mu).sum() > keep
+                consts["calls"] += 1
+                if consts["calls"] % 64 == 0 and bool(consts["overflow"]):
+                    raise RuntimeError(f"more than {keep} of the {local} local rows were selected")
+                sqrt_w_local = consts["sqrt_w_padded"][my_rank[local_order]]
+            else:
+                local_order = consts["ident"]
+                sqrt_w_local = consts["sqrt_w_padded"][my_rank]      # 0 for rows outside the best μ
+            S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)
             nn = self.dim * self.dim
             packed = torch.empty(nn + self.dim, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
             packed[nn:] = step_sum

@@ -26,8 +26,11 @@ def main():
     c = torch.full((dim,), 3.0, device=dev)
     lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}
-    if case in ("cmaes", "openes", "pgpe", "pso_replicated"):
-        algo = {"cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")), "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
+    if case in ("cmaes", "cmaes_wide", "openes", "pgpe", "pso_replicated"):
+        algo = {"cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
+                # local shares wide enough that only the rank-ordered head of the local rows is processed
+                "cmaes_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
+                "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
                 "pgpe": lambda: A.PGPE(16, c, "adam"), "pso_replicated": lambda: A.PSO(lb, ub, 16)}[case]()
         mon = monitors.EvalMonitor()
         wf = ShardedWorkflow(algo, problems.numerical.Ackley(), monitors=[mon])
@@ -35,10 +38,10 @@ def main():
         for _ in range(30):
             state = wf.step(state)
         alg = state.get_child_state("algorithm")
-        vec = alg.mean if case == "cmaes" else (alg.global_best_location if case == "pso_replicated" else alg.center)
+        vec = alg.mean if case in ("cmaes", "cmaes_wide") else (alg.global_best_location if case == "pso_replicated" else alg.center)
         result = {"vec": vec.tolist(), "world": state.world_size, "rank": state.rank,
                   "row_sharded": wf.row_sharded, "best": float(mon.get_best_fitness()),
-                  "local_rows": int(alg.population.shape[0]) if case == "cmaes" else None}
+                  "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_wide") else None}
     elif case == "std_multi_device":
         wf = workflows.StdWorkflow(A.PSO(lb, ub, 16), problems.numerical.Sphere())
         state = wf.enable_multi_devices(wf.init(ex.PRNGKey(5)))

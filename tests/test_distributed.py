@@ -114,7 +114,7 @@ def test_process_distributed_workflow_cso():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cmaes", "openes"])
+@pytest.mark.parametrize("case", ["cmaes", "cmaes_wide", "openes"])
 def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
     """The GPU code path of the row-sharded tell (gather kernel, Gram GEMM, fused path kernel): two
     and four ranks share the one GPU of the test box and talk over gloo."""
