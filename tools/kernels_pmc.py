@@ -27,5 +27,27 @@ for _ in range(3):
     pop = es.perturb(key, net.init(rnd.PRNGKey(1)).to(dev), 0.05, 1024, mirrored=True)   # es_perturb_kernel
     a = net.batched_apply(pop, torch.randn(1024, 1, 244, device=dev))        # mlp_forward_kernel
     gsum = es.weighted_noise_sum(key, torch.randn(1024, device=dev), net.n_params)      # noise_wsum_kernel
+# kernels added with the native factorisation path and the multi-objective / DE fusions
+from evox_amd import problems
+from evox_amd.ops import blas, de_adapt, sort, variation, _nds_hip
+ws = blas.NSWorkspace(n, dev)
+Cm = torch.eye(n, device=dev) + 0.01 * torch.randn(n, n, device=dev); Cm = (Cm + Cm.T) / 2 + 0.3 * torch.eye(n, device=dev)
+lb20, ub20 = torch.full((20,), -100.0, device=dev), torch.full((20,), 100.0, device=dev)
+cec = problems.numerical.CEC2022TestSuit.create(1)
+dtlz = problems.numerical.DTLZ2(m=3)
+for _ in range(3):
+    blas.ns_sqrt(Cm, ws, 4)                                                  # ns_matvec / ns_scale / ns_residual / ns_finish
+    o, rk = sort.argsort_with_rank(torch.randn(10000, device=dev))           # rank_sort_kernel
+    base = gemm.cma_covariance_base(Cm, pc, torch.tensor(0.99, device=dev), 1e-6)   # cov_base_kernel
+    px = torch.rand(100000, 12, device=dev)
+    off = variation.sbx_pm(key, key, px, torch.zeros(12, device=dev), torch.ones(12, device=dev))   # sbx_pm_kernel
+    fz, _ = dtlz.evaluate(None, px)                                          # dtlz_kernel
+    fr = torch.rand(8000, 3, device=dev)
+    cd = _nds_hip.crowding(fr)                                               # crowding_kernel (+3 rank sorts)
+    pop20 = torch.rand(50000, 20, device=dev) * 200 - 100
+    fc, _ = cec.evaluate(None, pop20)                                        # shift_rotate_kernel
+    Fv, CRv = de_adapt.draw_params(key, key, key, torch.full((100,), 0.5, device=dev), torch.full((100,), 0.5, device=dev), 50000)
+    de_adapt.select_and_adapt(pop20, pop20 + 1, fc + 1, fc, Fv, CRv, torch.full((100,), 0.5, device=dev),
+                              torch.full((100,), 0.5, device=dev), strict=True, weight_by_gain=True, mode="shade")
 torch.cuda.synchronize()
 print("done")
