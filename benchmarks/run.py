@@ -116,7 +116,8 @@ def openes_mlp(args):
     pop = args.pop or 4096
     dtype = torch.bfloat16 if args.param_dtype == "bf16" else torch.float32
     policy = net.batched_apply
-    to_param_dtype = [] if dtype == torch.float32 else [lambda w: w.to(dtype)]     # once per generation
+    from evox_amd.ops.es import cast_population
+    to_param_dtype = [] if dtype == torch.float32 else [lambda w: cast_population(w, dtype)]     # once per generation
     prob = TensorEnvProblem(policy, SyntheticLocomotion(obs_dim, act_dim, seed=4), max_episode_length=args.episode_length,
                             num_episodes=1)
     center = net.init(ex.PRNGKey(0)).to(device)

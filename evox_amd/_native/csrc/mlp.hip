@@ -12,6 +12,7 @@
 //                            accumulated with LDS float atomics, then bias + activation.
 #include "hip_common.h"
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 
 using namespace evox;
 
@@ -37,16 +38,28 @@ __device__ __forceinline__ float activate(float x, int act) {
   }
 }
 
-__device__ __forceinline__ float ld1(const float* p) { return *p; }
-__device__ __forceinline__ float ld1(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+
+// Parameter rows are read exactly once: non-temporal loads keep them from displacing the data that
+// IS reused across workgroups (the centre of a mirrored population) from the L2.
+__device__ __forceinline__ float ld1(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ld1(const uint16_t* p) {
+  return __uint_as_float((uint32_t)__builtin_nontemporal_load(p) << 16);
+}
 __device__ __forceinline__ void ld4(const float* p, float (&w)[4]) {
-  const float4 v = *reinterpret_cast<const float4*>(p);
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
   w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 __device__ __forceinline__ void ld4(const uint16_t* p, float (&w)[4]) {
-  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
   w[0] = __uint_as_float(v.x << 16); w[1] = __uint_as_float(v.x & 0xffff0000u);
   w[2] = __uint_as_float(v.y << 16); w[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+// centre of a mirrored population: ordinary (cached) loads
+__device__ __forceinline__ void ld4c(const float* p, float (&w)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
 }
 
 template <typename T, int E>
@@ -136,15 +149,195 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const T* __restrict__ f
   for (int e = t; e < E * nlast; e += NT) out[(int64_t)p * E * nlast + e] = hin[(e / nlast) * W + (e % nlast)];
 }
 
+// Mirrored populations, NP pairs per workgroup.  Row half+p equals 2·center − row p, so a workgroup
+// reads the "+" rows of its NP pairs once (HBM, non-temporal) and ONE pass of the centre (cached; its
+// cost is shared by the 2·NP individuals), rebuilds the "−" weights in registers and advances the
+// 2·NP·E activation vectors together.  Activation set index: (q·2 + sign)·E + e.
+template <typename T, int E, int NP>
+__global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat, int64_t pitch,
+                                                      const float* __restrict__ center, int half,
+                                                      const float* __restrict__ obs, float* __restrict__ out,
+                                                      MlpDesc d) {
+  constexpr int EA = 2 * NP * E;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int W = d.max_width;
+  float* buf0 = lds;
+  float* buf1 = lds + EA * W;
+  const int p0 = blockIdx.x * NP;                       // first pair of this workgroup
+  const int t = threadIdx.x;
+  auto member = [&](int ea) -> int64_t {                 // population row evaluated by activation set ea
+    const int q = ea / (2 * E), sign = (ea / E) & 1;
+    return (int64_t)(sign ? half : 0) + p0 + q;
+  };
+  const int in0 = d.in[0];
+  for (int e = t; e < EA * in0; e += NT) {
+    const int ea = e / in0, c = e - ea * in0;
+    buf0[ea * W + c] = obs[(member(ea) * E + (ea % E)) * in0 + c];
+  }
+  __syncthreads();
+
+  float* hin = buf0;
+  float* hout = buf1;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int nin = d.in[l], nout = d.out[l], act = d.act[l];
+    const bool has_b = d.b_off[l] >= 0;
+    const float* Cl = center + d.w_off[l];
+    const float* cbl = center + (has_b ? d.b_off[l] : 0);
+    const T* Wq[NP];
+    const T* bq[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const T* theta = flat + (int64_t)(p0 + q) * pitch;
+      Wq[q] = theta + d.w_off[l];
+      bq[q] = theta + (has_b ? d.b_off[l] : 0);
+    }
+    if (nout > 64 && d.vec4[l]) {
+      for (int c0 = t * 4; c0 < nout; c0 += NT * 4) {
+        float acc[EA][4];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float b = has_b ? ld1(bq[q] + c0 + k) : 0.f;
+            const float bm = has_b ? 2.f * cbl[c0 + k] - b : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              acc[(q * 2) * E + e][k] = b;
+              acc[(q * 2 + 1) * E + e][k] = bm;
+            }
+          }
+#pragma unroll 4
+        for (int i = 0; i < nin; ++i) {
+          float cw[4];
+          ld4c(Cl + (int64_t)i * nout + c0, cw);
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            float w[4], wm[4];
+            ld4(Wq[q] + (int64_t)i * nout + c0, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wm[k] = 2.f * cw[k] - w[k];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const float hp = hin[((q * 2) * E + e) * W + i], hm = hin[((q * 2 + 1) * E + e) * W + i];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                acc[(q * 2) * E + e][k] = fmaf(hp, w[k], acc[(q * 2) * E + e][k]);
+                acc[(q * 2 + 1) * E + e][k] = fmaf(hm, wm[k], acc[(q * 2 + 1) * E + e][k]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int ea = 0; ea < EA; ++ea)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hout[ea * W + c0 + k] = activate(acc[ea][k], act);
+      }
+    } else if (nout > 64) {
+      // wide layer whose rows are not 16-byte aligned: one output column per thread
+      for (int c = t; c < nout; c += NT) {
+        float acc[EA];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const float b = has_b ? ld1(bq[q] + c) : 0.f;
+          const float bm = has_b ? 2.f * cbl[c] - b : 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) { acc[(q * 2) * E + e] = b; acc[(q * 2 + 1) * E + e] = bm; }
+        }
+#pragma unroll 8
+        for (int i = 0; i < nin; ++i) {
+          const float cw = Cl[(int64_t)i * nout + c];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            const float w = ld1(Wq[q] + (int64_t)i * nout + c);
+            const float wm = 2.f * cw - w;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              acc[(q * 2) * E + e] = fmaf(hin[((q * 2) * E + e) * W + i], w, acc[(q * 2) * E + e]);
+              acc[(q * 2 + 1) * E + e] = fmaf(hin[((q * 2 + 1) * E + e) * W + i], wm, acc[(q * 2 + 1) * E + e]);
+            }
+          }
+        }
+#pragma unroll
+        for (int ea = 0; ea < EA; ++ea) hout[ea * W + c] = activate(acc[ea], act);
+      }
+    } else {
+      // narrow layers: flat walk with LDS accumulation (a small share of the parameters)
+      for (int e = t; e < EA * nout; e += NT) {
+        const int ea = e / nout, c = e - ea * nout;
+        const int q = ea / (2 * E), sign = (ea / E) & 1;
+        float b = has_b ? ld1(bq[q] + c) : 0.f;
+        if (has_b && sign) b = 2.f * cbl[c] - b;
+        hout[ea * W + c] = b;
+      }
+      __syncthreads();
+      const int total = nin * nout;
+      for (int idx = t; idx < total; idx += NT) {
+        const float cw = Cl[idx];
+        const int i = idx / nout, c = idx - i * nout;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const float w = ld1(Wq[q] + idx);
+          const float wm = 2.f * cw - w;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            atomicAdd(&hout[((q * 2) * E + e) * W + c], hin[((q * 2) * E + e) * W + i] * w);
+            atomicAdd(&hout[((q * 2 + 1) * E + e) * W + c], hin[((q * 2 + 1) * E + e) * W + i] * wm);
+          }
+        }
+      }
+      __syncthreads();
+      for (int e = t; e < EA * nout; e += NT) {
+        float* v = &hout[(e / nout) * W + (e % nout)];
+        *v = activate(*v, act);
+      }
+    }
+    __syncthreads();
+    float* tmp = hin; hin = hout; hout = tmp;
+  }
+  const int nlast = d.out[d.n_layers - 1];
+  for (int e = t; e < EA * nlast; e += NT) {
+    const int ea = e / nlast, c = e - ea * nlast;
+    out[(member(ea) * E + (ea % E)) * nlast + c] = hin[ea * W + c];
+  }
+}
+
+template <typename T, int E>
+int launch_pairs(const T* flat, int64_t pitch, const float* center, int half, const float* obs, float* out,
+                 const MlpDesc& d, hipStream_t s) {
+  // Pairs per workgroup: sharing one centre pass between several pairs was measured slower than one
+  // pair per workgroup (98 / 123 / 165 ms per OpenES generation for 1 / 2 / 4 pairs: fewer, fatter
+  // workgroups hide less latency and the centre stays cached anyway), so 1 is the default.
+  auto lds_of = [&](int np) { return (size_t)2 * (2 * np * E) * d.max_width * sizeof(float); };
+  const char* cap_env = getenv("EVOX_AMD_MLP_PAIRS");
+  const int cap = cap_env ? atoi(cap_env) : 1;
+  if (cap >= 4 && half % 4 == 0 && lds_of(4) <= 64 * 1024 && E == 1)
+    mlp_pair_kernel<T, E, 4><<<half / 4, NT, lds_of(4), s>>>(flat, pitch, center, half, obs, out, d);
+  else if (cap >= 2 && half % 2 == 0 && lds_of(2) <= 64 * 1024)
+    mlp_pair_kernel<T, E, 2><<<half / 2, NT, lds_of(2), s>>>(flat, pitch, center, half, obs, out, d);
+  else if (lds_of(1) <= 64 * 1024)
+    mlp_pair_kernel<T, E, 1><<<half, NT, lds_of(1), s>>>(flat, pitch, center, half, obs, out, d);
+  else
+    return (int)hipErrorInvalidValue;
+  return last_launch_status();
+}
+
 template <typename T>
-int launch(const T* flat, int64_t pitch, const float* obs, float* out, int P, int E, const MlpDesc& d, hipStream_t s) {
+int launch(const T* flat, int64_t pitch, const float* center, int half, const float* obs, float* out, int P, int E,
+           const MlpDesc& d, hipStream_t s) {
+  if (center != nullptr) {
+    if (E == 1) return launch_pairs<T, 1>(flat, pitch, center, half, obs, out, d, s);
+    if (E == 2) return launch_pairs<T, 2>(flat, pitch, center, half, obs, out, d, s);
+    return (int)hipErrorInvalidValue;
+  }
   const size_t lds = (size_t)2 * E * d.max_width * sizeof(float);
+#define EVOX_MLP(EE) mlp_forward_kernel<T, EE><<<P, NT, lds, s>>>(flat, pitch, obs, out, d)
   switch (E) {
-    case 1: mlp_forward_kernel<T, 1><<<P, NT, lds, s>>>(flat, pitch, obs, out, d); break;
-    case 2: mlp_forward_kernel<T, 2><<<P, NT, lds, s>>>(flat, pitch, obs, out, d); break;
-    case 4: mlp_forward_kernel<T, 4><<<P, NT, lds, s>>>(flat, pitch, obs, out, d); break;
+    case 1: EVOX_MLP(1); break;
+    case 2: EVOX_MLP(2); break;
+    case 4: EVOX_MLP(4); break;
     default: return (int)hipErrorInvalidValue;
   }
+#undef EVOX_MLP
   return last_launch_status();
 }
 
@@ -152,27 +345,44 @@ int launch(const T* flat, int64_t pitch, const float* obs, float* out, int P, in
 
 // sizes: n_layers + 1 widths; acts: per layer; dtype: 0 fp32, 1 bf16.  obs (P, E, sizes[0]) fp32,
 // out (P, E, sizes[n_layers]) fp32.  E in {1, 2, 4}; every width <= 4096 / E.
-EVOX_API int evox_hip_mlp_forward(const void* flat, int dtype, int64_t pitch, const float* obs, float* out, int P, int E,
-                                  const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
+// center != nullptr: the population is mirrored, row half + p = 2·center − row p for p < half = P/2
+// (center fp32 with the layout of one row); only rows [0, half) are read.  E in {1, 2} then.
+static int mlp_dispatch(const void* flat, int dtype, int64_t pitch, const float* center, const float* obs, float* out,
+                        int P, int E, const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
   if (n_layers < 1 || n_layers > kMaxLayers || P <= 0) return (int)hipErrorInvalidValue;
+  if (center && (P % 2)) return (int)hipErrorInvalidValue;
   MlpDesc d;
   d.n_layers = n_layers;
   d.max_width = 0;
   int64_t off = 0;
-  const int64_t esz = dtype == 1 ? 2 : 4;
   for (int l = 0; l < n_layers; ++l) {
     d.in[l] = sizes[l]; d.out[l] = sizes[l + 1]; d.act[l] = acts[l];
     d.w_off[l] = off; off += (int64_t)sizes[l] * sizes[l + 1];
     d.b_off[l] = bias ? off : -1; if (bias) off += sizes[l + 1];
-    const bool aligned = ((uintptr_t)flat % 16 == 0) && (pitch % 4 == 0) && (d.w_off[l] % 4 == 0) && (sizes[l + 1] % 4 == 0);
+    const bool aligned = ((uintptr_t)flat % 16 == 0) && (pitch % 4 == 0) && (d.w_off[l] % 4 == 0) && (sizes[l + 1] % 4 == 0) &&
+                         (!center || (uintptr_t)center % 16 == 0);
     d.vec4[l] = aligned ? 1 : 0;
     if (sizes[l] > d.max_width) d.max_width = sizes[l];
     if (sizes[l + 1] > d.max_width) d.max_width = sizes[l + 1];
   }
-  (void)esz;
   if (off > pitch) return (int)hipErrorInvalidValue;
   d.max_width = (d.max_width + 3) / 4 * 4;
-  if ((size_t)2 * E * d.max_width * sizeof(float) > 64 * 1024) return (int)hipErrorInvalidValue;
-  if (dtype == 1) return launch<uint16_t>((const uint16_t*)flat, pitch, obs, out, P, E, d, (hipStream_t)stream);
-  return launch<float>((const float*)flat, pitch, obs, out, P, E, d, (hipStream_t)stream);
+  const int ea = center ? 2 * E : E;
+  if ((size_t)2 * ea * d.max_width * sizeof(float) > 64 * 1024) return (int)hipErrorInvalidValue;
+  const int half = P / 2;
+  if (dtype == 1)
+    return launch<uint16_t>((const uint16_t*)flat, pitch, center, half, obs, out, P, E, d, (hipStream_t)stream);
+  return launch<float>((const float*)flat, pitch, center, half, obs, out, P, E, d, (hipStream_t)stream);
+}
+
+EVOX_API int evox_hip_mlp_forward(const void* flat, int dtype, int64_t pitch, const float* obs, float* out, int P, int E,
+                                  const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
+  return mlp_dispatch(flat, dtype, pitch, nullptr, obs, out, P, E, sizes, acts, n_layers, bias, stream);
+}
+
+EVOX_API int evox_hip_mlp_forward_mirrored(const void* flat, int dtype, int64_t pitch, const float* center,
+                                           const float* obs, float* out, int P, int E, const int* sizes, const int* acts,
+                                           int n_layers, int bias, void* stream) {
+  if (!center) return (int)hipErrorInvalidValue;
+  return mlp_dispatch(flat, dtype, pitch, center, obs, out, P, E, sizes, acts, n_layers, bias, stream);
 }

@@ -69,7 +69,8 @@ def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
     from .. import _native
     from ..ops._util import check, hip, stream_of
     P_, I_, I64_ = _native.P, _native.I, _native.I64
-    _native.register_hip_api({"evox_hip_mlp_forward": (I_, [P_, I_, I64_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
+    _native.register_hip_api({"evox_hip_mlp_forward": (I_, [P_, I_, I64_, P_, P_, I_, I_, P_, P_, I_, I_, P_]),
+                              "evox_hip_mlp_forward_mirrored": (I_, [P_, I_, I64_, P_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
     P, E = flat.shape[0], obs.shape[1]
     n_layers = len(sizes) - 1
     x = obs.to(torch.float32).contiguous()
@@ -77,10 +78,34 @@ def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
     c_sizes = (ctypes.c_int * (n_layers + 1))(*[int(s) for s in sizes])
     acts = [_ACT_CODE[activation]] * (n_layers - 1) + [_ACT_CODE[final_activation]]
     c_acts = (ctypes.c_int * n_layers)(*acts)
+    mirror = _mirror_of(flat, E, sizes)
+    if mirror is not None:
+        # mirrored population: each workgroup evaluates a (+, −) pair from one pass over the + row
+        check(hip().evox_hip_mlp_forward_mirrored(
+            flat.data_ptr(), 1 if flat.dtype == torch.bfloat16 else 0, flat.stride(0), mirror.data_ptr(), x.data_ptr(),
+            out.data_ptr(), P, E, ctypes.addressof(c_sizes), ctypes.addressof(c_acts), n_layers, int(bool(bias)),
+            stream_of(flat)), "mlp_forward_mirrored")
+        return out
     check(hip().evox_hip_mlp_forward(flat.data_ptr(), 1 if flat.dtype == torch.bfloat16 else 0, flat.stride(0), x.data_ptr(),
                                      out.data_ptr(), P, E, ctypes.addressof(c_sizes), ctypes.addressof(c_acts), n_layers,
                                      int(bool(bias)), stream_of(flat)), "mlp_forward")
     return out
+
+
+def _mirror_of(flat, E, sizes):
+    """The centre of a mirrored population (``ops.es.perturb`` marks the tensors it returns) when the
+    pair form of the kernel applies to it, else None."""
+    import os
+
+    tag = getattr(flat, "_evox_mirror", None)
+    if tag is None or os.environ.get("EVOX_AMD_MLP_MIRROR", "1") == "0":
+        return None
+    center, half = tag
+    if (flat.shape[0] != 2 * half or E not in (1, 2) or center.dtype != torch.float32 or not center.is_contiguous()
+            or center.device != flat.device or center.numel() != flat.shape[1]
+            or 4 * E * ((max(sizes) + 3) // 4 * 4) * 4 > 64 * 1024):
+        return None
+    return center
 
 
 class MLP:

@@ -66,7 +66,12 @@ def perturb(key, center, scale, n_rows: int, mirrored: bool = False, row_offset:
     dim = center.shape[0]
     total = n_rows if total_rows is None else total_rows
     if on_gpu(center) and center.dtype == torch.float32:
-        return _perturb_hip(key, center, scale, n_rows, dim, row_offset, total // 2 if mirrored else 0, out_dtype)
+        out = _perturb_hip(key, center, scale, n_rows, dim, row_offset, total // 2 if mirrored else 0, out_dtype)
+        if mirrored and row_offset == 0 and total == n_rows and n_rows % 2 == 0:
+            # the whole mirrored population in one tensor: row half+j = 2·center − row j.  Consumers
+            # that stream every row (the per-individual MLP kernel) can read the first half only.
+            out._evox_mirror = (center, n_rows // 2)
+        return out
     if out_dtype not in (None, torch.float32):
         return perturb(key, center, scale, n_rows, mirrored, row_offset, total_rows).to(out_dtype)
     if not mirrored:
@@ -123,3 +128,21 @@ def _has(symbol: str) -> bool:
         return True
     except AttributeError:
         return False
+
+
+def cast_population(pop: torch.Tensor, dtype) -> torch.Tensor:
+    """``pop.to(dtype)`` that keeps the mirrored-population mark of ``perturb`` (a storage-precision
+    cast leaves row half+j = 2·center − row j true up to the rounding of the stored rows, which is
+    what a consumer of reduced-precision parameters accepts anyway)."""
+    if pop.dim() == 2 and pop.is_cuda and pop.shape[1] % 4:
+        # keep rows padded to a multiple of four elements (vector loads in the consumers)
+        pitch = (pop.shape[1] + 3) // 4 * 4
+        buf = torch.empty((pop.shape[0], pitch), dtype=dtype, device=pop.device)
+        out = buf[:, :pop.shape[1]]
+        out.copy_(pop)
+    else:
+        out = pop.to(dtype)
+    tag = getattr(pop, "_evox_mirror", None)
+    if tag is not None:
+        out._evox_mirror = tag
+    return out

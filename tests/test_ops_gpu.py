@@ -608,3 +608,27 @@ def test_fused_rank_crowding_truncation_matches_sort_formulation(cuda, n, m, k):
     both_inf = torch.isinf(d_ref) & torch.isinf(d_got)
     assert torch.allclose(d_got[~both_inf], d_ref[~both_inf], rtol=1e-5, atol=1e-6)
     assert torch.equal(torch.isinf(d_ref), torch.isinf(d_got))
+
+
+@pytest.mark.parametrize("sizes", [(244, 1024, 720, 17), (27, 64, 8), (5, 130, 3)])
+@pytest.mark.parametrize("E", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pop_n", [64, 20, 6])
+def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, dtype, pop_n, monkeypatch):
+    """A mirrored population evaluated pair-wise from its first half (second half rebuilt from the
+    centre) against the plain kernel that streams every row."""
+    from evox_amd.models import MLP
+    from evox_amd.ops import es
+
+    net = MLP(list(sizes))
+    center = net.init(rnd.PRNGKey(1)).to(cuda)
+    pop = es.perturb(rnd.PRNGKey(2).to(cuda), center, 0.05, pop_n, mirrored=True, out_dtype=dtype)
+    assert getattr(pop, "_evox_mirror", None) is not None
+    obs = torch.randn(pop_n, E, sizes[0], device=cuda)
+    got = net.batched_apply(pop, obs)
+    monkeypatch.setenv("EVOX_AMD_MLP_MIRROR", "0")
+    ref = net.batched_apply(pop, obs)
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    h = pop_n // 2
+    assert torch.allclose(got[:h], ref[:h], rtol=1e-5, atol=1e-5)               # + members: the same arithmetic
+    assert torch.allclose(got[h:], ref[h:], rtol=tol, atol=tol), (got[h:] - ref[h:]).abs().max()
