@@ -56,10 +56,17 @@ __device__ __forceinline__ void ld4(const uint16_t* p, float (&w)[4]) {
   w[0] = __uint_as_float(v.x << 16); w[1] = __uint_as_float(v.x & 0xffff0000u);
   w[2] = __uint_as_float(v.y << 16); w[3] = __uint_as_float(v.y & 0xffff0000u);
 }
-// centre of a mirrored population: ordinary (cached) loads
+// centre of a mirrored population (fp32, or bf16 next to bf16 rows): ordinary (cached) loads
+__device__ __forceinline__ float ld1c(const float* p) { return *p; }
+__device__ __forceinline__ float ld1c(const uint16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
 __device__ __forceinline__ void ld4c(const float* p, float (&w)[4]) {
   const float4 v = *reinterpret_cast<const float4*>(p);
   w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+}
+__device__ __forceinline__ void ld4c(const uint16_t* p, float (&w)[4]) {
+  const uint2 v = *reinterpret_cast<const uint2*>(p);
+  w[0] = __uint_as_float(v.x << 16); w[1] = __uint_as_float(v.x & 0xffff0000u);
+  w[2] = __uint_as_float(v.y << 16); w[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
 template <typename T, int E>
@@ -153,9 +160,9 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const T* __restrict__ f
 // reads the "+" rows of its NP pairs once (HBM, non-temporal) and ONE pass of the centre (cached; its
 // cost is shared by the 2·NP individuals), rebuilds the "−" weights in registers and advances the
 // 2·NP·E activation vectors together.  Activation set index: (q·2 + sign)·E + e.
-template <typename T, int E, int NP>
+template <typename T, typename CT, int E, int NP>
 __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat, int64_t pitch,
-                                                      const float* __restrict__ center, int half,
+                                                      const CT* __restrict__ center, int half,
                                                       const float* __restrict__ obs, float* __restrict__ out,
                                                       MlpDesc d) {
   constexpr int EA = 2 * NP * E;
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
   for (int l = 0; l < d.n_layers; ++l) {
     const int nin = d.in[l], nout = d.out[l], act = d.act[l];
     const bool has_b = d.b_off[l] >= 0;
-    const float* Cl = center + d.w_off[l];
-    const float* cbl = center + (has_b ? d.b_off[l] : 0);
+    const CT* Cl = center + d.w_off[l];
+    const CT* cbl = center + (has_b ? d.b_off[l] : 0);
     const T* Wq[NP];
     const T* bq[NP];
 #pragma unroll
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float b = has_b ? ld1(bq[q] + c0 + k) : 0.f;
-            const float bm = has_b ? 2.f * cbl[c0 + k] - b : 0.f;
+            const float bm = has_b ? 2.f * ld1c(cbl + c0 + k) - b : 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
               acc[(q * 2) * E + e][k] = b;
@@ -239,13 +246,13 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
           const float b = has_b ? ld1(bq[q] + c) : 0.f;
-          const float bm = has_b ? 2.f * cbl[c] - b : 0.f;
+          const float bm = has_b ? 2.f * ld1c(cbl + c) - b : 0.f;
 #pragma unroll
           for (int e = 0; e < E; ++e) { acc[(q * 2) * E + e] = b; acc[(q * 2 + 1) * E + e] = bm; }
         }
 #pragma unroll 8
         for (int i = 0; i < nin; ++i) {
-          const float cw = Cl[(int64_t)i * nout + c];
+          const float cw = ld1c(Cl + (int64_t)i * nout + c);
 #pragma unroll
           for (int q = 0; q < NP; ++q) {
             const float w = ld1(Wq[q] + (int64_t)i * nout + c);
@@ -266,13 +273,13 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
         const int ea = e / nout, c = e - ea * nout;
         const int q = ea / (2 * E), sign = (ea / E) & 1;
         float b = has_b ? ld1(bq[q] + c) : 0.f;
-        if (has_b && sign) b = 2.f * cbl[c] - b;
+        if (has_b && sign) b = 2.f * ld1c(cbl + c) - b;
         hout[ea * W + c] = b;
       }
       __syncthreads();
       const int total = nin * nout;
       for (int idx = t; idx < total; idx += NT) {
-        const float cw = Cl[idx];
+        const float cw = ld1c(Cl + idx);
         const int i = idx / nout, c = idx - i * nout;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -301,8 +308,8 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
   }
 }
 
-template <typename T, int E>
-int launch_pairs(const T* flat, int64_t pitch, const float* center, int half, const float* obs, float* out,
+template <typename T, typename CT, int E>
+int launch_pairs(const T* flat, int64_t pitch, const CT* center, int half, const float* obs, float* out,
                  const MlpDesc& d, hipStream_t s) {
   // Pairs per workgroup: sharing one centre pass between several pairs was measured slower than one
   // pair per workgroup (98 / 123 / 165 ms per OpenES generation for 1 / 2 / 4 pairs: fewer, fatter
@@ -311,22 +318,29 @@ int launch_pairs(const T* flat, int64_t pitch, const float* center, int half, co
   const char* cap_env = getenv("EVOX_AMD_MLP_PAIRS");
   const int cap = cap_env ? atoi(cap_env) : 1;
   if (cap >= 4 && half % 4 == 0 && lds_of(4) <= 64 * 1024 && E == 1)
-    mlp_pair_kernel<T, E, 4><<<half / 4, NT, lds_of(4), s>>>(flat, pitch, center, half, obs, out, d);
+    mlp_pair_kernel<T, CT, E, 4><<<half / 4, NT, lds_of(4), s>>>(flat, pitch, center, half, obs, out, d);
   else if (cap >= 2 && half % 2 == 0 && lds_of(2) <= 64 * 1024)
-    mlp_pair_kernel<T, E, 2><<<half / 2, NT, lds_of(2), s>>>(flat, pitch, center, half, obs, out, d);
+    mlp_pair_kernel<T, CT, E, 2><<<half / 2, NT, lds_of(2), s>>>(flat, pitch, center, half, obs, out, d);
   else if (lds_of(1) <= 64 * 1024)
-    mlp_pair_kernel<T, E, 1><<<half, NT, lds_of(1), s>>>(flat, pitch, center, half, obs, out, d);
+    mlp_pair_kernel<T, CT, E, 1><<<half, NT, lds_of(1), s>>>(flat, pitch, center, half, obs, out, d);
   else
     return (int)hipErrorInvalidValue;
   return last_launch_status();
 }
 
 template <typename T>
-int launch(const T* flat, int64_t pitch, const float* center, int half, const float* obs, float* out, int P, int E,
-           const MlpDesc& d, hipStream_t s) {
+int launch(const T* flat, int64_t pitch, const void* center, int center_dtype, int half, const float* obs, float* out,
+           int P, int E, const MlpDesc& d, hipStream_t s) {
   if (center != nullptr) {
-    if (E == 1) return launch_pairs<T, 1>(flat, pitch, center, half, obs, out, d, s);
-    if (E == 2) return launch_pairs<T, 2>(flat, pitch, center, half, obs, out, d, s);
+    if (center_dtype == 1) {
+      const uint16_t* c16 = (const uint16_t*)center;
+      if (E == 1) return launch_pairs<T, uint16_t, 1>(flat, pitch, c16, half, obs, out, d, s);
+      if (E == 2) return launch_pairs<T, uint16_t, 2>(flat, pitch, c16, half, obs, out, d, s);
+    } else {
+      const float* c32 = (const float*)center;
+      if (E == 1) return launch_pairs<T, float, 1>(flat, pitch, c32, half, obs, out, d, s);
+      if (E == 2) return launch_pairs<T, float, 2>(flat, pitch, c32, half, obs, out, d, s);
+    }
     return (int)hipErrorInvalidValue;
   }
   const size_t lds = (size_t)2 * E * d.max_width * sizeof(float);
@@ -346,9 +360,10 @@ int launch(const T* flat, int64_t pitch, const float* center, int half, const fl
 // sizes: n_layers + 1 widths; acts: per layer; dtype: 0 fp32, 1 bf16.  obs (P, E, sizes[0]) fp32,
 // out (P, E, sizes[n_layers]) fp32.  E in {1, 2, 4}; every width <= 4096 / E.
 // center != nullptr: the population is mirrored, row half + p = 2·center − row p for p < half = P/2
-// (center fp32 with the layout of one row); only rows [0, half) are read.  E in {1, 2} then.
-static int mlp_dispatch(const void* flat, int dtype, int64_t pitch, const float* center, const float* obs, float* out,
-                        int P, int E, const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
+// (center fp32, or bf16 when center_dtype == 1, with the layout of one row); only rows [0, half) are
+// read.  E in {1, 2} then.
+static int mlp_dispatch(const void* flat, int dtype, int64_t pitch, const void* center, int center_dtype,
+                        const float* obs, float* out, int P, int E, const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
   if (n_layers < 1 || n_layers > kMaxLayers || P <= 0) return (int)hipErrorInvalidValue;
   if (center && (P % 2)) return (int)hipErrorInvalidValue;
   MlpDesc d;
@@ -371,18 +386,18 @@ static int mlp_dispatch(const void* flat, int dtype, int64_t pitch, const float*
   if ((size_t)2 * ea * d.max_width * sizeof(float) > 64 * 1024) return (int)hipErrorInvalidValue;
   const int half = P / 2;
   if (dtype == 1)
-    return launch<uint16_t>((const uint16_t*)flat, pitch, center, half, obs, out, P, E, d, (hipStream_t)stream);
-  return launch<float>((const float*)flat, pitch, center, half, obs, out, P, E, d, (hipStream_t)stream);
+    return launch<uint16_t>((const uint16_t*)flat, pitch, center, center_dtype, half, obs, out, P, E, d, (hipStream_t)stream);
+  return launch<float>((const float*)flat, pitch, center, center_dtype, half, obs, out, P, E, d, (hipStream_t)stream);
 }
 
 EVOX_API int evox_hip_mlp_forward(const void* flat, int dtype, int64_t pitch, const float* obs, float* out, int P, int E,
                                   const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
-  return mlp_dispatch(flat, dtype, pitch, nullptr, obs, out, P, E, sizes, acts, n_layers, bias, stream);
+  return mlp_dispatch(flat, dtype, pitch, nullptr, 0, obs, out, P, E, sizes, acts, n_layers, bias, stream);
 }
 
-EVOX_API int evox_hip_mlp_forward_mirrored(const void* flat, int dtype, int64_t pitch, const float* center,
-                                           const float* obs, float* out, int P, int E, const int* sizes, const int* acts,
+EVOX_API int evox_hip_mlp_forward_mirrored(const void* flat, int dtype, int64_t pitch, const void* center,
+                                           int center_dtype, const float* obs, float* out, int P, int E, const int* sizes, const int* acts,
                                            int n_layers, int bias, void* stream) {
   if (!center) return (int)hipErrorInvalidValue;
-  return mlp_dispatch(flat, dtype, pitch, center, obs, out, P, E, sizes, acts, n_layers, bias, stream);
+  return mlp_dispatch(flat, dtype, pitch, center, center_dtype, obs, out, P, E, sizes, acts, n_layers, bias, stream);
 }

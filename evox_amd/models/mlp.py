@@ -70,7 +70,7 @@ def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
     from ..ops._util import check, hip, stream_of
     P_, I_, I64_ = _native.P, _native.I, _native.I64
     _native.register_hip_api({"evox_hip_mlp_forward": (I_, [P_, I_, I64_, P_, P_, I_, I_, P_, P_, I_, I_, P_]),
-                              "evox_hip_mlp_forward_mirrored": (I_, [P_, I_, I64_, P_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
+                              "evox_hip_mlp_forward_mirrored": (I_, [P_, I_, I64_, P_, I_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
     P, E = flat.shape[0], obs.shape[1]
     n_layers = len(sizes) - 1
     x = obs.to(torch.float32).contiguous()
@@ -81,8 +81,17 @@ def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
     mirror = _mirror_of(flat, E, sizes)
     if mirror is not None:
         # mirrored population: each workgroup evaluates a (+, −) pair from one pass over the + row
+        if flat.dtype == torch.bfloat16:
+            # bf16 rows: a bf16 copy of the centre (made once per population) halves the centre traffic;
+            # 2·bf16(c) − bf16(w₊) is as close to c − σz as a stored bf16 row would be
+            c16 = getattr(flat, "_evox_mirror_c16", None)
+            if c16 is None:
+                c16 = mirror.to(torch.bfloat16)
+                flat._evox_mirror_c16 = c16
+            mirror = c16
         check(hip().evox_hip_mlp_forward_mirrored(
-            flat.data_ptr(), 1 if flat.dtype == torch.bfloat16 else 0, flat.stride(0), mirror.data_ptr(), x.data_ptr(),
+            flat.data_ptr(), 1 if flat.dtype == torch.bfloat16 else 0, flat.stride(0), mirror.data_ptr(),
+            1 if mirror.dtype == torch.bfloat16 else 0, x.data_ptr(),
             out.data_ptr(), P, E, ctypes.addressof(c_sizes), ctypes.addressof(c_acts), n_layers, int(bool(bias)),
             stream_of(flat)), "mlp_forward_mirrored")
         return out

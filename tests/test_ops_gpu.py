@@ -628,7 +628,14 @@ def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, d
     got = net.batched_apply(pop, obs)
     monkeypatch.setenv("EVOX_AMD_MLP_MIRROR", "0")
     ref = net.batched_apply(pop, obs)
-    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
     h = pop_n // 2
     assert torch.allclose(got[:h], ref[:h], rtol=1e-5, atol=1e-5)               # + members: the same arithmetic
-    assert torch.allclose(got[h:], ref[h:], rtol=tol, atol=tol), (got[h:] - ref[h:]).abs().max()
+    if dtype == torch.float32:
+        assert torch.allclose(got[h:], ref[h:], rtol=1e-4, atol=1e-4), (got[h:] - ref[h:]).abs().max()
+    else:
+        # bf16 storage: both forms approximate the fp32 population; the rebuilt − members (from a bf16
+        # centre) must be about as close to it as the stored bf16 rows are
+        exact = net.batched_apply(es.perturb(rnd.PRNGKey(2).to(cuda), center, 0.05, pop_n, mirrored=True), obs)
+        err_rows = float((ref[h:] - exact[h:]).abs().max())
+        err_pair = float((got[h:] - exact[h:]).abs().max())
+        assert err_pair <= 2.5 * err_rows + 5e-3, (err_pair, err_rows)
