@@ -60,7 +60,17 @@ __global__ __launch_bounds__(kThreads) void rank_sort_kernel(const float* __rest
     // and the 0xFFFFFFFF padding never counts.
     const int m0 = min(max(i0 - base, lo), hi), m1 = min(max(i0 + kRows - base, lo), hi);
     cnt += count_below(sk, lo, m0, ki + 1u);
-    for (int j = m0; j < m1; ++j) cnt += (int)(sk[j] < ki + (uint32_t)(base + j < i));
+    {
+      // at most 16 groups: unrolled so that the LDS reads go out together
+      const uint4* p4 = reinterpret_cast<const uint4*>(sk);
+#pragma unroll 16
+      for (int g = m0 >> 2; g < (m1 >> 2); ++g) {
+        const uint4 k = p4[g];
+        const int gj = base + 4 * g;
+        cnt += (int)(k.x < ki + (uint32_t)(gj + 0 < i)) + (int)(k.y < ki + (uint32_t)(gj + 1 < i)) +
+               (int)(k.z < ki + (uint32_t)(gj + 2 < i)) + (int)(k.w < ki + (uint32_t)(gj + 3 < i));
+      }
+    }
     cnt += count_below(sk, m1, hi, ki);
     __syncthreads();
   }
