@@ -11,7 +11,10 @@ pop = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
 dim = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda")
 lb, ub = torch.full((dim,), -100.0, device=dev), torch.full((dim,), 100.0, device=dev)
-algo = getattr(algorithms, name)(lb, ub, pop_size=pop)
+try:
+    algo = getattr(algorithms, name)(lb, ub, pop_size=pop)
+except TypeError:
+    algo = getattr(algorithms, name)(lb, ub, pop)
 prob = problems.numerical.CEC2022TestSuit.create(1) if dim in (2, 10, 20) else problems.numerical.Rastrigin()
 wf = workflows.StdWorkflow(algo, prob)
 state = wf.init(ex.PRNGKey(0).to(dev))
@@ -32,5 +35,5 @@ for _ in range(200):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
 print(s.getvalue()[:9000])

@@ -1,6 +1,6 @@
 """Which algorithms' steady-state step can be replayed from a HIP graph, and what it buys.
 
-    python tools/graph_survey.py [--dim 100] [--pop 1024] [--steps 30]
+    python tools/graph_survey.py [--dim 100] [--pop 1024] [--steps 100] [--warmup 20]
 
 For every algorithm: eager ms/step, graphed ms/step, and whether the graphed run reproduces the
 eager one exactly.  A step that synchronises with the host or keeps a changing Python value in
@@ -40,7 +40,7 @@ def run(name, args, dev, graph):
     algo = make(name, args.dim, args.pop, dev)
     wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), graph_step=graph)
     state = wf.init(ex.PRNGKey(5).to(dev))
-    for _ in range(4):
+    for _ in range(args.warmup):
         state = wf.step(state)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -54,7 +54,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--pop", type=int, default=1024)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -66,7 +67,7 @@ if __name__ == "__main__":
         import subprocess
         for name in names:
             subprocess.run([sys.executable, os.path.abspath(__file__), "--only", name, "--dim", str(args.dim), "--pop",
-                            str(args.pop), "--steps", str(args.steps)], timeout=120)
+                            str(args.pop), "--steps", str(args.steps), "--warmup", str(args.warmup)], timeout=120)
         sys.exit(0)
     for name in names:
         row = {"algorithm": name}
