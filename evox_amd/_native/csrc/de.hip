@@ -20,6 +20,7 @@ namespace {
 
 constexpr int kMaxPicks = 9;
 enum Base { kRand = 0, kBest = 1, kPbest = 2, kCurrent = 3 };
+enum Cross { kBin = 0, kExp = 1, kArith = 2 };            // kExp is not handled here (callers keep it on the tensor path)
 
 __device__ __forceinline__ uint32_t bits_at(uint32_t k0, uint32_t k1, uint64_t e) {
   const u32x4 b = philox_block(k0, k1, e >> 2, kStreamDraw);
@@ -30,14 +31,17 @@ template <int LPR>
 __global__ __launch_bounds__(256) void de_trial_kernel(
     const float* __restrict__ pop, int64_t ldpop, int n_pop, int dim, const int64_t* __restrict__ rows, int b,
     const int64_t* __restrict__ best_index, const int64_t* __restrict__ pbest_rows, const float* __restrict__ F, int f_is_vec,
-    const float* __restrict__ CR, int cr_is_vec, int prim, int sec, int num_diff, int n_picks,
-    const int32_t* __restrict__ key_sel, const int32_t* __restrict__ key_jrand, const int32_t* __restrict__ key_mask,
+    const float* __restrict__ CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
+    const int32_t* __restrict__ row_codes, int n_picks, const int32_t* __restrict__ key_sel, const int32_t* __restrict__ key_jrand, const int32_t* __restrict__ key_mask,
     const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out) {
   constexpr int RPB = 256 / LPR;                       // rows per block
   const int sub = threadIdx.x % LPR;
   const int r = blockIdx.x * RPB + threadIdx.x / LPR;
   if (r >= b) return;
   const int64_t self = rows ? rows[r] : r;
+  if (row_codes) {                                     // per-row strategy: (primary, secondary, #differences, crossover)
+    prim = row_codes[4 * r]; sec = row_codes[4 * r + 1]; num_diff = row_codes[4 * r + 2]; cross = row_codes[4 * r + 3];
+  }
 
   // ---- distinct picks (ascending list `taken` starts with the row itself) -------------------
   const uint32_t s0 = (uint32_t)key_sel[0], s1 = (uint32_t)key_sel[1];
@@ -83,8 +87,13 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
     float diff = d1a[c] - d1b[c];
     if (num_diff > 1) diff = diff + (d2a[c] - d2b[c]);
     const float mutant = p + f * (s_row[c] - p) + f * diff;
-    const float u = bits_to_unit(bits_at(m0, m1, (uint64_t)r * dim + c));
-    const float x = (u < cr || c == jrand) ? mutant : cur[c];
+    float x;
+    if (cross == kArith) {
+      x = cur[c] + cr * (mutant - cur[c]);               // arithmetic recombination, CR plays K
+    } else {
+      const float u = bits_to_unit(bits_at(m0, m1, (uint64_t)r * dim + c));
+      x = (u < cr || c == jrand) ? mutant : cur[c];
+    }
     out[(int64_t)r * dim + c] = fminf(fmaxf(x, lb[c]), ub[c]);
   }
 }
@@ -93,17 +102,20 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
 
 EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int dim, const int64_t* rows, int b,
                                const int64_t* best_index, const int64_t* pbest_rows, const float* F, int f_is_vec,
-                               const float* CR, int cr_is_vec, int prim, int sec, int num_diff, int n_picks,
-                               const int32_t* key_sel, const int32_t* key_jrand, const int32_t* key_mask, const float* lb,
+                               const float* CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
+                               const int32_t* row_codes, int n_picks, const int32_t* key_sel, const int32_t* key_jrand, const int32_t* key_mask, const float* lb,
                                const float* ub, float* out, void* stream) {
   if (b <= 0 || dim <= 0) return 0;
+  if (row_codes) num_diff = 2;                          // per-row values are 1 or 2 (checked by the caller)
   if (n_picks > kMaxPicks || n_picks < 2 * num_diff + 1 || num_diff < 1 || num_diff > 2 || n_pop <= n_picks)
     return (int)hipErrorInvalidValue;
-  if ((prim == kPbest || sec == kPbest) && pbest_rows == nullptr) return (int)hipErrorInvalidValue;
+  if (!row_codes && cross != kBin && cross != kArith) return (int)hipErrorInvalidValue;
+  if ((row_codes || prim == kPbest || sec == kPbest) && pbest_rows == nullptr) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
 #define EVOX_DE_LAUNCH(LPR)                                                                                            \
   de_trial_kernel<LPR><<<(b + 256 / LPR - 1) / (256 / LPR), 256, 0, s>>>(                                              \
-      pop, ldpop, n_pop, dim, rows, b, best_index, pbest_rows, F, f_is_vec, CR, cr_is_vec, prim, sec, num_diff, n_picks, \
+      pop, ldpop, n_pop, dim, rows, b, best_index, pbest_rows, F, f_is_vec, CR, cr_is_vec, prim, sec, num_diff, cross,   \
+      row_codes, n_picks,                                                                                              \
       key_sel, key_jrand, key_mask, lb, ub, out)
   if (dim <= 8) EVOX_DE_LAUNCH(8);
   else if (dim <= 16) EVOX_DE_LAUNCH(16);

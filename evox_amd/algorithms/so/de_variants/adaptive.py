@@ -159,8 +159,9 @@ class SaDE(DEBase):
         self._init_common(lb, ub, pop_size)
         self.diff_padding_num = diff_padding_num
         self.LP = LP
-        self.strategy_pool = torch.tensor([_RAND_1_BIN, _RAND2BEST_2_BIN, _RAND_2_BIN, _CURRENT2RAND_1],
-                                          device=self.lb.device)
+        pool = [_RAND_1_BIN, _RAND2BEST_2_BIN, _RAND_2_BIN, _CURRENT2RAND_1]
+        self.strategy_pool = torch.tensor(pool, device=self.lb.device)
+        self._code_sets = {"num_diff": {p[2] for p in pool}, "cross": {p[3] for p in pool}}
 
     def setup(self, key):
         dev = self.lb.device
@@ -191,7 +192,7 @@ class SaDE(DEBase):
         code = self.strategy_pool[sid]
         idx = self._window(state)
         trial = self._strategy_trials(k_var, state, idx, code[:, 0], code[:, 1], code[:, 2], code[:, 3], F, CR,
-                                      self.diff_padding_num)
+                                      self.diff_padding_num, code_sets=self._code_sets)
         return trial, state.replace(trial_vectors=trial, key=key, CRs=CR, strategy_ids=sid, iter=state.iter + 1)
 
     def tell(self, state, trial_fitness):

@@ -75,7 +75,8 @@ class DEBase(Algorithm):
         return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start)
 
     # -- batched strategy evaluation -----------------------------------------------------
-    def _strategy_trials(self, key, state, idx, prim, sec, num_diff, cross, F, CR, diff_padding_num, replace=False):
+    def _strategy_trials(self, key, state, idx, prim, sec, num_diff, cross, F, CR, diff_padding_num, replace=False,
+                         code_sets=None):
         """Trial vectors for window ``idx``.  ``prim``/``sec`` (base-vector codes), ``num_diff``
         and ``cross`` may be ints or per-row tensors; ``F``/``CR`` scalars or per-row tensors::
 
@@ -95,15 +96,15 @@ class DEBase(Algorithm):
         static_nd = isinstance(num_diff, int)
         n_picks = min(diff_padding_num, 2 * num_diff + 1) if static_nd else diff_padding_num
         from ....ops import de as _de
-        if _de.supported(pop, prim, sec, num_diff, cross, n_picks, replace):
+        if _de.supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets):
             # GPU: one fused launch (same random elements as the formulation below)
             pbest_rows = None
-            if PBEST in (prim, sec):
+            if not static_nd or PBEST in (prim, sec):
                 top = max(int(self.pop_size * 0.05), 1)
                 best = torch.topk(fit, top, largest=False).indices
                 pbest_rows = best[rnd.randint(k_pb, (b,), 0, top)]
             return _de.de_trial(key, pop, idx, state.best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks,
-                                self.lb, self.ub)
+                                self.lb, self.ub, cross)
         if replace:
             picks = rnd.randint(k_sel, (b, n_picks), 0, self.pop_size)
             picks = torch.where(picks == idx[:, None], torch.full_like(picks, self.pop_size - 1), picks)

@@ -11,7 +11,7 @@ from ._util import check, hip, stream_of
 
 P, I, I64 = _native.P, _native.I, _native.I64
 _native.register_hip_api({
-    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, P, P, P, P, P, P]),
+    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P]),
 })
 
 
@@ -22,18 +22,37 @@ def _vec(x, b, dev):
     return torch.full((1,), float(x), dtype=torch.float32, device=dev), 0
 
 
-def supported(pop, prim, sec, num_diff, cross, n_picks, replace) -> bool:
-    return (pop.is_cuda and pop.dtype == torch.float32 and isinstance(prim, int) and isinstance(sec, int)
-            and isinstance(num_diff, int) and isinstance(cross, int) and cross == 0 and not replace
-            and 1 <= num_diff <= 2 and 2 * num_diff + 1 <= n_picks <= 9 and pop.shape[0] > n_picks)
+BIN, EXP, ARITH = 0, 1, 2
 
 
-def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub):
+def supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets=None) -> bool:
+    """Static strategies (ints) with binomial crossover or arithmetic recombination, or per-row
+    strategy tensors whose possible values the caller declares in ``code_sets`` (``{"cross": {...},
+    "num_diff": {...}}``): exponential crossover stays on the tensor path."""
+    if not (pop.is_cuda and pop.dtype == torch.float32 and not replace and n_picks <= 9 and pop.shape[0] > n_picks):
+        return False
+    static = all(isinstance(v, int) for v in (prim, sec, num_diff, cross))
+    if static:
+        return cross in (BIN, ARITH) and 1 <= num_diff <= 2 and 2 * num_diff + 1 <= n_picks
+    if code_sets is None or any(isinstance(v, int) for v in (prim, sec, num_diff, cross)):
+        return False
+    return (set(code_sets.get("cross", (EXP,))) <= {BIN, ARITH} and set(code_sets.get("num_diff", (3,))) <= {1, 2}
+            and n_picks >= 5)
+
+
+def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub, cross=BIN):
     """Trial vectors for the rows ``idx`` of ``pop``; ``key`` is split exactly as the PyTorch path does
-    (selection / pbest / crossover → jrand, mask)."""
+    (selection / pbest / crossover → jrand, mask).  ``prim, sec, num_diff, cross`` are ints, or all four
+    per-row integer tensors."""
     dev = pop.device
     b, dim = idx.shape[0], pop.shape[1]
     k_sel, _k_pb, k_x = rnd.split(key, 3)
+    per_row = isinstance(prim, torch.Tensor)
+    if per_row:
+        # the tensor formulation gives the binomial crossover the first half of a further split
+        k_x = rnd.split(k_x)[0]
+        codes = torch.stack([prim, sec, num_diff, cross], dim=1).to(device=dev, dtype=torch.int32).contiguous()
+        prim = sec = num_diff = cross = 0
     k_r, k_m = rnd.split(k_x)
     if pop.stride(1) != 1:
         pop = pop.contiguous()
@@ -43,7 +62,8 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
     check(hip().evox_hip_de_trial(
         pop.data_ptr(), pop.stride(0), pop.shape[0], dim, idx.contiguous().data_ptr(), b,
         best_index.reshape(1).contiguous().data_ptr(), pbest_rows.contiguous().data_ptr() if pbest_rows is not None else None,
-        f.data_ptr(), f_vec, cr.data_ptr(), cr_vec, int(prim), int(sec), int(num_diff), int(n_picks),
+        f.data_ptr(), f_vec, cr.data_ptr(), cr_vec, int(prim), int(sec), int(num_diff), int(cross),
+        codes.data_ptr() if per_row else None, int(n_picks),
         k_sel.contiguous().data_ptr(), k_r.contiguous().data_ptr(), k_m.contiguous().data_ptr(),
         lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), out.data_ptr(), stream_of(pop)), "de_trial")
     return out

@@ -336,7 +336,7 @@ def test_cmaes_graph_step_matches_eager(cuda):
 
 
 @pytest.mark.parametrize("algo_name,dim,pop", [("SHADE", 20, 5000), ("JaDE", 7, 300), ("DE_rand", 33, 1000),
-                                               ("DE_best2", 100, 500)])
+                                               ("DE_best2", 100, 500), ("CoDE", 30, 400), ("SaDE", 25, 600)])
 def test_de_trial_kernel_matches_batched_formulation(cuda, algo_name, dim, pop, monkeypatch):
     import evox_amd as ex
     from evox_amd import algorithms
@@ -344,7 +344,9 @@ def test_de_trial_kernel_matches_batched_formulation(cuda, algo_name, dim, pop, 
     lb, ub = torch.full((dim,), -5.0, device=cuda), torch.full((dim,), 5.0, device=cuda)
     make = {"SHADE": lambda: algorithms.SHADE(lb, ub, pop), "JaDE": lambda: algorithms.JaDE(lb, ub, pop),
             "DE_rand": lambda: algorithms.DE(lb, ub, pop, base_vector="rand", num_difference_vectors=1),
-            "DE_best2": lambda: algorithms.DE(lb, ub, pop, base_vector="best", num_difference_vectors=2)}[algo_name]
+            "DE_best2": lambda: algorithms.DE(lb, ub, pop, base_vector="best", num_difference_vectors=2),
+            # static arithmetic recombination (third CoDE strategy) and per-row strategy codes (SaDE)
+            "CoDE": lambda: algorithms.CoDE(lb, ub, pop), "SaDE": lambda: algorithms.SaDE(lb, ub, pop)}[algo_name]
     algo = make()
     state = algo.init(ex.PRNGKey(4))
     state = state.replace(fitness=torch.rand(pop, device=cuda))
