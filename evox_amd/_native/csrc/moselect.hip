@@ -87,13 +87,63 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(float* __restrict__ 
   }
 }
 
-// The bubble sort is a chain of dependent compare-swaps: one lane walks it with the permutation
-// in LDS (n <= 16384) while the rest of the workgroup idles.
+// Stochastic bubble sort.  Inside one sweep every compare-swap depends on the previous one, but sweep
+// s+1 may work on position j as soon as sweep s has left position j+1: the 64 lanes of one wave run 64
+// consecutive sweeps as a systolic pipeline, lane l trailing lane l−1 by two positions (lane l at time
+// t handles position t − 2l).  Each lane carries the element it is bubbling; in one time step the lanes
+// touch distinct entries of the permutation (LDS), and the LDS operations of a wave complete in order,
+// so the result is exactly that of the sequential sort in n/128 passes of n + 126 steps instead of
+// n/2 passes of n steps by a single lane.
 __global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
                                                                 const float* __restrict__ u, float pc, int n,
-                                                                int64_t* __restrict__ rank, int* __restrict__ scratch) {
-  extern __shared__ __attribute__((aligned(16))) int s_rank[];
-  int* rk = scratch != nullptr ? scratch : s_rank;
+                                                                int64_t* __restrict__ rank, int keys_in_lds) {
+  extern __shared__ __attribute__((aligned(16))) int s_mem[];
+  volatile int* rk = s_mem;                              // the permutation, n entries
+  float* l1 = reinterpret_cast<float*>(s_mem + n);       // optional copies of I1, I2, u
+  float* l2 = l1 + n;
+  float* lu = l2 + n;
+  const int lane = threadIdx.x;
+  for (int i = lane; i < n; i += 64) {
+    rk[i] = i;
+    if (keys_in_lds) { l1[i] = I1[i]; l2[i] = I2[i]; lu[i] = u[i]; }
+  }
+  __syncthreads();
+  const float* K1 = keys_in_lds ? l1 : I1;
+  const float* K2 = keys_in_lds ? l2 : I2;
+  const float* U = keys_in_lds ? lu : u;
+  const int sweeps = (n + 1) / 2;
+  const int steps = (n - 1) + 2 * 63;
+  for (int s0 = 0; s0 < sweeps; s0 += 64) {
+    const bool mine = s0 + lane < sweeps;
+    int a = 0;
+    float a1 = 0.f, a2 = 0.f;
+    for (int t = 0; t < steps; ++t) {
+      const int j = t - 2 * lane;
+      if (mine && j >= 0 && j < n - 1) {
+        if (j == 0) { a = rk[0]; a1 = K1[a]; a2 = K2[a]; }
+        const int b = rk[j + 1];
+        const float b1 = K1[b], b2 = K2[b];
+        const bool first = U[j] < pc;
+        if ((first ? a1 : a2) < (first ? b1 : b2)) {
+          rk[j] = b;                                       // b moves left, a keeps bubbling right
+        } else {
+          rk[j] = a;
+          a = b; a1 = b1; a2 = b2;
+        }
+        if (j == n - 2) rk[n - 1] = a;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) rank[i] = rk[i];
+}
+
+// sequential form for permutations that do not fit the LDS (n > 40 000)
+__global__ __launch_bounds__(64) void stochastic_ranking_serial_kernel(const float* __restrict__ I1,
+                                                                       const float* __restrict__ I2,
+                                                                       const float* __restrict__ u, float pc, int n,
+                                                                       int64_t* __restrict__ rank, int* __restrict__ rk) {
   for (int i = threadIdx.x; i < n; i += 64) rk[i] = i;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -104,7 +154,7 @@ __global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __r
       for (int j = 0; j + 1 < n; ++j) {
         const int b = rk[j + 1];
         const float* key = u[j] < pc ? I1 : I2;
-        if (key[a] < key[b]) { rk[j] = b; swapped = true; /* a keeps moving right */ }
+        if (key[a] < key[b]) { rk[j] = b; swapped = true; }
         else { rk[j] = a; a = b; }
       }
       rk[n - 1] = a;
@@ -130,7 +180,21 @@ EVOX_API int evox_hip_spea2_truncate(float* dis, int n, int n_remove, uint8_t* k
 
 EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
                                          int64_t* rank, int* scratch, void* stream) {
-  const size_t lds = scratch != nullptr ? 0 : (size_t)n * sizeof(int);
-  stochastic_ranking_kernel<<<1, 64, lds, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);
+  if (n <= 0) return 0;
+  const size_t perm = (size_t)n * sizeof(int);
+  if (perm <= 160 * 1024) {
+    const size_t with_keys = perm * 4;
+    const int keys_in_lds = with_keys <= 160 * 1024;
+    const size_t lds = keys_in_lds ? with_keys : perm;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    stochastic_ranking_kernel<<<1, 64, lds, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, keys_in_lds);
+    return last_launch_status();
+  }
+  if (scratch == nullptr) return (int)hipErrorInvalidValue;
+  stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);
   return last_launch_status();
 }

@@ -116,7 +116,7 @@ def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
     rank = torch.empty(n, dtype=torch.int64, device=I1.device)
     pc = float(pc)
     if on_gpu(I1):
-        scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 8192 else None
+        scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
         check(hip().evox_hip_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr(),
                                                 scratch.data_ptr() if scratch is not None else None, stream_of(I1)),
               "stochastic_ranking")

@@ -641,3 +641,19 @@ def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, d
         err_rows = float((ref[h:] - exact[h:]).abs().max())
         err_pair = float((got[h:] - exact[h:]).abs().max())
         assert err_pair <= 2.5 * err_rows + 5e-3, (err_pair, err_rows)
+
+
+@pytest.mark.parametrize("n", [2, 3, 64, 129, 700, 5000])
+def test_pipelined_stochastic_ranking_equals_sequential_sort(cuda, n):
+    """The wave-pipelined bubble sort (64 sweeps in flight) against the sequential host twin, with
+    ties and for sizes around the pipeline depth; n = 5000 keeps the keys out of the LDS copy."""
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n)
+    I1 = (torch.rand(n, generator=g) * 20).round() / 20
+    I2 = torch.rand(n, generator=g)
+    u = torch.rand(n, generator=g)
+    got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), u.to(cuda), 0.45)
+    ref = moselect.stochastic_ranking(I1, I2, u, 0.45)                   # native host implementation
+    assert torch.equal(got.cpu(), ref)
+    assert sorted(got.tolist()) == list(range(n))

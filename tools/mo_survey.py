@@ -1,0 +1,32 @@
+"""Generation time of every multi-objective algorithm on DTLZ2 (m=3) on the GPU.
+usage: mo_survey.py [pop] ; one JSON line per algorithm."""
+import json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import evox_amd as ex
+from evox_amd import algorithms, problems, workflows
+
+pop = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+names = ["NSGA2", "NSGA3", "RVEA", "RVEAa", "MOEAD", "MOEADDRA", "MOEADM2M", "EAGMOEAD", "IBEA", "BCEIBEA", "SPEA2", "HypE",
+         "KnEA", "BiGE", "GDE3", "SRA", "TDEA", "LMOCSO", "IMMOEA"]
+dev = torch.device("cuda")
+prob = problems.numerical.DTLZ2(m=3)
+lb, ub = torch.zeros(prob.d, device=dev), torch.ones(prob.d, device=dev)
+for name in names:
+    row = {"algorithm": name, "pop": pop}
+    try:
+        algo = algorithms.LMOCSO(3, lb, ub, pop) if name == "LMOCSO" else getattr(algorithms, name)(lb, ub, 3, pop)
+        wf = workflows.StdWorkflow(algo, prob)
+        state = wf.init(ex.PRNGKey(0).to(dev))
+        for _ in range(5):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 20
+        for _ in range(steps):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        row["ms_per_generation"] = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as e:                                            # noqa: BLE001
+        row["error"] = f"{type(e).__name__}: {e}"[:160]
+    print(json.dumps(row), flush=True)
