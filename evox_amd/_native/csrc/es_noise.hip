@@ -187,6 +187,25 @@ EVOX_API int evox_hip_es_perturb(const int32_t* key, const float* center, const 
   return last_launch_status();
 }
 
+// [center + scale·z; center − scale·z] for the noise rows [noise_start, noise_start + count): a rank's
+// share of a mirrored population with both members of every pair on the same rank.  out: 2·count rows.
+EVOX_API int evox_hip_es_perturb_pairs(const int32_t* key, const float* center, const float* scale, int scale_is_vec,
+                                       void* out, int out_dtype, int64_t pitch, int64_t noise_start, int64_t count,
+                                       int64_t dim, void* stream) {
+  if (count <= 0 || dim <= 0) return 0;
+  if (pitch < dim || noise_start < 0) return (int)hipErrorInvalidValue;
+  const int64_t blocks4 = (count * dim + 3) / 4 + 1;
+  const int grid1 = (int)((blocks4 + 255) / 256 < 16384 ? (blocks4 + 255) / 256 : 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dtype == 1)
+    es_perturb_flat_kernel<uint16_t, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch,
+                                                                 noise_start, count, dim);
+  else
+    es_perturb_flat_kernel<float, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch,
+                                                              noise_start, count, dim);
+  return last_launch_status();
+}
+
 EVOX_API int evox_hip_noise_wsum(const int32_t* key, const float* w, const float* v, float* gslab, float* hslab,
                                  void* reserved, int64_t n, int64_t dim, int64_t row_offset, int64_t splits, int flags,
                                  void* stream) {

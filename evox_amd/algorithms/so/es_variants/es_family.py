@@ -59,6 +59,19 @@ def _mirrored_local_sum(noise_key, w_full, dim, pop_size, mirrored, rank, world,
     return g if v_full is None else (g, h)
 
 
+def _pair_local(pop_size: int, world: int, mirrored: bool) -> int:
+    """Pairs per rank when a mirrored population can be dealt out pair-wise (both members of a pair
+    on one rank, so the policy kernel reads one row per pair), else 0."""
+    return pop_size // 2 // world if mirrored and world > 0 and pop_size % (2 * world) == 0 else 0
+
+
+def _logical_fitness(fitness, world: int, c: int):
+    """Fitness gathered from the pair-local layout (rank r: [+ of its c pairs; − of them]) reordered to
+    the logical layout [+ of every pair; − of every pair]."""
+    fr = fitness.reshape(world, 2, c)
+    return torch.cat([fr[:, 0].reshape(-1), fr[:, 1].reshape(-1)])
+
+
 class _ESBase(Algorithm):
     def _center(self, center_init):
         super().__init__()
@@ -117,14 +130,24 @@ class OpenES(_ESBase):
     def ask_sharded(self, state, rank: int, world: int):
         local = self.pop_size // world
         key, noise_key = rnd.split(state.key)
-        population = _es.perturb(noise_key, state.center, self.noise_stdev, local, self.mirrored_sampling,
-                                 row_offset=rank * local, total_rows=self.pop_size)
+        c = _pair_local(self.pop_size, world, self.mirrored_sampling)
+        if c:
+            # pair-local deal: this rank's c noise rows and their mirrors
+            population = _es.perturb_pairs(noise_key, state.center, self.noise_stdev, rank * c, c)
+        else:
+            population = _es.perturb(noise_key, state.center, self.noise_stdev, local, self.mirrored_sampling,
+                                     row_offset=rank * local, total_rows=self.pop_size)
         return population, state.replace(key=key, noise_key=noise_key)
 
     def tell_sharded(self, state, fitness, rank: int, world: int):
         from ....core import distributed as dist
 
-        g = _mirrored_local_sum(state.noise_key, fitness, self.dim, self.pop_size, self.mirrored_sampling, rank, world)
+        c = _pair_local(self.pop_size, world, self.mirrored_sampling)
+        if c:
+            mine = fitness[rank * 2 * c:(rank + 1) * 2 * c]
+            g, _ = _es.weighted_noise_sum(state.noise_key, mine[:c] - mine[c:], self.dim, row_offset=rank * c)
+        else:
+            g = _mirrored_local_sum(state.noise_key, fitness, self.dim, self.pop_size, self.mirrored_sampling, rank, world)
         grad = dist.all_reduce(g) / self.pop_size / self.noise_stdev
         return self._apply(state, grad)
 
@@ -175,21 +198,33 @@ class PGPE(_ESBase):
     def ask_sharded(self, state, rank: int, world: int):
         local = self.pop_size // world
         key, noise_key = rnd.split(state.key)
-        population = _es.perturb(noise_key, state.center, state.stdev, local, True, row_offset=rank * local,
-                                 total_rows=self.pop_size)
+        c = _pair_local(self.pop_size, world, True)
+        if c:
+            population = _es.perturb_pairs(noise_key, state.center, state.stdev, rank * c, c)
+        else:
+            population = _es.perturb(noise_key, state.center, state.stdev, local, True, row_offset=rank * local,
+                                     total_rows=self.pop_size)
         return population, state.replace(key=key, noise_key=noise_key)
 
     def tell_sharded(self, state, fitness, rank: int, world: int):
         from ....core import distributed as dist
 
         h = self.pop_size // 2
+        c = _pair_local(self.pop_size, world, True)
+        if c:
+            fitness = _logical_fitness(fitness, world, c)
         f_pos, f_neg = fitness[:h], fitness[h:]
         # per-row weights of the logical population: +w_i on row i, −w_i on its mirror (for the
         # mean); v_i on both (z² is even)
         w = (f_pos - f_neg) / 4
         v = ((f_pos + f_neg) / 2 - fitness.mean()) / 2
-        g, s = _mirrored_local_sum(state.noise_key, torch.cat([w, -w]), self.dim, self.pop_size, True, rank, world,
-                                   v_full=torch.cat([v, v]))
+        if c:
+            # both members of a pair are local: their weights fold into one pass over the c noise rows
+            lo = rank * c
+            g, s = _es.weighted_noise_sum(state.noise_key, 2 * w[lo:lo + c], self.dim, v=2 * v[lo:lo + c], row_offset=lo)
+        else:
+            g, s = _mirrored_local_sum(state.noise_key, torch.cat([w, -w]), self.dim, self.pop_size, True, rank, world,
+                                       v_full=torch.cat([v, v]))
         packed = dist.all_reduce(torch.cat([g, s]))
         g, s = packed[: self.dim], packed[self.dim:]
         return self._apply(state, state.stdev * g / h, state.stdev * s / h)

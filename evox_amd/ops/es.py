@@ -28,6 +28,11 @@ _native.register_hip_api({
                                         _native.I64, _native.I64, _native.I64, _native.I64, _native.P]),
 })
 
+_native.register_hip_api({
+    "evox_hip_es_perturb_pairs": (_native.I, [_native.P, _native.P, _native.P, _native.I, _native.P, _native.I, _native.I64,
+                                              _native.I64, _native.I64, _native.I64, _native.P]),
+})
+
 _CHUNK_ELEMS = 1 << 24
 
 
@@ -86,6 +91,32 @@ def perturb(key, center, scale, n_rows: int, mirrored: bool = False, row_offset:
         b = max(lo, half)
         parts.append(center - scale * noise_rows(key, hi - b, dim, b - half))
     return torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
+
+
+def perturb_pairs(key, center, scale, noise_start: int, count: int, out_dtype=None):
+    """``[center + scale·z; center − scale·z]`` for the noise rows ``noise_start … noise_start+count−1``:
+    a share of a mirrored population that keeps both members of every pair together (the returned
+    tensor carries the mirrored-population mark, so pair-aware consumers read its first half only)."""
+    dim = center.shape[0]
+    if on_gpu(center) and center.dtype == torch.float32:
+        dev = center.device
+        dt = torch.float32 if out_dtype is None else out_dtype
+        pitch = (dim + 3) // 4 * 4
+        buf = torch.empty((2 * count, pitch), dtype=dt, device=dev)
+        if isinstance(scale, torch.Tensor):
+            sc = scale.to(device=dev, dtype=torch.float32).contiguous().reshape(-1)
+        else:
+            sc = torch.full((1,), float(scale), dtype=torch.float32, device=dev)
+        check(hip().evox_hip_es_perturb_pairs(key.contiguous().data_ptr(), center.contiguous().data_ptr(), sc.data_ptr(),
+                                              int(sc.numel() == dim and dim > 1), buf.data_ptr(),
+                                              1 if dt == torch.bfloat16 else 0, pitch, int(noise_start), int(count), dim,
+                                              stream_of(center)), "es_perturb_pairs")
+        out = buf if pitch == dim else buf[:, :dim]
+        out._evox_mirror = (center, count)
+        return out
+    z = noise_rows(key, count, dim, noise_start)
+    out = torch.cat([center + scale * z, center - scale * z], dim=0)
+    return out if out_dtype in (None, torch.float32) else out.to(out_dtype)
 
 
 def weighted_noise_sum_reference(key, w, dim: int, v=None, row_offset: int = 0):
