@@ -39,6 +39,11 @@ HIP_FLAGS = [
     "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
 ]
 CPU_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-march=x86-64-v3"]
+# EVOX_AMD_SANITIZE=address,undefined builds the HOST library with those sanitizers (run the CPU tests
+# with LD_PRELOAD=$(g++ -print-file-name=libasan.so)); device code is never instrumented.
+_SAN = os.environ.get("EVOX_AMD_SANITIZE", "").strip()
+if _SAN:
+    CPU_FLAGS = [f for f in CPU_FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", f"-fsanitize={_SAN}"]
 
 
 def _newer(target: Path, sources) -> bool:
