@@ -202,23 +202,20 @@ class SaDE(DEBase):
         fail = (onehot * (~ok)[:, None]).sum(0)
         success_memory = torch.cat([succ[None], state.success_memory[:-1]], dim=0)
         failure_memory = torch.cat([fail[None], state.failure_memory[:-1]], dim=0)
-        # per strategy, push the successful CR values of this generation (most recent first)
-        # onto its column of the LP-deep memory
-        cols = []
-        for k in range(4):
-            sel = ok & (state.strategy_ids == k)
-            # stable compaction of the successful values, newest (highest index) first
-            order = torch.argsort(sel.to(torch.int64) * (torch.arange(sel.shape[0], device=sel.device) + 1),
-                                  descending=True)
-            vals = torch.where(sel[order], state.CRs[order], torch.full_like(state.CRs, float("nan")))[: self.LP]
-            cnt = sel.sum().clamp(max=self.LP)
-            old = state.CR_memory[:, k]
-            pos = torch.arange(self.LP, device=sel.device)
-            shifted = old[(pos - cnt).clamp_min(0)]
-            pad = torch.full((self.LP,), float("nan"), device=sel.device)
-            pad[: vals.shape[0]] = vals
-            cols.append(torch.where(pos < cnt, pad, shifted))
-        CR_memory = torch.stack(cols, dim=1)
+        # per strategy, push the successful CR values of this generation (most recent first) onto its
+        # column of the LP-deep memory — all four columns at once
+        B, LP, dev = state.CRs.shape[0], self.LP, state.CRs.device
+        sel = ok[:, None] & onehot.bool()                                         # (B, 4)
+        newest_first = torch.argsort(sel.to(torch.int64) * (torch.arange(B, device=dev)[:, None] + 1), dim=0,
+                                     descending=True, stable=True)                # successful rows, highest index first
+        vals = torch.where(torch.gather(sel, 0, newest_first), state.CRs[newest_first],
+                           torch.full((), float("nan"), device=dev))[:LP]          # (min(B, LP), 4)
+        if vals.shape[0] < LP:
+            vals = torch.cat([vals, torch.full((LP - vals.shape[0], 4), float("nan"), device=dev)], dim=0)
+        cnt = sel.sum(0).clamp(max=LP)                                            # (4,)
+        pos = torch.arange(LP, device=dev)[:, None]
+        shifted = torch.gather(state.CR_memory, 0, (pos - cnt).clamp_min(0))
+        CR_memory = torch.where(pos < cnt, vals, shifted)
         return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
                              success_memory=success_memory, failure_memory=failure_memory, CR_memory=CR_memory)
 
