@@ -72,6 +72,9 @@ def matmul(a: torch.Tensor, b: torch.Tensor, **kw):
     return matmul_nt(a, b.T, **kw)
 
 
+_epilogue_ok = [True]
+
+
 def _sample_impl() -> str:
     """How the sampling GEMM runs on the GPU.
 
@@ -97,12 +100,18 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
         z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
         bd = B if D is None else B * D                            # (n, n): column j of B scaled by d_j
         sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
-        if impl != "mfma" and _blas.available():
+        if impl != "mfma" and _blas.available() and _epilogue_ok[0]:
             # mean + σ·Z·(B∘d)ᵀ from the GEMM alone: σ is read on the device, the mean is the
             # epilogue's bias vector
-            if precision == "bf16":
-                return _blas.gemm(z.bfloat16(), bd.bfloat16(), trans_b=True, alpha=sig, bias=mean)
-            return _blas.gemm(z, bd, trans_b=True, alpha=sig, bias=mean)
+            try:
+                if precision == "bf16":
+                    return _blas.gemm(z.bfloat16(), bd.bfloat16(), trans_b=True, alpha=sig, bias=mean)
+                return _blas.gemm(z, bd, trans_b=True, alpha=sig, bias=mean)
+            except RuntimeError as e:
+                # a hipBLASLt build without this epilogue / scale mode: say so once, use the plain product
+                import warnings
+                warnings.warn(f"library GEMM with fused scale and bias is unavailable ({e}); using GEMM + affine pass")
+                _epilogue_ok[0] = False
         if precision == "bf16":
             g = torch.mm(z.bfloat16(), bd.bfloat16().T, out_dtype=torch.float32)
         elif impl == "mfma":
