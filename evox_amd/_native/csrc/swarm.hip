@@ -106,3 +106,53 @@ EVOX_API int evox_hip_pso_step(const int32_t* key, const float* pop, const float
                                                             o_vel, o_pbest, o_gbest, n, d, w, phi_p, phi_g);
   return last_launch_status();
 }
+
+// Competitive swarm optimiser: one pass over the random pairs.  perm[0:half] meets perm[half:2·half];
+// the loser of each pair learns from the winner,
+//     v' = r1·v + r2·(x_w − x_l) + phi·r3·(mean − x_l),   x' = clip(x_l + v'),
+// with r1, r2, r3 the Philox uniforms of key at elements (k·half + pair)·dim + c (the layout of the tensor
+// formulation's (3, half, dim) draw).  new_pop / new_vel are copies of the inputs made by the caller;
+// only the losers' rows are rewritten.  Outputs: cand (half × dim, the losers' new positions) and
+// students (the losers' row numbers).
+namespace {
+__global__ __launch_bounds__(256) void cso_step_kernel(const int32_t* __restrict__ key, const float* __restrict__ pop,
+                                                       const float* __restrict__ vel, const float* __restrict__ fit,
+                                                       const int64_t* __restrict__ perm, const float* __restrict__ center,
+                                                       float phi, const float* __restrict__ lb, const float* __restrict__ ub,
+                                                       int half, int dim, float* __restrict__ new_pop,
+                                                       float* __restrict__ new_vel, float* __restrict__ cand,
+                                                       int64_t* __restrict__ students) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const int64_t total = (int64_t)half * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / dim), c = (int)(e - (int64_t)r * dim);
+    const int64_t a = perm[r], b = perm[half + r];
+    const bool first_wins = fit[a] < fit[b];
+    const int64_t w = first_wins ? a : b, l = first_wins ? b : a;
+    auto uni = [&](int k) {
+      const uint64_t idx = ((uint64_t)k * half + r) * dim + c;
+      const u32x4 blk = philox_block(k0, k1, idx >> 2, kStreamDraw);
+      return bits_to_unit(lane_of(blk, (int)(idx & 3)));
+    };
+    const float xl = pop[l * dim + c];
+    float v = uni(0) * vel[l * dim + c] + uni(1) * (pop[w * dim + c] - xl);
+    if (phi != 0.f) v += phi * uni(2) * (center[c] - xl);
+    const float x = fminf(fmaxf(xl + v, lb[c]), ub[c]);
+    new_pop[l * dim + c] = x;
+    new_vel[l * dim + c] = v;
+    cand[e] = x;
+    if (c == 0) students[r] = l;
+  }
+}
+}  // namespace
+
+EVOX_API int evox_hip_cso_step(const int32_t* key, const float* pop, const float* vel, const float* fit,
+                               const int64_t* perm, const float* center, float phi, const float* lb, const float* ub,
+                               int half, int dim, float* new_pop, float* new_vel, float* cand, int64_t* students,
+                               void* stream) {
+  if (half <= 0 || dim <= 0) return 0;
+  if (phi != 0.f && center == nullptr) return (int)hipErrorInvalidValue;
+  cso_step_kernel<<<stream_grid((int64_t)half * dim, 256), 256, 0, (hipStream_t)stream>>>(
+      key, pop, vel, fit, perm, center, phi, lb, ub, half, dim, new_pop, new_vel, cand, students);
+  return last_launch_status();
+}

@@ -10,6 +10,7 @@ import torch
 from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.struct import dataclass, pytree_field
+from ....ops import swarm as _swarm
 
 
 @dataclass
@@ -58,6 +59,11 @@ class CSO(Algorithm):
         key, k_pair, k_r = rnd.split(state.key, 3)
         half = self.pop_size // 2
         perm = rnd.permutation(k_pair, self.pop_size)[: 2 * half].reshape(2, half)
+        if (_swarm.on_gpu(state.population) and state.population.dtype == torch.float32 and half > 0
+                and state.population.dim() == 2 and state.fitness.dim() == 1):
+            cand, population, velocity, students = _swarm.cso_step(k_r, state.population, state.velocity, state.fitness,
+                                                                   perm, self.phi, self.lb, self.ub)
+            return cand, state.replace(population=population, velocity=velocity, students=students, key=key)
         first_wins = state.fitness[perm[0]] < state.fitness[perm[1]]
         teachers = torch.where(first_wins, perm[0], perm[1])
         students = torch.where(first_wins, perm[1], perm[0])

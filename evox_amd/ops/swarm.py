@@ -10,6 +10,7 @@ from ..core import random as rnd
 from ._util import check, hip, on_gpu, stream_of
 
 _native.register_hip_api({
+    "evox_hip_cso_step": (_native.I, [_native.P] * 6 + [_native.F, _native.P, _native.P, _native.I, _native.I] + [_native.P] * 5),
     "evox_hip_pso_step": (_native.I, [_native.P] * 17 + [_native.I64, _native.I, _native.F, _native.F, _native.F,
                                                         _native.P]),
 })
@@ -47,3 +48,22 @@ def pso_step(key, pop, vel, fit, pbest, pbest_fit, gbest, gbest_fit, lb, ub, w, 
         o_pop.data_ptr(), o_vel.data_ptr(), o_pbest.data_ptr(), o_pfit.data_ptr(), o_gbest.data_ptr(),
         o_gfit.data_ptr(), ws.data_ptr(), n, d, float(w), float(phi_p), float(phi_g), stream_of(pop)), "pso_step")
     return o_pop, o_vel, o_pbest, o_pfit, o_gbest, o_gfit
+
+
+def cso_step(key, pop, vel, fit, perm, phi, lb, ub):
+    """One competitive-swarm generation on the GPU (``csrc/swarm.hip``): ``perm`` pairs the first
+    half of a random permutation with the second; returns ``(cand, population, velocity, students)``
+    like the tensor formulation in ``algorithms/so/pso_variants/cso.py``."""
+    n, d = pop.shape
+    half = n // 2
+    pop, vel = pop.contiguous(), vel.contiguous()
+    new_pop, new_vel = pop.clone(), vel.clone()
+    cand = torch.empty((half, d), dtype=torch.float32, device=pop.device)
+    students = torch.empty(half, dtype=torch.int64, device=pop.device)
+    center = pop.mean(0) if phi != 0 else None
+    check(hip().evox_hip_cso_step(key.contiguous().data_ptr(), pop.data_ptr(), vel.data_ptr(), fit.contiguous().data_ptr(),
+                                  perm.contiguous().data_ptr(), center.data_ptr() if center is not None else None,
+                                  float(phi), lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), half, d,
+                                  new_pop.data_ptr(), new_vel.data_ptr(), cand.data_ptr(), students.data_ptr(),
+                                  stream_of(pop)), "cso_step")
+    return cand, new_pop, new_vel, students

@@ -657,3 +657,22 @@ def test_pipelined_stochastic_ranking_equals_sequential_sort(cuda, n):
     ref = moselect.stochastic_ranking(I1, I2, u, 0.45)                   # native host implementation
     assert torch.equal(got.cpu(), ref)
     assert sorted(got.tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("pop,dim,phi", [(1024, 100, 0.0), (101, 7, 0.1), (4, 3, 0.2)])
+def test_fused_cso_step_matches_tensor_formulation(cuda, pop, dim, phi, monkeypatch):
+    import evox_amd as ex
+    from evox_amd import algorithms
+    from evox_amd.ops import swarm
+
+    lb, ub = torch.full((dim,), -3.0, device=cuda), torch.full((dim,), 3.0, device=cuda)
+    algo = algorithms.CSO(lb, ub, pop, phi=phi)
+    state = algo.init(ex.PRNGKey(6))
+    state = state.replace(fitness=torch.rand(pop, device=cuda), velocity=torch.randn(pop, dim, device=cuda) * 0.1)
+    cand, s1 = algo.ask(state)
+    monkeypatch.setattr(swarm, "on_gpu", lambda x: False)
+    ref_cand, s2 = algo.ask(state)
+    assert torch.allclose(cand, ref_cand, rtol=1e-5, atol=1e-6)
+    assert torch.equal(s1.students, s2.students)
+    assert torch.allclose(s1.population, s2.population, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(s1.velocity, s2.velocity, rtol=1e-5, atol=1e-6)
