@@ -11,11 +11,15 @@ import math
 
 import torch
 
+from ... import _native
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import selection
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...ops import moselect as _sel
+from ...ops._util import check as _check
+from ...ops._util import hip as _hip
+from ...ops._util import stream_of as _stream_of
 from ...utils.common import cal_max, dominate_relation
 from .common import MOAlgorithm
 
@@ -89,16 +93,37 @@ class SPEA2(MOAlgorithm):
         return state.replace(population=pop[idx], fitness=obj[idx])
 
 
+_native.register_hip_api({"evox_hip_hv_credit": (_native.I, [_native.P, _native.I, _native.P, _native.I, _native.I, _native.P,
+                                                            _native.P, _native.P, _native.I, _native.P])})
+
+
+def _hv_kernel_enabled() -> bool:
+    import os
+
+    return os.environ.get("EVOX_AMD_HV", "hip") == "hip"
+
+
 def cal_hv(points, ref, k, n_sample, key):
     """HypE's Monte-Carlo estimate of each point's hypervolume contribution when ``k`` points
     are to be removed: a sample dominated by j points credits each of them α_j."""
     n, m = points.shape
     dev = points.device
     i = torch.arange(1, n, device=dev, dtype=torch.float32)
-    alpha = torch.cumprod(torch.cat([torch.ones(1, device=dev), (k - i) / (n - i)]), 0) / torch.arange(
+    # α_j = Π_{i<j} (k−i)/(n−i) / j vanishes for j > k; clamping the factors keeps a parallel scan from
+    # multiplying that zero with an overflowed tail (the factors beyond k grow up to n−1−k)
+    alpha = torch.cumprod(torch.cat([torch.ones(1, device=dev), (k - i).clamp_min(0) / (n - i)]), 0) / torch.arange(
         1, n + 1, device=dev, dtype=torch.float32)
     f_min = points.amin(0)
     samples = f_min + rnd.uniform(key, (n_sample, m)) * (ref - f_min)
+    if points.is_cuda and points.dtype == torch.float32 and 2 <= m <= 8 and _hv_kernel_enabled():
+        # two scans on the GPU instead of (n × S) boolean blocks (csrc/hvmc.hip)
+        ysplit = 8
+        cnt = torch.zeros(n_sample, dtype=torch.int32, device=dev)
+        partial = torch.empty((ysplit, n), dtype=torch.float32, device=dev)
+        _check(_hip().evox_hip_hv_credit(points.contiguous().data_ptr(), n, samples.contiguous().data_ptr(), n_sample, m,
+                                         cnt.data_ptr(), alpha.contiguous().data_ptr(), partial.data_ptr(), ysplit,
+                                         _stream_of(points)), "hv_credit")
+        return partial.sum(0) * (ref - f_min).prod() / n_sample
     credit = torch.zeros(n, device=dev)
     step = max(1, (1 << 22) // max(n, 1))
     for s in range(0, n_sample, step):

@@ -676,3 +676,17 @@ def test_fused_cso_step_matches_tensor_formulation(cuda, pop, dim, phi, monkeypa
     assert torch.equal(s1.students, s2.students)
     assert torch.allclose(s1.population, s2.population, rtol=1e-5, atol=1e-6)
     assert torch.allclose(s1.velocity, s2.velocity, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,S", [(200, 3, 5000), (3000, 2, 10000), (777, 5, 2048)])
+def test_hv_credit_kernel_matches_tensor_formulation(cuda, n, m, S, monkeypatch):
+    from evox_amd.algorithms.mo import indicator
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    pts = torch.rand(n, m, generator=g).to(cuda)
+    ref = torch.full((m,), 1.2, device=cuda)
+    key = rnd.PRNGKey(9).to(cuda)
+    got = indicator.cal_hv(pts, ref, n // 2, S, key)
+    monkeypatch.setenv("EVOX_AMD_HV", "torch")
+    want = indicator.cal_hv(pts, ref, n // 2, S, key)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), (got - want).abs().max()
