@@ -1,5 +1,5 @@
 """Generation time of every multi-objective algorithm on DTLZ2 (m=3) on the GPU.
-usage: mo_survey.py [pop] ; one JSON line per algorithm."""
+usage: mo_survey.py [pop] ; one JSON line per algorithm (time per generation, IGD after 65 generations)."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,6 +27,14 @@ for name in names:
             state = wf.step(state)
         torch.cuda.synchronize()
         row["ms_per_generation"] = (time.perf_counter() - t0) / steps * 1e3
+        # quality after 25 + 40 more generations: IGD to the true front (finite and small means selection works)
+        for _ in range(40):
+            state = wf.step(state)
+        from evox_amd import metrics
+        fit = state.get_child_state("algorithm").fitness
+        fit = fit[torch.isfinite(fit).all(1)]
+        row["igd_after_65_generations"] = float(metrics.igd(fit, prob.pf().to(dev)))
+        row["n_finite"] = int(fit.shape[0])
     except Exception as e:                                            # noqa: BLE001
         row["error"] = f"{type(e).__name__}: {e}"[:160]
     print(json.dumps(row), flush=True)
