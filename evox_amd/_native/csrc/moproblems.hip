@@ -119,3 +119,48 @@ EVOX_API int evox_hip_shift_rotate(const float* x, int64_t ldx, const float* o, 
                                                                                                n, d, out);
   return evox::last_launch_status();
 }
+
+// A x = b for one tiny dense system (m ≤ 16) by Gaussian elimination with partial pivoting, one lane.
+// The library routes (lstsq / solve / matrix_rank) cost milliseconds of host time on a 3 × 3 system;
+// NSGA-III solves one per generation for its hyperplane intercepts.  flag[0] = 1 when a pivot is
+// negligible against the largest entry (the matrix is numerically rank deficient).
+namespace {
+__global__ void small_solve_kernel(const float* __restrict__ A, const float* __restrict__ b, int m, float* __restrict__ x,
+                                   int* __restrict__ flag) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float a[16][17];
+  float scale = 0.f;
+  for (int i = 0; i < m; ++i) {
+    for (int j = 0; j < m; ++j) { a[i][j] = A[i * m + j]; scale = fmaxf(scale, fabsf(a[i][j])); }
+    a[i][m] = b[i];
+  }
+  int singular = !(scale > 0.f) || !(scale < INFINITY);
+  const float tiny = scale * 1e-6f * (float)m;
+  for (int c = 0; c < m && !singular; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < m; ++r) if (fabsf(a[r][c]) > fabsf(a[piv][c])) piv = r;
+    if (!(fabsf(a[piv][c]) > tiny)) { singular = 1; break; }
+    if (piv != c) for (int j = c; j <= m; ++j) { const float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const float inv = 1.f / a[c][c];
+    for (int r = c + 1; r < m; ++r) {
+      const float f = a[r][c] * inv;
+      for (int j = c; j <= m; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  if (!singular) {
+    for (int r = m - 1; r >= 0; --r) {
+      float s = a[r][m];
+      for (int j = r + 1; j < m; ++j) s -= a[r][j] * a[j][m];
+      a[r][m] = s / a[r][r];
+    }
+  }
+  for (int i = 0; i < m; ++i) x[i] = singular ? NAN : a[i][m];
+  flag[0] = singular;
+}
+}  // namespace
+
+EVOX_API int evox_hip_small_solve(const float* A, const float* b, int m, float* x, int* flag, void* stream) {
+  if (m < 1 || m > 16) return (int)hipErrorInvalidValue;
+  small_solve_kernel<<<1, 64, 0, (hipStream_t)stream>>>(A, b, m, x, flag);
+  return evox::last_launch_status();
+}

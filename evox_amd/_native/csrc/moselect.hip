@@ -165,6 +165,73 @@ __global__ __launch_bounds__(64) void stochastic_ranking_serial_kernel(const flo
   for (int i = threadIdx.x; i < n; i += 64) rank[i] = rk[i];
 }
 
+
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* s_w) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) s_w[wave] = v;
+  __syncthreads();
+  long long r = 0;
+  for (int w = 0; w < NT / 64; ++w) r += s_w[w];
+  return r;
+}
+
+// NSGA-III niche water-filling: the smallest level L with Σ_j min(c_j, max(0, L − ρ_j)) ≥ k by bisection,
+// then t_j = granted(L − 1) plus one more for the first (k − Σ granted(L − 1)) niches that can still take
+// one at level L, in index order.  One workgroup: the bisection is ~log2(population) block reductions
+// over a few thousand niches, which as separate tensor operations costs a hundred launches.
+__global__ __launch_bounds__(NT) void niche_fill_kernel(const int64_t* __restrict__ rho, const int64_t* __restrict__ cnt,
+                                                        int nref, const int64_t* __restrict__ kptr,
+                                                        int64_t* __restrict__ out) {
+  __shared__ long long s_w[NT / 64];
+  __shared__ int s_scan[NT / 64];
+  const long long k = *kptr;
+  long long mr = 0, mc = 0;
+  for (int j = threadIdx.x; j < nref; j += NT) { mr = max(mr, (long long)rho[j]); mc = max(mc, (long long)cnt[j]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mr = max(mr, __shfl_xor(mr, o, 64)); mc = max(mc, __shfl_xor(mc, o, 64)); }
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = mr + mc;      // ≥ every ρ_j + c_j after the max below
+  __syncthreads();
+  long long hi = 0;
+  for (int w = 0; w < NT / 64; ++w) hi = max(hi, s_w[w]);
+  hi += 1;
+  long long lo = 0;
+  auto granted = [&](int j, long long level) -> long long {
+    const long long room = level - (long long)rho[j];
+    return min((long long)cnt[j], room > 0 ? room : 0ll);
+  };
+  while (lo < hi) {                                                   // uniform: every thread holds the same lo, hi
+    const long long mid = (lo + hi) / 2;
+    long long part = 0;
+    for (int j = threadIdx.x; j < nref; j += NT) part += granted(j, mid);
+    if (block_sum_ll(part, s_w) >= k) hi = mid; else lo = mid + 1;
+  }
+  const long long level = hi;
+  long long part = 0;
+  for (int j = threadIdx.x; j < nref; j += NT) part += granted(j, level - 1);
+  const long long need = k - block_sum_ll(part, s_w);
+  // running count of niches that can take one more, in index order, chunk by chunk
+  long long before = 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int j0 = 0; j0 < nref; j0 += NT) {
+    const int j = j0 + threadIdx.x;
+    long long base = 0; int ok = 0;
+    if (j < nref) { base = granted(j, level - 1); ok = granted(j, level) > base; }
+    int inc = ok;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    __syncthreads();
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    int wave_before = 0, total = 0;
+    for (int w = 0; w < NT / 64; ++w) { if (w < wave) wave_before += s_scan[w]; total += s_scan[w]; }
+    if (j < nref) out[j] = base + ((ok && before + wave_before + inc <= need) ? 1 : 0);
+    before += total;
+  }
+}
+
 }  // namespace
 
 EVOX_API int evox_hip_ibea_remove(float* fit, const float* I, const float* C, float kappa, int n, int n_remove,
@@ -196,5 +263,12 @@ EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const
   }
   if (scratch == nullptr) return (int)hipErrorInvalidValue;
   stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_niche_fill(const int64_t* rho, const int64_t* cnt, int nref, const int64_t* k, int64_t* out,
+                                 void* stream) {
+  if (nref <= 0) return 0;
+  niche_fill_kernel<<<1, NT, 0, (hipStream_t)stream>>>(rho, cnt, nref, k, out);
   return last_launch_status();
 }

@@ -12,26 +12,60 @@ from __future__ import annotations
 
 import torch
 
+from ... import _native
 from ...core import random as rnd
 from ...core.state import State
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...utils.common import cos_dist
+from ...ops._util import check as _check
+from ...ops._util import hip as _hip
+from ...ops._util import stream_of as _stream_of
 from .common import MOAlgorithm
 
+_native.register_hip_api({
+    "evox_hip_small_solve": (_native.I, [_native.P, _native.P, _native.I, _native.P, _native.P, _native.P]),
+    "evox_hip_niche_fill": (_native.I, [_native.P, _native.P, _native.I, _native.P, _native.P, _native.P]),
+})
 
-def _niche_fill(rho, cnt, k):
+
+def _hyperplane_intercepts(extreme):
+    """``(intercepts, ok)`` of the hyperplane through the rows of ``extreme`` (m × m): the solution of
+    ``extreme · x = 1`` inverted, and whether the system was well posed."""
+    m = extreme.shape[0]
+    if extreme.is_cuda and extreme.dtype == torch.float32 and m <= 16:
+        # one tiny elimination kernel instead of the library's least-squares + rank routines
+        sol = torch.empty(m, dtype=torch.float32, device=extreme.device)
+        flag = torch.empty(1, dtype=torch.int32, device=extreme.device)
+        ones = torch.ones(m, dtype=torch.float32, device=extreme.device)
+        _check(_hip().evox_hip_small_solve(extreme.contiguous().data_ptr(), ones.data_ptr(), m, sol.data_ptr(), flag.data_ptr(),
+                                           _stream_of(extreme)), "small_solve")
+        return 1.0 / sol, flag[0] == 0
+    sol = torch.linalg.lstsq(extreme, torch.ones(m, 1, device=extreme.device)).solution[:, 0]
+    return 1.0 / sol, torch.linalg.matrix_rank(extreme) == m
+
+
+def _niche_fill(rho, cnt, k, max_level: int = 1 << 40):
     """Slots t_j granted to each niche (ρ_j members already, c_j candidates) when ``k`` more
-    individuals are admitted one at a time to the currently least crowded niche."""
+    individuals are admitted one at a time to the currently least crowded niche.  ``max_level``:
+    a host-known bound on ρ_j + c_j + 1 (the population size), which bounds the bisection."""
     rho = rho.to(torch.int64)
     cnt = cnt.to(torch.int64)
+    if rho.is_cuda:
+        # the whole bisection and the tie-breaking prefix count in one single-workgroup launch
+        kk = torch.as_tensor(k, dtype=torch.int64, device=rho.device).reshape(1)
+        rho, cnt = rho.contiguous(), cnt.contiguous()
+        out = torch.empty_like(rho)
+        _check(_hip().evox_hip_niche_fill(rho.data_ptr(), cnt.data_ptr(), rho.shape[0], kk.data_ptr(), out.data_ptr(),
+                                          _stream_of(rho)), "niche_fill")
+        return out
     lo = torch.zeros((), dtype=torch.int64, device=rho.device)
     hi = (rho.max() + cnt.max() + 1).to(torch.int64)
 
     def granted(level):
         return torch.minimum(cnt, (level - rho).clamp_min(0))
 
-    for _ in range(40):                     # bisection on the level; 2^40 exceeds any count
+    for _ in range(max_level.bit_length() + 1):        # bisection on the level (an integer below max_level)
         mid = (lo + hi) // 2
         enough = granted(mid).sum() >= k
         hi = torch.where(enough, mid, hi)
@@ -66,9 +100,7 @@ class NSGA3(MOAlgorithm):
         extreme = shifted[torch.argmin(asf, dim=1)]                                # (m, m)
         worst = torch.where(considered[:, None], shifted, -inf).amax(0)
         # hyperplane through the extreme points; fall back to the worst point when degenerate
-        sol = torch.linalg.lstsq(extreme, torch.ones(m, 1, device=fit.device)).solution[:, 0]
-        intercept = 1.0 / sol
-        full_rank = torch.linalg.matrix_rank(extreme) == m
+        intercept, full_rank = _hyperplane_intercepts(extreme)
         ok = full_rank & torch.isfinite(intercept).all() & (intercept > 1e-12).all()
         nadir = torch.where(ok, intercept, worst).clamp_min(1e-12)
         return shifted / nadir
@@ -89,11 +121,10 @@ class NSGA3(MOAlgorithm):
         gdist = dist.amin(1)
         nref = self.ref.shape[0]
         earlier, last = rank < last_rank, rank == last_rank
-        rho = torch.bincount(group[earlier], minlength=nref) if bool(earlier.any()) else torch.zeros(nref, dtype=torch.int64, device=fit.device)
         rho = torch.zeros(nref, dtype=torch.int64, device=fit.device).scatter_add(0, group, earlier.to(torch.int64))
         cnt = torch.zeros(nref, dtype=torch.int64, device=fit.device).scatter_add(0, group, last.to(torch.int64))
         need = k_total - earlier.sum()
-        slots = _niche_fill(rho, cnt, need)                                        # (nref,)
+        slots = _niche_fill(rho, cnt, need, max_level=2 * n + 2)                   # (nref,)
         # order of the candidates inside their niche: closest first if the niche was empty,
         # otherwise random
         u = rnd.uniform(k_sel, (n,))
