@@ -54,16 +54,45 @@ __global__ __launch_bounds__(NT) void ibea_remove_kernel(float* __restrict__ fit
   }
 }
 
-__global__ __launch_bounds__(NT) void spea2_truncate_kernel(float* __restrict__ dis, int n, int n_remove,
-                                                            uint8_t* __restrict__ keep, float* __restrict__ rowmin,
-                                                            int* __restrict__ nn) {
+// SPEA2 truncation.  The distance matrix is read-only (rows padded to a multiple of four floats, +inf on
+// the diagonal); which points are gone is a byte mask.  Per point the kernel tracks the distance to the
+// nearest live neighbour and who that is; removing x only invalidates the rows whose neighbour was x,
+// and each of those is rescanned by one wave with 16-byte loads.  The three per-point arrays live in
+// LDS (9 bytes a point) when they fit.
+template <bool kLds>
+__global__ __launch_bounds__(NT) void spea2_truncate_kernel(const float* __restrict__ dis, int n, int ld, int n_remove,
+                                                            uint8_t* __restrict__ alive_g, float* __restrict__ rowmin_g,
+                                                            int* __restrict__ nn_g) {
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];
   __shared__ float s_v[NT / 64];
   __shared__ int s_i[NT / 64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = NT / 64;
-  auto scan_row = [&](int i) {           // one wavefront scans one row
+  float* rowmin = rowmin_g;
+  int* nn = nn_g;
+  uint8_t* alive = alive_g;
+  if constexpr (kLds) {
+    rowmin = reinterpret_cast<float*>(s_dyn);
+    nn = s_dyn + ld;
+    alive = reinterpret_cast<uint8_t*>(s_dyn + 2 * ld);
+    for (int j = threadIdx.x; j < ld; j += NT) {
+      rowmin[j] = j < n ? rowmin_g[j] : INFINITY;
+      nn[j] = j < n ? nn_g[j] : -1;
+      alive[j] = alive_g[j];
+    }
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto scan_row = [&](int i) {           // one wavefront rescans one row among the live columns
     float v = INFINITY; int a = 0x7fffffff;
-    const float* row = dis + (int64_t)i * n;
-    for (int j = lane; j < n; j += 64) { const float d = row[j]; if (d < v || (d == v && j < a)) { v = d; a = j; } }
+    const float4* row = reinterpret_cast<const float4*>(dis + (int64_t)i * ld);
+    const uint32_t* al4 = reinterpret_cast<const uint32_t*>(alive);
+    for (int q = lane; q < (ld >> 2); q += 64) {
+      const float4 d = row[q];
+      const uint32_t al = al4[q];
+      if ((al & 0x000000ffu) && d.x < v) { v = d.x; a = 4 * q; }
+      if ((al & 0x0000ff00u) && d.y < v) { v = d.y; a = 4 * q + 1; }
+      if ((al & 0x00ff0000u) && d.z < v) { v = d.z; a = 4 * q + 2; }
+      if ((al & 0xff000000u) && d.w < v) { v = d.w; a = 4 * q + 3; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(v, o, 64); const int oa = __shfl_xor(a, o, 64);
@@ -71,19 +100,26 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(float* __restrict__ 
     }
     if (lane == 0) { rowmin[i] = v; nn[i] = (v == INFINITY) ? -1 : a; }
   };
-  for (int i = wave; i < n; i += nwave) scan_row(i);
-  __syncthreads();
   for (int r = 0; r < n_remove; ++r) {
     float v = INFINITY; int idx = 0x7fffffff;
     for (int j = threadIdx.x; j < n; j += NT) { const float f = rowmin[j]; if (f < v || (f == v && j < idx)) { v = f; idx = j; } }
     const ArgMin m = block_argmin(v, idx, s_v, s_i);
     const int x = m.i == 0x7fffffff ? 0 : m.i;
-    for (int j = threadIdx.x; j < n; j += NT) { dis[(int64_t)x * n + j] = INFINITY; dis[(int64_t)j * n + x] = INFINITY; }
-    if (threadIdx.x == 0) { keep[x] = 0; rowmin[x] = INFINITY; nn[x] = -1; }
+    if (threadIdx.x == 0) { alive[x] = 0; rowmin[x] = INFINITY; nn[x] = -1; }
     __syncthreads();
-    for (int i = wave; i < n; i += nwave)
-      if (nn[i] == x) scan_row(i);                      // wave-uniform condition
+    for (int i0 = 0; i0 < n; i0 += NT) {
+      const int i = i0 + threadIdx.x;
+      unsigned long long hit = __ballot(i < n && nn[i] == x);
+      while (hit) {                                     // wave-uniform
+        const int bit = __ffsll((long long)hit) - 1;
+        hit &= hit - 1;
+        scan_row(i0 + wave * 64 + bit);
+      }
+    }
     __syncthreads();
+  }
+  if constexpr (kLds) {
+    for (int j = threadIdx.x; j < n; j += NT) alive_g[j] = alive[j];
   }
 }
 
@@ -240,8 +276,23 @@ EVOX_API int evox_hip_ibea_remove(float* fit, const float* I, const float* C, fl
   return last_launch_status();
 }
 
-EVOX_API int evox_hip_spea2_truncate(float* dis, int n, int n_remove, uint8_t* keep, float* rowmin, int* nn, void* stream) {
-  spea2_truncate_kernel<<<1, NT, 0, (hipStream_t)stream>>>(dis, n, n_remove, keep, rowmin, nn);
+// dis: (n, ld) with ld % 4 == 0; alive: ld bytes in/out (padding zero); rowmin / nn: each row's minimum over
+// the live columns and its position, computed by the caller with a full-chip reduction.
+EVOX_API int evox_hip_spea2_truncate(const float* dis, int n, int ld, int n_remove, uint8_t* alive, float* rowmin, int* nn,
+                                     void* stream) {
+  if (n <= 0 || n_remove <= 0) return 0;
+  if (ld < n || (ld & 3)) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)ld * 9;
+  if (lds <= 150 * 1024) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)spea2_truncate_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    spea2_truncate_kernel<true><<<1, NT, lds, (hipStream_t)stream>>>(dis, n, ld, n_remove, alive, rowmin, nn);
+  } else {
+    spea2_truncate_kernel<false><<<1, NT, 0, (hipStream_t)stream>>>(dis, n, ld, n_remove, alive, rowmin, nn);
+  }
   return last_launch_status();
 }
 

@@ -58,13 +58,21 @@ class IBEA(MOAlgorithm):
 
 def spea2_fitness(obj):
     """Raw fitness (sum of the strengths of one's dominators) + k-th-nearest-neighbour density."""
+    if _sel.spea2_fitness_supported(obj) and obj.shape[0] >= 2:
+        return _sel.spea2_fitness(obj)
+    return spea2_fitness_reference(obj)
+
+
+def spea2_fitness_reference(obj):
+    """``spea2_fitness`` with dense n × n dominance and distance matrices."""
     n = obj.shape[0]
     dom = dominate_relation(obj, obj)
     strength = dom.sum(1).to(torch.float32)
     raw = (dom.to(torch.float32) * strength[:, None]).sum(0)
     dis = torch.cdist(obj, obj)
     dis = dis.masked_fill(torch.eye(n, dtype=torch.bool, device=obj.device), float("inf"))
-    kth = torch.sort(dis, dim=1).values[:, int(math.floor(math.sqrt(6))) - 1]
+    k = int(math.floor(math.sqrt(6)))
+    kth = torch.topk(dis, k, dim=1, largest=False).values[:, k - 1]
     return 1.0 / (kth + 2) + raw
 
 

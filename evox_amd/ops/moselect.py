@@ -22,8 +22,9 @@ _native.register_cpu_api({
 })
 _native.register_hip_api({
     "evox_hip_ibea_remove": (I, [P, P, P, F, I, I, P, P]),
-    "evox_hip_spea2_truncate": (I, [P, I, I, P, P, P, P]),
+    "evox_hip_spea2_truncate": (I, [P, I, I, I, P, P, P, P]),
     "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
+    "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
 })
 
 
@@ -63,6 +64,22 @@ def _masked_distances(obj, mask):
     return torch.where(pair, dis, torch.full_like(dis, float("inf"))).contiguous()
 
 
+def spea2_fitness_supported(obj) -> bool:
+    return on_gpu(obj) and obj.dim() == 2 and obj.dtype == torch.float32 and 2 <= obj.shape[1] <= 8
+
+
+def spea2_fitness(obj) -> torch.Tensor:
+    """SPEA2 fitness (strength-weighted dominator sum + 1 / (2nd-nearest-neighbour distance + 2)) of the
+    rows of ``obj`` in two streaming passes; no n × n matrix is formed."""
+    n, m = obj.shape
+    obj = obj.contiguous()
+    scratch = torch.empty((2, n), dtype=torch.float32, device=obj.device)
+    fit = torch.empty(n, dtype=torch.float32, device=obj.device)
+    check(hip().evox_hip_spea2_fitness(obj.data_ptr(), n, m, scratch[0].data_ptr(), scratch[1].data_ptr(), fit.data_ptr(),
+                                       stream_of(obj)), "spea2_fitness")
+    return fit
+
+
 def spea2_truncate_reference(obj, mask, n_remove: int) -> torch.Tensor:
     n = obj.shape[0]
     dis = _masked_distances(obj, mask)
@@ -80,15 +97,30 @@ def spea2_truncate(obj, mask, n_remove: int) -> torch.Tensor:
     """SPEA2 archive truncation among the rows selected by ``mask``: repeatedly drop the point
     whose nearest remaining neighbour is closest.  Returns the survivor mask (⊂ mask)."""
     n = obj.shape[0]
+    if on_gpu(obj):
+        if int(n_remove) <= 0:
+            return mask.clone()
+        # the loop only concerns the selected rows: compact them (host-synchronising; callers know the
+        # count already) so that the matrix and the per-point state cover those rows only
+        idx = torch.nonzero(mask).squeeze(1)
+        sub = obj[idx].float()
+        nv = sub.shape[0]
+        ld = (nv + 3) // 4 * 4
+        dis = torch.full((nv, ld), float("inf"), dtype=torch.float32, device=obj.device)
+        dis[:, :nv] = torch.cdist(sub, sub)
+        dis.diagonal().fill_(float("inf"))
+        rowmin, nn = dis.min(1)                           # full-chip reduction; the kernel keeps it current
+        nn = nn.to(torch.int32)
+        alive = torch.zeros(ld, dtype=torch.uint8, device=obj.device)
+        alive[:nv] = 1
+        check(hip().evox_hip_spea2_truncate(dis.data_ptr(), nv, ld, int(n_remove), alive.data_ptr(), rowmin.data_ptr(),
+                                            nn.data_ptr(), stream_of(dis)), "spea2_truncate")
+        keep = torch.zeros(n, dtype=torch.bool, device=obj.device)
+        keep[idx] = alive[:nv].bool()
+        return keep
     dis = _masked_distances(obj, mask)
     keep = mask.to(torch.uint8).contiguous()
-    if on_gpu(dis):
-        rowmin = torch.empty(n, dtype=torch.float32, device=dis.device)
-        nn = torch.empty(n, dtype=torch.int32, device=dis.device)
-        check(hip().evox_hip_spea2_truncate(dis.data_ptr(), n, int(n_remove), keep.data_ptr(), rowmin.data_ptr(),
-                                            nn.data_ptr(), stream_of(dis)), "spea2_truncate")
-    else:
-        _native.cpu().evox_cpu_spea2_truncate(dis.data_ptr(), n, int(n_remove), keep.data_ptr())
+    _native.cpu().evox_cpu_spea2_truncate(dis.data_ptr(), n, int(n_remove), keep.data_ptr())
     return keep.bool()
 
 

@@ -722,3 +722,17 @@ def test_niche_fill_kernel_matches_bisection(nref, k):
     got = _niche_fill(rho.cuda(), cnt.cuda(), torch.tensor(k).cuda())
     assert torch.equal(got.cpu(), ref)
     assert int(ref.sum()) == min(k, int(cnt.sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(2, 2), (65, 3), (700, 2), (1237, 5), (4000, 3)])
+def test_spea2_fitness_kernels_match_dense_formulation(n, m):
+    from evox_amd.algorithms.mo.indicator import spea2_fitness, spea2_fitness_reference
+
+    g = torch.Generator().manual_seed(n + m)
+    obj = torch.rand(n, m, generator=g)
+    obj[n // 2] = obj[0]                                   # a duplicate: distance 0, no dominance either way
+    got = spea2_fitness(obj.cuda()).cpu()
+    want = spea2_fitness_reference(obj.double()).float()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), (got - want).abs().max()
+    assert torch.equal(got < 1, want < 1)
