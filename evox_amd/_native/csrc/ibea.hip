@@ -1,0 +1,249 @@
+// IBEA's ε-indicator fitness and its removal loop straight from the objective vectors.
+//
+// I(i, j) = max_k (f_i[k] − f_j[k]) is a three-flop function of two short vectors, so neither the
+// fitness  F_j = 1 − Σ_i exp(−I(i, j) / (C_j κ)),  C_j = max_i |I(i, j)|,  nor the removal loop needs the
+// n × n indicator matrix (nor the n × n × m difference tensor behind it): two streaming passes compute
+// C and F, and the removal loop keeps objectives, C and F of the whole merged population in LDS, so one
+// removal is an arg-min and one LDS-to-LDS update between workgroup barriers, with no global-memory
+// latency on its critical path.
+#include "hip_common.h"
+
+using namespace evox;
+
+namespace {
+
+constexpr int NT = 1024;
+
+template <int M>
+__device__ __forceinline__ float eps_ind(const float (&a)[M], const float (&b)[M]) {
+  float v = a[0] - b[0];
+#pragma unroll
+  for (int k = 1; k < M; ++k) v = fmaxf(v, a[k] - b[k]);
+  return v;
+}
+
+// 256 threads = 64 columns j × 4 slices of the rows i; PASS 0: C_j, PASS 1: F_j (reads C).
+template <int M, int PASS>
+__global__ __launch_bounds__(256) void ibea_fitness_kernel(const float* __restrict__ obj, int n, float kappa,
+                                                           float* __restrict__ C, float* __restrict__ fit) {
+  __shared__ float tile[M][256];
+  __shared__ float part[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + r;
+  float mine[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) mine[k] = j < n ? obj[(int64_t)j * M + k] : 0.f;
+  const float cj = (PASS == 1 && j < n) ? C[j] : 1.f;
+  float acc = 0.f;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? obj[(int64_t)ii * M + k] : 0.f;
+    __syncthreads();
+    const int lim = min(64, n - i0 - s * 64);             // rows of this slice that exist
+    for (int q = 0; q < lim; ++q) {
+      const int c = s * 64 + q;
+      float other[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) other[k] = tile[k][c];
+      const float v = eps_ind<M>(other, mine);
+      if (PASS == 0) acc = fmaxf(acc, fabsf(v));
+      else acc += expf(-v / cj / kappa);
+    }
+  }
+  part[s][r] = acc;
+  __syncthreads();
+  if (s == 0 && j < n) {
+    if (PASS == 0) C[j] = fmaxf(fmaxf(acc, part[1][r]), fmaxf(part[2][r], part[3][r]));
+    else fit[j] = 1.0f - (acc + part[1][r] + part[2][r] + part[3][r]);
+  }
+}
+
+struct ArgMin { float v; int i; };
+
+__device__ __forceinline__ ArgMin block_argmin(float v, int i, float* s_v, int* s_i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
+  __syncthreads();
+  // every wave folds the 16 partial results with four shuffle steps
+  float rv = s_v[lane & 15];
+  int ri = s_i[lane & 15];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(rv, o, 64);
+    const int oi = __shfl_xor(ri, o, 64);
+    if (ov < rv || (ov == rv && oi < ri)) { rv = ov; ri = oi; }
+  }
+  return ArgMin{rv, ri};
+}
+
+// LDS: objectives [M][n4] | C [n4] | fitness [n4] | alive bytes [n4]
+template <int M>
+__global__ __launch_bounds__(NT) void ibea_remove_obj_kernel(const float* __restrict__ obj, int n, const float* __restrict__ C,
+                                                             float kappa, const float* __restrict__ fit_in, int n_remove,
+                                                             uint8_t* __restrict__ alive_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_f[];
+  __shared__ float s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  const int n4 = (n + 3) & ~3;
+  float* o = s_f;
+  float* c = s_f + M * n4;
+  float* fit = c + n4;
+  uint8_t* alive = reinterpret_cast<uint8_t*>(fit + n4);
+  for (int j = threadIdx.x; j < n; j += NT) {
+#pragma unroll
+    for (int k = 0; k < M; ++k) o[k * n4 + j] = obj[(int64_t)j * M + k];
+    c[j] = C[j]; fit[j] = fit_in[j]; alive[j] = 1;
+  }
+  __syncthreads();
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += NT)
+      if (alive[j]) { const float f = fit[j]; if (f < v || (f == v && j < idx)) { v = f; idx = j; } }
+    const ArgMin m = block_argmin(v, idx, s_v, s_i);
+    if (m.i == 0x7fffffff) break;                       // uniform: nothing left
+    const int x = m.i;
+    const float s = 1.0f / (c[x] * kappa);
+    float ox[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) ox[k] = o[k * n4 + x];
+    for (int j = threadIdx.x; j < n; j += NT) {
+      float oj[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) oj[k] = o[k * n4 + j];
+      fit[j] += expf(-eps_ind<M>(ox, oj) * s);
+    }
+    if (threadIdx.x == 0) alive[x] = 0;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n; j += NT) alive_out[j] = alive[j];
+}
+
+// The same loop with every thread's share of the population (E members: fitness and objectives) held in
+// registers: LDS serves only the broadcast of the removed member's objectives and scale.  One workgroup
+// is bound by instruction issue of its single compute unit, so the loop body is kept to the E indicator
+// evaluations (hardware exp) and a running arg-min for the next round.
+template <int M, int E>
+__global__ __launch_bounds__(NT) void ibea_remove_reg_kernel(const float* __restrict__ obj, int n, const float* __restrict__ C,
+                                                             float kappa, const float* __restrict__ fit_in, int n_remove,
+                                                             uint8_t* __restrict__ alive_out) {
+  extern __shared__ __attribute__((aligned(16))) float s_f[];
+  __shared__ float s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  const int n4 = (n + 3) & ~3;
+  float* o = s_f;
+  float* c = s_f + M * n4;
+  float f[E], oj[E][M];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = threadIdx.x + e * NT;
+    f[e] = INFINITY;
+#pragma unroll
+    for (int k = 0; k < M; ++k) oj[e][k] = 0.f;
+    if (j < n) {
+      f[e] = fit_in[j];
+#pragma unroll
+      for (int k = 0; k < M; ++k) { oj[e][k] = obj[(int64_t)j * M + k]; o[k * n4 + j] = oj[e][k]; }
+      c[j] = C[j];
+    }
+  }
+  __syncthreads();
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = 0x7fffffff;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (f[e] < v) { v = f[e]; idx = threadIdx.x + e * NT; }
+    const ArgMin m = block_argmin(v, idx, s_v, s_i);
+    if (m.i == 0x7fffffff) break;                       // uniform: nothing left
+    const int x = m.i;
+    const float s = -1.0f / (c[x] * kappa);
+    float ox[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) ox[k] = o[k * n4 + x];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float add = __expf(eps_ind<M>(ox, oj[e]) * s);
+      f[e] = (threadIdx.x + e * NT == x) ? INFINITY : f[e] + add;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = threadIdx.x + e * NT;
+    if (j < n) alive_out[j] = f[e] < INFINITY ? 1 : 0;
+  }
+}
+
+template <int M>
+int launch_fitness(const float* obj, int n, float kappa, float* C, float* fit, hipStream_t st) {
+  const int blocks = (n + 63) / 64;
+  ibea_fitness_kernel<M, 0><<<blocks, 256, 0, st>>>(obj, n, kappa, C, fit);
+  ibea_fitness_kernel<M, 1><<<blocks, 256, 0, st>>>(obj, n, kappa, C, fit);
+  return last_launch_status();
+}
+
+template <int M, int E>
+int launch_remove_reg(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove, uint8_t* alive,
+                      hipStream_t st) {
+  const size_t lds = (size_t)((n + 3) & ~3) * 4 * (M + 1);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)ibea_remove_reg_kernel<M, E>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  ibea_remove_reg_kernel<M, E><<<1, NT, lds, st>>>(obj, n, C, kappa, fit, n_remove, alive);
+  return last_launch_status();
+}
+
+template <int M>
+int launch_remove(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove, uint8_t* alive,
+                  hipStream_t st) {
+  if (n <= 4 * NT) return launch_remove_reg<M, 4>(obj, n, C, kappa, fit, n_remove, alive, st);
+  if (n <= 8 * NT && M <= 4) return launch_remove_reg<M, 8>(obj, n, C, kappa, fit, n_remove, alive, st);
+  const size_t lds = (size_t)((n + 3) & ~3) * (4 * (M + 2) + 1);
+  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)ibea_remove_obj_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  ibea_remove_obj_kernel<M><<<1, NT, lds, st>>>(obj, n, C, kappa, fit, n_remove, alive);
+  return last_launch_status();
+}
+
+}  // namespace
+
+#define EVOX_IBEA_DISPATCH(FN, ...)                \
+  switch (m) {                                     \
+    case 2: return FN<2>(__VA_ARGS__);             \
+    case 3: return FN<3>(__VA_ARGS__);             \
+    case 4: return FN<4>(__VA_ARGS__);             \
+    case 5: return FN<5>(__VA_ARGS__);             \
+    case 6: return FN<6>(__VA_ARGS__);             \
+    case 7: return FN<7>(__VA_ARGS__);             \
+    case 8: return FN<8>(__VA_ARGS__);             \
+    default: return (int)hipErrorInvalidValue;     \
+  }
+
+// obj: (n, m) row-major fp32 (already normalised), 2 ≤ m ≤ 8.  C, fit: out (n).
+EVOX_API int evox_hip_ibea_fitness(const float* obj, int n, int m, float kappa, float* C, float* fit, void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_fitness, obj, n, kappa, C, fit, (hipStream_t)stream)
+}
+
+// Bytes of LDS the removal loop needs for (n, m); the caller falls back to the matrix form above 150 KB.
+EVOX_API int64_t evox_hip_ibea_remove_obj_lds(int n, int m) { return (int64_t)((n + 3) & ~3) * (4 * (m + 2) + 1); }
+
+EVOX_API int evox_hip_ibea_remove_obj(const float* obj, int n, int m, const float* C, float kappa, const float* fit,
+                                      int n_remove, uint8_t* alive, void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_remove, obj, n, C, kappa, fit, n_remove, alive, (hipStream_t)stream)
+}

@@ -33,13 +33,27 @@ __device__ __forceinline__ ArgMin block_argmin(float v, int i, float* s_v, int* 
   return r;
 }
 
-__global__ __launch_bounds__(NT) void ibea_remove_kernel(float* __restrict__ fit, const float* __restrict__ I,
+// IBEA removal: drop the member with the smallest fitness, add back the indicator loss it caused to
+// everyone else (one matrix row), repeat.  Fitness and the live mask stay in LDS when they fit; the row
+// is read with 16-byte loads when rows are 16-byte aligned.
+template <bool kLds>
+__global__ __launch_bounds__(NT) void ibea_remove_kernel(float* __restrict__ fit_g, const float* __restrict__ I,
                                                          const float* __restrict__ C, float kappa, int n, int n_remove,
-                                                         uint8_t* __restrict__ alive) {
+                                                         uint8_t* __restrict__ alive_g) {
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];
   __shared__ float s_v[NT / 64];
   __shared__ int s_i[NT / 64];
+  float* fit = fit_g;
+  uint8_t* alive = alive_g;
+  const int n4 = (n + 3) & ~3;
+  if constexpr (kLds) {
+    fit = reinterpret_cast<float*>(s_dyn);
+    alive = reinterpret_cast<uint8_t*>(s_dyn + n4);
+    for (int j = threadIdx.x; j < n; j += NT) fit[j] = fit_g[j];
+  }
   for (int j = threadIdx.x; j < n; j += NT) alive[j] = 1;
   __syncthreads();
+  const bool vec = (n & 3) == 0;
   for (int r = 0; r < n_remove; ++r) {
     float v = INFINITY; int idx = 0x7fffffff;
     for (int j = threadIdx.x; j < n; j += NT)
@@ -48,9 +62,70 @@ __global__ __launch_bounds__(NT) void ibea_remove_kernel(float* __restrict__ fit
     if (m.i == 0x7fffffff) break;                       // uniform: nothing left
     const float s = 1.0f / (C[m.i] * kappa);
     const float* row = I + (int64_t)m.i * n;
-    for (int j = threadIdx.x; j < n; j += NT) fit[j] += expf(-row[j] * s);
+    if (vec) {
+      const float4* row4 = reinterpret_cast<const float4*>(row);
+      float4* fit4 = reinterpret_cast<float4*>(fit);
+      for (int q = threadIdx.x; q < (n >> 2); q += NT) {
+        const float4 d = row4[q];
+        float4 f = fit4[q];
+        f.x += expf(-d.x * s); f.y += expf(-d.y * s); f.z += expf(-d.z * s); f.w += expf(-d.w * s);
+        fit4[q] = f;
+      }
+    } else {
+      for (int j = threadIdx.x; j < n; j += NT) fit[j] += expf(-row[j] * s);
+    }
     if (threadIdx.x == 0) alive[m.i] = 0;
     __syncthreads();
+  }
+  if constexpr (kLds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += NT) { fit_g[j] = fit[j]; alive_g[j] = alive[j]; }
+  }
+}
+
+// Niche-crowding removal (the Pareto-criterion archive of BCE): the crowding degree of member j is
+// 1 − Π_{i alive} min(d_ij / r, 1), kept as a sum of logarithms plus a count of zero factors.  Each step
+// drops the most crowded member x and takes its factors out of every product: row x of ``logs``, where a
+// NaN entry stands for a zero factor.
+template <bool kLds>
+__global__ __launch_bounds__(NT) void crowd_remove_kernel(const float* __restrict__ logs, int n, int n_remove,
+                                                          float* __restrict__ log_sum_g, int* __restrict__ zero_cnt_g,
+                                                          uint8_t* __restrict__ alive_g) {
+  extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+  __shared__ float s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  float* log_sum = log_sum_g;
+  int* zero_cnt = zero_cnt_g;
+  uint8_t* alive = alive_g;
+  const int n4 = (n + 3) & ~3;
+  if constexpr (kLds) {
+    log_sum = reinterpret_cast<float*>(s_dyn);
+    zero_cnt = s_dyn + n4;
+    alive = reinterpret_cast<uint8_t*>(s_dyn + 2 * n4);
+    for (int j = threadIdx.x; j < n; j += NT) { log_sum[j] = log_sum_g[j]; zero_cnt[j] = zero_cnt_g[j]; }
+  }
+  for (int j = threadIdx.x; j < n; j += NT) alive[j] = 1;
+  __syncthreads();
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = 0x7fffffff;               // argmin of the negated crowding degree
+    for (int j = threadIdx.x; j < n; j += NT)
+      if (alive[j]) {
+        const float f = zero_cnt[j] > 0 ? -1.0f : expf(log_sum[j]) - 1.0f;
+        if (f < v || (f == v && j < idx)) { v = f; idx = j; }
+      }
+    const ArgMin m = block_argmin(v, idx, s_v, s_i);
+    if (m.i == 0x7fffffff) break;
+    const float* row = logs + (int64_t)m.i * n;
+    for (int j = threadIdx.x; j < n; j += NT) {
+      const float d = row[j];
+      if (d != d) zero_cnt[j] -= 1; else log_sum[j] -= d;
+    }
+    if (threadIdx.x == 0) alive[m.i] = 0;
+    __syncthreads();
+  }
+  if constexpr (kLds) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += NT) alive_g[j] = alive[j];
   }
 }
 
@@ -272,7 +347,37 @@ __global__ __launch_bounds__(NT) void niche_fill_kernel(const int64_t* __restric
 
 EVOX_API int evox_hip_ibea_remove(float* fit, const float* I, const float* C, float kappa, int n, int n_remove,
                                   uint8_t* alive, void* stream) {
-  ibea_remove_kernel<<<1, NT, 0, (hipStream_t)stream>>>(fit, I, C, kappa, n, n_remove, alive);
+  if (n <= 0) return 0;
+  const size_t lds = (size_t)((n + 3) & ~3) * 5;
+  if (lds <= 150 * 1024) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)ibea_remove_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    ibea_remove_kernel<true><<<1, NT, lds, (hipStream_t)stream>>>(fit, I, C, kappa, n, n_remove, alive);
+  } else {
+    ibea_remove_kernel<false><<<1, NT, 0, (hipStream_t)stream>>>(fit, I, C, kappa, n, n_remove, alive);
+  }
+  return last_launch_status();
+}
+
+// logs: (n, n), NaN where the factor is zero; log_sum / zero_cnt: column sums of the finite entries / counts
+// of the NaN entries (scratch, modified); alive: out (n).
+EVOX_API int evox_hip_crowd_remove(const float* logs, int n, int n_remove, float* log_sum, int* zero_cnt, uint8_t* alive,
+                                   void* stream) {
+  if (n <= 0) return 0;
+  const size_t lds = (size_t)((n + 3) & ~3) * 9;
+  if (lds <= 150 * 1024) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)crowd_remove_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    crowd_remove_kernel<true><<<1, NT, lds, (hipStream_t)stream>>>(logs, n, n_remove, log_sum, zero_cnt, alive);
+  } else {
+    crowd_remove_kernel<false><<<1, NT, 0, (hipStream_t)stream>>>(logs, n, n_remove, log_sum, zero_cnt, alive);
+  }
   return last_launch_status();
 }
 

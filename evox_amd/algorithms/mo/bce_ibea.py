@@ -20,7 +20,7 @@ from ...operators import crossover, selection
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...ops import moselect as _sel
 from .common import MOAlgorithm
-from .indicator import ibea_fitness
+from .indicator import ibea_fitness_only, ibea_survivors
 
 
 def _third_nearest(dist):
@@ -45,7 +45,7 @@ def pc_selection(pc, pc_obj, n):
     """Keep the non-dominated set; when it exceeds ``n`` repeatedly drop the most crowded
     member (largest ``1 - Π_j min(d_ij / r, 1)``).  The crowding products are maintained
     incrementally (log-sum plus a zero counter), O(N) per removal."""
-    rank = non_dominated_sort(pc_obj)
+    rank = non_dominated_sort(pc_obj, until=1)             # only membership of the first front matters
     nd = rank == 0
     idx = torch.nonzero(nd)[:, 0]
     n_nd = int(idx.shape[0])
@@ -56,26 +56,14 @@ def pc_selection(pc, pc_obj, n):
         kth, d = _third_nearest(torch.cdist(norm, norm))
         r = kth.sum() / n_nd
         big_r = (d / r).clamp_max(1.0)
-        zero = big_r <= 0
-        logs = torch.where(zero, torch.zeros_like(big_r), torch.log(big_r.clamp_min(1e-38)))
-        log_sum, zero_cnt = logs.sum(0), zero.sum(0)
-        alive = torch.ones(n_nd, dtype=torch.bool, device=obj.device)
-        for _ in range(n_nd - n):
-            crowd = torch.where(zero_cnt > 0, torch.ones_like(log_sum), 1 - torch.exp(log_sum))
-            crowd = torch.where(alive, crowd, torch.full_like(crowd, -1.0))
-            x = torch.argmax(crowd)
-            alive[x] = False
-            log_sum = log_sum - logs[x]
-            zero_cnt = zero_cnt - zero[x].to(zero_cnt.dtype)
-        idx = idx[alive]
+        idx = idx[_sel.crowd_remove(big_r, n_nd - n)]
     else:
         idx = torch.cat([idx, idx[:1].expand(n - n_nd)])
     return pc[idx], pc_obj[idx], n_nd
 
 
 def environmental_selection(pop, obj, n, kappa):
-    fit, I, C = ibea_fitness(obj, kappa)
-    alive = _sel.ibea_remove(fit, I, C, kappa, obj.shape[0] - n)
+    alive = ibea_survivors(obj, kappa, n)
     idx = torch.argsort((~alive).to(torch.int8), stable=True)[:n]
     return pop[idx], obj[idx]
 
@@ -118,7 +106,7 @@ class BCEIBEA(MOAlgorithm):
 
     def _ask_even(self, state):
         key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
-        fit = -ibea_fitness(state.npc_obj, self.kappa)[0]
+        fit = -ibea_fitness_only(state.npc_obj, self.kappa)
         parents, _ = self.selection(k_sel, state.npc, fit)
         nxt = self._vary(k_x, k_mut, parents)
         return nxt, state.replace(new_npc=nxt, next_generation=nxt, key=key)

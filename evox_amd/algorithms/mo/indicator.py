@@ -24,13 +24,36 @@ from ...utils.common import cal_max, dominate_relation
 from .common import MOAlgorithm
 
 
-def ibea_fitness(pop_obj, kappa):
+def _normalised(pop_obj):
     lo, hi = pop_obj.min(), pop_obj.max()
-    obj = (pop_obj - lo) / (hi - lo)
+    return (pop_obj - lo) / (hi - lo)
+
+
+def ibea_fitness(pop_obj, kappa):
+    """``(fitness, indicator matrix, C)`` with the dense n × n ε-indicator matrix."""
+    obj = _normalised(pop_obj)
     I = cal_max(obj, obj)
     C = I.abs().amax(0)
     fit = (-torch.exp(-I / C[None, :] / kappa)).sum(0) + 1
     return fit, I, C
+
+
+def ibea_fitness_only(pop_obj, kappa):
+    """The fitness alone; on a GPU without forming the indicator matrix."""
+    if _sel.ibea_streaming_supported(pop_obj):
+        return _sel.ibea_fitness(_normalised(pop_obj), kappa)[0]
+    return ibea_fitness(pop_obj, kappa)[0]
+
+
+def ibea_survivors(pop_obj, kappa, n_keep):
+    """Boolean mask of the ``n_keep`` members IBEA's environmental selection retains."""
+    n = pop_obj.shape[0]
+    if _sel.ibea_streaming_supported(pop_obj) and _sel.ibea_remove_streaming_fits(n, pop_obj.shape[1]):
+        obj = _normalised(pop_obj)
+        fit, C = _sel.ibea_fitness(obj, kappa)
+        return _sel.ibea_remove_streaming(obj, fit, C, kappa, n - n_keep)
+    fit, I, C = ibea_fitness(pop_obj, kappa)
+    return _sel.ibea_remove(fit, I, C, kappa, n - n_keep)
 
 
 class IBEA(MOAlgorithm):
@@ -43,15 +66,14 @@ class IBEA(MOAlgorithm):
 
     def ask(self, state):
         key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
-        fit = ibea_fitness(state.fitness, self.kappa)[0]
+        fit = ibea_fitness_only(state.fitness, self.kappa)
         parents, _ = self.selection(k_sel, state.population, -fit)
         nxt = self._vary(k_x, k_mut, parents)
         return nxt, state.replace(next_generation=nxt, key=key)
 
     def tell(self, state, fitness):
         pop, obj = self._merged(state, fitness)
-        fit, I, C = ibea_fitness(obj, self.kappa)
-        alive = _sel.ibea_remove(fit, I, C, self.kappa, obj.shape[0] - self.pop_size)
+        alive = ibea_survivors(obj, self.kappa, self.pop_size)
         idx = torch.argsort((~alive).to(torch.int8), stable=True)[: self.pop_size]
         return state.replace(population=pop[idx], fitness=obj[idx])
 

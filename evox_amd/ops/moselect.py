@@ -25,6 +25,10 @@ _native.register_hip_api({
     "evox_hip_spea2_truncate": (I, [P, I, I, I, P, P, P, P]),
     "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
+    "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
+    "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
+    "evox_hip_ibea_remove_obj_lds": (I64, [I, I]),
+    "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
 })
 
 
@@ -54,6 +58,71 @@ def ibea_remove(fitness, I_mat, C, kappa, n_remove: int) -> torch.Tensor:
     else:
         _native.cpu().evox_cpu_ibea_remove(fit.data_ptr(), I_mat.data_ptr(), C.data_ptr(), float(kappa), n,
                                            int(n_remove), alive.data_ptr())
+    return alive.bool()
+
+
+def ibea_streaming_supported(obj) -> bool:
+    return on_gpu(obj) and obj.dim() == 2 and obj.dtype == torch.float32 and 2 <= obj.shape[1] <= 8
+
+
+def ibea_fitness(obj, kappa):
+    """``(F, C)`` of IBEA's additive ε-indicator fitness for normalised objectives ``obj`` (n, m):
+    ``C_j = max_i |I(i, j)|``, ``F_j = 1 − Σ_i exp(−I(i, j) / C_j / κ)`` with ``I(i, j) = max_k (obj_i − obj_j)_k``,
+    in two streaming passes without the n × n indicator matrix."""
+    n, m = obj.shape
+    obj = obj.contiguous()
+    C = torch.empty(n, dtype=torch.float32, device=obj.device)
+    fit = torch.empty(n, dtype=torch.float32, device=obj.device)
+    check(hip().evox_hip_ibea_fitness(obj.data_ptr(), n, m, float(kappa), C.data_ptr(), fit.data_ptr(), stream_of(obj)),
+          "ibea_fitness")
+    return fit, C
+
+
+def ibea_remove_streaming_fits(n: int, m: int) -> bool:
+    return int(hip().evox_hip_ibea_remove_obj_lds(int(n), int(m))) <= 150 * 1024
+
+
+def ibea_remove_streaming(obj, fit, C, kappa, n_remove: int) -> torch.Tensor:
+    """``ibea_remove`` with the indicator rows recomputed from the (normalised) objectives held in LDS."""
+    n, m = obj.shape
+    obj = obj.contiguous()
+    alive = torch.empty(n, dtype=torch.uint8, device=obj.device)
+    check(hip().evox_hip_ibea_remove_obj(obj.data_ptr(), n, m, C.data_ptr(), float(kappa), fit.data_ptr(), int(n_remove),
+                                         alive.data_ptr(), stream_of(obj)), "ibea_remove_obj")
+    return alive.bool()
+
+
+def crowd_remove_reference(big_r, n_remove: int) -> torch.Tensor:
+    """Survivor mask after ``n_remove`` times dropping the member j with the largest crowding degree
+    ``1 − Π_{i alive} big_r[i, j]`` (``big_r`` ∈ [0, 1], symmetric, diagonal 1); the products are kept as
+    log-sums plus zero counts and updated in O(n) per removal."""
+    zero = big_r <= 0
+    logs = torch.where(zero, torch.zeros_like(big_r), torch.log(big_r.clamp_min(1e-38)))
+    log_sum, zero_cnt = logs.sum(0), zero.sum(0)
+    alive = torch.ones(big_r.shape[0], dtype=torch.bool, device=big_r.device)
+    for _ in range(int(n_remove)):
+        crowd = torch.where(zero_cnt > 0, torch.ones_like(log_sum), 1 - torch.exp(log_sum))
+        crowd = torch.where(alive, crowd, torch.full_like(crowd, -1.0))
+        x = torch.argmax(crowd)
+        alive[x] = False
+        log_sum = log_sum - logs[x]
+        zero_cnt = zero_cnt - zero[x].to(zero_cnt.dtype)
+    return alive
+
+
+def crowd_remove(big_r, n_remove: int) -> torch.Tensor:
+    """``crowd_remove_reference`` as one persistent launch on the GPU."""
+    if not (on_gpu(big_r) and big_r.dtype == torch.float32) or int(n_remove) <= 0:
+        return crowd_remove_reference(big_r, n_remove)
+    n = big_r.shape[0]
+    zero = big_r <= 0
+    logs = torch.log(big_r.clamp_min(1e-38))
+    log_sum = torch.where(zero, torch.zeros_like(logs), logs).sum(0)
+    zero_cnt = zero.sum(0).to(torch.int32)
+    logs = torch.where(zero, torch.full_like(logs, float("nan")), logs).contiguous()      # NaN marks a zero factor
+    alive = torch.empty(n, dtype=torch.uint8, device=big_r.device)
+    check(hip().evox_hip_crowd_remove(logs.data_ptr(), n, int(n_remove), log_sum.data_ptr(), zero_cnt.data_ptr(),
+                                      alive.data_ptr(), stream_of(logs)), "crowd_remove")
     return alive.bool()
 
 

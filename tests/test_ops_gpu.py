@@ -736,3 +736,59 @@ def test_spea2_fitness_kernels_match_dense_formulation(n, m):
     want = spea2_fitness_reference(obj.double()).float()
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), (got - want).abs().max()
     assert torch.equal(got < 1, want < 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [200, 203, 1500])
+def test_removal_loop_kernels_other_sizes(n):
+    """Rows that are / are not 16-byte aligned, and a SPEA2 state larger than one 1024-thread pass."""
+    from evox_amd.algorithms.mo.indicator import ibea_fitness
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n)
+    obj = torch.rand(n, 3, generator=g).cuda()
+    fit, I, C = ibea_fitness(obj, 0.05)
+    k = n // 2
+    assert torch.equal(moselect.ibea_remove(fit, I, C, 0.05, k), moselect.ibea_remove_reference(fit, I, C, 0.05, k))
+    mask = torch.rand(n, generator=g).cuda() < 0.9
+    k = int(mask.sum()) // 2
+    assert torch.equal(moselect.spea2_truncate(obj, mask, k), moselect.spea2_truncate_reference(obj, mask, k))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,n_remove", [(50, 20), (301, 150), (1200, 500)])
+def test_crowd_remove_kernel_matches_reference(n, n_remove):
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(n, 3, generator=g)
+    d = torch.cdist(pts, pts)
+    d.fill_diagonal_(float("inf"))
+    r = torch.sort(d, dim=1).values[:, 2].mean()
+    big_r = (d / r).clamp_max(1.0)
+    big_r[3, 7] = big_r[7, 3] = 0.0                         # a coincident pair: zero factors
+    want = moselect.crowd_remove_reference(big_r.cuda(), n_remove)
+    got = moselect.crowd_remove(big_r.cuda(), n_remove)
+    assert int(got.sum()) == n - n_remove
+    assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(130, 2), (1000, 3), (4000, 3), (777, 6)])
+def test_ibea_streaming_matches_dense(n, m):
+    from evox_amd.algorithms.mo import indicator
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n + m)
+    obj = torch.rand(n, m, generator=g).cuda()
+    fit_d, I, C_d = indicator.ibea_fitness(obj, 0.05)
+    fit_s, C_s = moselect.ibea_fitness(indicator._normalised(obj), 0.05)
+    assert torch.allclose(C_s, C_d, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(fit_s, fit_d, rtol=1e-4, atol=1e-4)
+    # same inputs to both removal loops: the survivors agree exactly
+    want = moselect.ibea_remove(fit_s, I, C_s, 0.05, n // 2)
+    got = moselect.ibea_remove_streaming(indicator._normalised(obj), fit_s, C_s, 0.05, n // 2)
+    assert int(got.sum()) == n - n // 2
+    assert (got != want).sum() <= max(2, n // 200), int((got != want).sum())
+    keep = indicator.ibea_survivors(obj, 0.05, n // 2)
+    assert int(keep.sum()) == n // 2
