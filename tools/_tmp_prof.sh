@@ -1,11 +1,7 @@
-set -e
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -k "ibea or IBEA or removal_loop or sequential_selection" 2>&1 | tail -5
-for a in IBEA; do
-  bash tools/gpu_prof2.sh mo_$a tools/cpu_profile_mo.py $a 2000
-  grep pop= gpurun_out/prof_mo_$a/stdout.log
-  python3 - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/prof_mo_IBEA/kernel_stats_top.csv')))
-for r in rows[:4]: print(r['Name'][:70], r['Calls'], r['AverageNs'], r['Percentage'])
-PY
-done
+bash tools/gpu_ci.sh "" || exit $?
+timeout -k 10 400 python tools/mo_survey.py 2000 > gpurun_out/mo_survey_2000.jsonl 2> gpurun_out/mo_survey_2000.err || exit $?
+python3 -c "
+import json
+for l in open('gpurun_out/mo_survey_2000.jsonl'):
+    d=json.loads(l); print(d['algorithm'], round(d['ms_per_generation'],2), round(d['igd_after_65_generations'],4))
+"
