@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
@@ -36,9 +38,9 @@ def exploration(pc_obj, npc_obj, n_nd, n):
     f_min, f_max = pc_obj.amin(0), pc_obj.amax(0)
     span = (f_max - f_min).clamp_min(1e-12)
     a, b = (pc_obj - f_min) / span, (npc_obj - f_min) / span
-    r0 = _third_nearest(torch.cdist(a, a))[0].mean()
+    r0 = _third_nearest(_cdist(a, a))[0].mean()
     r = n_nd / n * r0
-    return (torch.cdist(a, b) <= r).sum(1) <= 1
+    return (_cdist(a, b) <= r).sum(1) <= 1
 
 
 def pc_selection(pc, pc_obj, n):
@@ -53,7 +55,7 @@ def pc_selection(pc, pc_obj, n):
         obj = pc_obj[idx]
         f_min, f_max = obj.amin(0), obj.amax(0)
         norm = (obj - f_min) / (f_max - f_min).clamp_min(1e-12)
-        kth, d = _third_nearest(torch.cdist(norm, norm))
+        kth, d = _third_nearest(_cdist(norm, norm))
         r = kth.sum() / n_nd
         big_r = (d / r).clamp_max(1.0)
         idx = idx[_sel.crowd_remove(big_r, n_nd - n)]

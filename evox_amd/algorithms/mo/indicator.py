@@ -11,6 +11,8 @@ import math
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ... import _native
 from ...core import random as rnd
 from ...core.state import State
@@ -91,7 +93,7 @@ def spea2_fitness_reference(obj):
     dom = dominate_relation(obj, obj)
     strength = dom.sum(1).to(torch.float32)
     raw = (dom.to(torch.float32) * strength[:, None]).sum(0)
-    dis = torch.cdist(obj, obj)
+    dis = _cdist(obj, obj)
     dis = dis.masked_fill(torch.eye(n, dtype=torch.bool, device=obj.device), float("inf"))
     k = int(math.floor(math.sqrt(6)))
     kth = torch.topk(dis, k, dim=1, largest=False).values[:, k - 1]

@@ -4,6 +4,8 @@ from __future__ import annotations
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import selection
@@ -15,7 +17,7 @@ from .common import MOAlgorithm
 
 def calc_DW(fit, k):
     """Weighted distance to the k nearest neighbours (KnEA's density estimate)."""
-    dis = torch.cdist(fit, fit)
+    dis = _cdist(fit, fit)
     nb = torch.sort(dis, dim=1).values[:, 1:k + 1]
     avg = nb.sum(1) / k
     r = 1 / (nb - avg[:, None]).abs().clamp_min(1e-12)
@@ -119,7 +121,7 @@ def bige_estimate(fit, mask):
     normed = (fit - f_min) / (f_max - f_min).clamp_min(1e-6)
     normed = torch.where(mask[:, None], normed, torch.full_like(normed, float(m)))
     pr = normed.sum(1)
-    dis = torch.cdist(normed, normed)
+    dis = _cdist(normed, normed)
     ge = (pr[:, None] >= pr[None, :]).to(torch.float32)
     gt = (pr[:, None] > pr[None, :]).to(torch.float32)
     sh = ((dis < r) * 0.5 * ((1 + ge + gt) * (1 - dis / r))) ** 2

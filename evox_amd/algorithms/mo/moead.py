@@ -12,6 +12,8 @@ import math
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
@@ -47,7 +49,7 @@ class MOEAD(MOAlgorithm):
 
     def setup(self, key):
         f = self._base_fields(key)
-        nb = torch.argsort(torch.cdist(self._w, self._w), dim=1, stable=True)[:, : self.n_neighbor]
+        nb = torch.argsort(_cdist(self._w, self._w), dim=1, stable=True)[:, : self.n_neighbor]
         return State(weight_vector=self._w, neighbors=nb, z=torch.zeros(self.n_objs, device=self.device), **f)
 
     def init_tell(self, state, fitness):
@@ -105,7 +107,7 @@ class MOEADDRA(MOAlgorithm):
         key, k_w = rnd.split(f["key"])
         f["key"] = key
         w = self.sample(k_w)
-        B = torch.argsort(torch.cdist(w, w), dim=1, stable=True)[:, : self.T]
+        B = torch.argsort(_cdist(w, w), dim=1, stable=True)[:, : self.T]
         n, dev = self.pop_size, self.device
         return State(weight_vector=w, B=B, Z=torch.zeros(self.n_objs, device=dev), pi=torch.ones(n, device=dev),
                      old_obj=torch.zeros(n, device=dev), choosed_p=torch.zeros((n, self.T), dtype=torch.int64, device=dev),

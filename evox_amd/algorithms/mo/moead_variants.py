@@ -6,6 +6,8 @@ import math
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
@@ -37,7 +39,7 @@ class EAGMOEAD(MOAlgorithm):
         key, k_w = rnd.split(f["key"])
         f["key"] = key
         w = self.sample(k_w)
-        B = torch.argsort(torch.cdist(w, w), dim=1, stable=True)[:, : self.T]
+        B = torch.argsort(_cdist(w, w), dim=1, stable=True)[:, : self.T]
         n, dev = self.pop_size, self.device
         return State(inner_pop=f["population"], inner_obj=f["fitness"], weight_vector=w, B=B,
                      s=torch.zeros((n, self.LGs), device=dev), offspring_loc=torch.zeros(n, dtype=torch.int64, device=dev),

@@ -9,7 +9,9 @@ from ....utils.common import min_by  # noqa: F401  (re-exported)
 
 def get_distance_matrix(location: torch.Tensor) -> torch.Tensor:
     """Euclidean distance between every pair of rows."""
-    return torch.cdist(location, location, compute_mode="donot_use_mm_for_euclid_dist")
+    from ....ops.distance import cdist
+
+    return cdist(location, location)
 
 
 def row_argsort(x: torch.Tensor) -> torch.Tensor:

@@ -8,7 +8,9 @@ from ..core import random as rnd
 
 
 def _pairwise(a, b):
-    return torch.cdist(a.float(), b.float(), compute_mode="donot_use_mm_for_euclid_dist")
+    from ..ops.distance import cdist
+
+    return cdist(a.float(), b.float())
 
 
 def _pairwise_plus(a, b):

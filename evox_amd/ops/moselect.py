@@ -13,6 +13,7 @@ import torch
 
 from .. import _native
 from ._util import check, hip, on_gpu, stream_of
+from .distance import cdist as _cdist
 
 P, I, I64, F = _native.P, _native.I, _native.I64, _native.F
 _native.register_cpu_api({
@@ -128,7 +129,7 @@ def crowd_remove(big_r, n_remove: int) -> torch.Tensor:
 
 def _masked_distances(obj, mask):
     n = obj.shape[0]
-    dis = torch.cdist(obj.float(), obj.float())
+    dis = _cdist(obj.float(), obj.float())
     pair = mask[:, None] & mask[None, :] & ~torch.eye(n, dtype=torch.bool, device=obj.device)
     return torch.where(pair, dis, torch.full_like(dis, float("inf"))).contiguous()
 
@@ -176,7 +177,7 @@ def spea2_truncate(obj, mask, n_remove: int) -> torch.Tensor:
         nv = sub.shape[0]
         ld = (nv + 3) // 4 * 4
         dis = torch.full((nv, ld), float("inf"), dtype=torch.float32, device=obj.device)
-        dis[:, :nv] = torch.cdist(sub, sub)
+        dis[:, :nv] = _cdist(sub, sub)
         dis.diagonal().fill_(float("inf"))
         rowmin, nn = dis.min(1)                           # full-chip reduction; the kernel keeps it current
         nn = nn.to(torch.int32)

@@ -14,6 +14,8 @@ import math
 
 import torch
 
+from ...ops.distance import cdist as _cdist
+
 from ...core.problem import Problem
 from ...core.state import State
 from ...operators.sampling import UniformSampling
@@ -275,7 +277,7 @@ class MaF8(MaF):
         self.points = regular_polygon(self.m)
 
     def evaluate(self, state, X):
-        return torch.cdist(X[:, :2].to(torch.float32), self.points.to(X.device)), state
+        return _cdist(X[:, :2].to(torch.float32), self.points.to(X.device)), state
 
     def _grid_inside(self):
         side = int(math.ceil(math.sqrt(self.ref_num * self.m)))
@@ -285,7 +287,7 @@ class MaF8(MaF):
         return pts[point_in_polygon(self.points, pts)]
 
     def pf(self):
-        return torch.cdist(self._grid_inside(), self.points)
+        return _cdist(self._grid_inside(), self.points)
 
 
 class MaF9(MaF8):

@@ -46,15 +46,21 @@ def chebyshev_dist(x, y):
 
 
 def pairwise_euclidean_dist(x, y):
-    return torch.cdist(x, y, p=2.0, compute_mode="donot_use_mm_for_euclid_dist")
+    from ..ops.distance import cdist
+
+    return cdist(x, y)
 
 
 def pairwise_manhattan_dist(x, y):
-    return torch.cdist(x, y, p=1.0)
+    from ..ops.distance import cdist
+
+    return cdist(x, y, p=1.0)
 
 
 def pairwise_chebyshev_dist(x, y):
-    return torch.cdist(x, y, p=float("inf"))
+    from ..ops.distance import cdist
+
+    return cdist(x, y, p=float("inf"))
 
 
 def pair_max(a, b):

@@ -792,3 +792,22 @@ def test_ibea_streaming_matches_dense(n, m):
     assert (got != want).sum() <= max(2, n // 200), int((got != want).sum())
     keep = indicator.ibea_survivors(obj, 0.05, n // 2)
     assert int(keep.sum()) == n // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,r,m", [(1, 1, 3), (33, 257, 2), (500, 4000, 3), (2926, 10000, 3), (100, 300, 8), (70, 513, 9),
+                                   (257, 1000, 100)])
+def test_cdist_kernel_is_exact_at_every_size(p, r, m):
+    from evox_amd.ops.distance import cdist
+
+    g = torch.Generator().manual_seed(p + r + m)
+    a, b = torch.rand(p, m, generator=g), torch.rand(r, m, generator=g)
+    b[0] = a[0] + 1e-5                                     # a near-coincident pair: the GEMM form loses it
+    ref = torch.cdist(a.double(), b.double())
+    got = cdist(a.cuda(), b.cuda()).cpu().double()
+    assert (got - ref).abs().max() < 5e-6 * max(1.0, m / 8)      # fp32 accumulation over m terms
+    assert abs(float(got[0, 0]) - float(ref[0, 0])) < 1e-7
+    assert torch.allclose(cdist(a.cuda(), b.cuda(), squared=True).cpu().double(), ref.square(), atol=1e-5 * max(1.0, m / 8))
+    for q in (1.0, float("inf")):
+        want = torch.cdist(a.double(), b.double(), p=q)
+        assert (cdist(a.cuda(), b.cuda(), p=q).cpu().double() - want).abs().max() < 2e-5 * max(1.0, m / 8)
