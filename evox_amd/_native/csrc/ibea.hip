@@ -3,9 +3,9 @@
 // I(i, j) = max_k (f_i[k] − f_j[k]) is a three-flop function of two short vectors, so neither the
 // fitness  F_j = 1 − Σ_i exp(−I(i, j) / (C_j κ)),  C_j = max_i |I(i, j)|,  nor the removal loop needs the
 // n × n indicator matrix (nor the n × n × m difference tensor behind it): two streaming passes compute
-// C and F, and the removal loop keeps objectives, C and F of the whole merged population in LDS, so one
-// removal is an arg-min and one LDS-to-LDS update between workgroup barriers, with no global-memory
-// latency on its critical path.
+// C and F, and the removal loop keeps objectives, C and F of the whole merged population in the registers
+// of one workgroup, so one removal is an arg-min and one register update between workgroup barriers,
+// with no global-memory latency on its critical path.
 #include "hip_common.h"
 
 using namespace evox;
@@ -85,78 +85,30 @@ __device__ __forceinline__ ArgMin block_argmin(float v, int i, float* s_v, int* 
   return ArgMin{rv, ri};
 }
 
-// LDS: objectives [M][n4] | C [n4] | fitness [n4] | alive bytes [n4]
-template <int M>
-__global__ __launch_bounds__(NT) void ibea_remove_obj_kernel(const float* __restrict__ obj, int n, const float* __restrict__ C,
-                                                             float kappa, const float* __restrict__ fit_in, int n_remove,
-                                                             uint8_t* __restrict__ alive_out) {
-  extern __shared__ __attribute__((aligned(16))) float s_f[];
-  __shared__ float s_v[NT / 64];
-  __shared__ int s_i[NT / 64];
-  const int n4 = (n + 3) & ~3;
-  float* o = s_f;
-  float* c = s_f + M * n4;
-  float* fit = c + n4;
-  uint8_t* alive = reinterpret_cast<uint8_t*>(fit + n4);
-  for (int j = threadIdx.x; j < n; j += NT) {
-#pragma unroll
-    for (int k = 0; k < M; ++k) o[k * n4 + j] = obj[(int64_t)j * M + k];
-    c[j] = C[j]; fit[j] = fit_in[j]; alive[j] = 1;
-  }
-  __syncthreads();
-  for (int r = 0; r < n_remove; ++r) {
-    float v = INFINITY; int idx = 0x7fffffff;
-    for (int j = threadIdx.x; j < n; j += NT)
-      if (alive[j]) { const float f = fit[j]; if (f < v || (f == v && j < idx)) { v = f; idx = j; } }
-    const ArgMin m = block_argmin(v, idx, s_v, s_i);
-    if (m.i == 0x7fffffff) break;                       // uniform: nothing left
-    const int x = m.i;
-    const float s = 1.0f / (c[x] * kappa);
-    float ox[M];
-#pragma unroll
-    for (int k = 0; k < M; ++k) ox[k] = o[k * n4 + x];
-    for (int j = threadIdx.x; j < n; j += NT) {
-      float oj[M];
-#pragma unroll
-      for (int k = 0; k < M; ++k) oj[k] = o[k * n4 + j];
-      fit[j] += expf(-eps_ind<M>(ox, oj) * s);
-    }
-    if (threadIdx.x == 0) alive[x] = 0;
-    __syncthreads();
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < n; j += NT) alive_out[j] = alive[j];
-}
-
-// The same loop with every thread's share of the population (E members: fitness and objectives) held in
-// registers: LDS serves only the broadcast of the removed member's objectives and scale.  One workgroup
-// is bound by instruction issue of its single compute unit, so the loop body is kept to the E indicator
-// evaluations (hardware exp) and a running arg-min for the next round.
+// The same loop with every thread's share of the population (E members: fitness, scale and objectives)
+// held in registers; the thread that owns the removed member publishes its objectives and scale through
+// a few words of LDS.  One workgroup is bound by instruction issue of its single compute unit, so the
+// loop body is kept to the E indicator evaluations (hardware exp) and a running arg-min.
 template <int M, int E>
 __global__ __launch_bounds__(NT) void ibea_remove_reg_kernel(const float* __restrict__ obj, int n, const float* __restrict__ C,
                                                              float kappa, const float* __restrict__ fit_in, int n_remove,
                                                              uint8_t* __restrict__ alive_out) {
-  extern __shared__ __attribute__((aligned(16))) float s_f[];
   __shared__ float s_v[NT / 64];
   __shared__ int s_i[NT / 64];
-  const int n4 = (n + 3) & ~3;
-  float* o = s_f;
-  float* c = s_f + M * n4;
-  float f[E], oj[E][M];
+  __shared__ float s_x[M + 1];
+  float f[E], cj[E], oj[E][M];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = threadIdx.x + e * NT;
-    f[e] = INFINITY;
+    f[e] = INFINITY; cj[e] = 1.f;
 #pragma unroll
     for (int k = 0; k < M; ++k) oj[e][k] = 0.f;
     if (j < n) {
-      f[e] = fit_in[j];
+      f[e] = fit_in[j]; cj[e] = C[j];
 #pragma unroll
-      for (int k = 0; k < M; ++k) { oj[e][k] = obj[(int64_t)j * M + k]; o[k * n4 + j] = oj[e][k]; }
-      c[j] = C[j];
+      for (int k = 0; k < M; ++k) oj[e][k] = obj[(int64_t)j * M + k];
     }
   }
-  __syncthreads();
   for (int r = 0; r < n_remove; ++r) {
     float v = INFINITY; int idx = 0x7fffffff;
 #pragma unroll
@@ -165,15 +117,23 @@ __global__ __launch_bounds__(NT) void ibea_remove_reg_kernel(const float* __rest
     const ArgMin m = block_argmin(v, idx, s_v, s_i);
     if (m.i == 0x7fffffff) break;                       // uniform: nothing left
     const int x = m.i;
-    const float s = -1.0f / (c[x] * kappa);
+    if ((int)threadIdx.x == (x & (NT - 1))) {           // the owner of x
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (e == x / NT) {
+#pragma unroll
+          for (int k = 0; k < M; ++k) s_x[k] = oj[e][k];
+          s_x[M] = -1.0f / (cj[e] * kappa);
+          f[e] = INFINITY;
+        }
+    }
+    __syncthreads();
     float ox[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) ox[k] = o[k * n4 + x];
+    for (int k = 0; k < M; ++k) ox[k] = s_x[k];
+    const float s = s_x[M];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const float add = __expf(eps_ind<M>(ox, oj[e]) * s);
-      f[e] = (threadIdx.x + e * NT == x) ? INFINITY : f[e] + add;
-    }
+    for (int e = 0; e < E; ++e) f[e] += __expf(eps_ind<M>(ox, oj[e]) * s);      // +inf stays +inf
   }
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -193,30 +153,25 @@ int launch_fitness(const float* obj, int n, float kappa, float* C, float* fit, h
 template <int M, int E>
 int launch_remove_reg(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove, uint8_t* alive,
                       hipStream_t st) {
-  const size_t lds = (size_t)((n + 3) & ~3) * 4 * (M + 1);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)ibea_remove_reg_kernel<M, E>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  ibea_remove_reg_kernel<M, E><<<1, NT, lds, st>>>(obj, n, C, kappa, fit, n_remove, alive);
+  ibea_remove_reg_kernel<M, E><<<1, NT, 0, st>>>(obj, n, C, kappa, fit, n_remove, alive);
   return last_launch_status();
 }
+
+// members per thread that the register form is built for, given m (0: none — use the matrix form)
+constexpr int reg_capacity(int m) { return m <= 3 ? 20 : (m <= 4 ? 16 : 8); }
 
 template <int M>
 int launch_remove(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove, uint8_t* alive,
                   hipStream_t st) {
   if (n <= 4 * NT) return launch_remove_reg<M, 4>(obj, n, C, kappa, fit, n_remove, alive, st);
-  if (n <= 8 * NT && M <= 4) return launch_remove_reg<M, 8>(obj, n, C, kappa, fit, n_remove, alive, st);
-  const size_t lds = (size_t)((n + 3) & ~3) * (4 * (M + 2) + 1);
-  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)ibea_remove_obj_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
+  if (n <= 8 * NT) return launch_remove_reg<M, 8>(obj, n, C, kappa, fit, n_remove, alive, st);
+  if constexpr (M <= 4) {
+    if (n <= 16 * NT) return launch_remove_reg<M, 16>(obj, n, C, kappa, fit, n_remove, alive, st);
   }
-  ibea_remove_obj_kernel<M><<<1, NT, lds, st>>>(obj, n, C, kappa, fit, n_remove, alive);
-  return last_launch_status();
+  if constexpr (M <= 3) {
+    if (n <= 20 * NT) return launch_remove_reg<M, 20>(obj, n, C, kappa, fit, n_remove, alive, st);
+  }
+  return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -239,8 +194,9 @@ EVOX_API int evox_hip_ibea_fitness(const float* obj, int n, int m, float kappa, 
   EVOX_IBEA_DISPATCH(launch_fitness, obj, n, kappa, C, fit, (hipStream_t)stream)
 }
 
-// Bytes of LDS the removal loop needs for (n, m); the caller falls back to the matrix form above 150 KB.
-EVOX_API int64_t evox_hip_ibea_remove_obj_lds(int n, int m) { return (int64_t)((n + 3) & ~3) * (4 * (m + 2) + 1); }
+// Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix
+// form beyond it).
+EVOX_API int64_t evox_hip_ibea_remove_obj_max(int m) { return m >= 2 && m <= 8 ? (int64_t)reg_capacity(m) * NT : 0; }
 
 EVOX_API int evox_hip_ibea_remove_obj(const float* obj, int n, int m, const float* C, float kappa, const float* fit,
                                       int n_remove, uint8_t* alive, void* stream) {

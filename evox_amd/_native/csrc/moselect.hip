@@ -199,22 +199,24 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(const float* __restr
 }
 
 // Stochastic bubble sort.  Inside one sweep every compare-swap depends on the previous one, but sweep
-// s+1 may work on position j as soon as sweep s has left position j+1: the 64 lanes of one wave run 64
-// consecutive sweeps as a systolic pipeline, lane l trailing lane l−1 by two positions (lane l at time
-// t handles position t − 2l).  Each lane carries the element it is bubbling; in one time step the lanes
-// touch distinct entries of the permutation (LDS), and the LDS operations of a wave complete in order,
-// so the result is exactly that of the sequential sort in n/128 passes of n + 126 steps instead of
-// n/2 passes of n steps by a single lane.
-__global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
-                                                                const float* __restrict__ u, float pc, int n,
-                                                                int64_t* __restrict__ rank, int keys_in_lds) {
+// s+1 may work on position j as soon as sweep s has left position j+1: the threads of the workgroup run
+// consecutive sweeps as a systolic pipeline, thread g trailing thread g−1 by two positions (thread g at
+// time t handles position t − 2g).  Each thread carries the element it is bubbling; in one time step the
+// threads touch distinct entries of the permutation (LDS) and a thread reads what its predecessor wrote
+// one step earlier, so a workgroup barrier separates the steps (a wave barrier when one wave suffices).
+// The result is exactly that of the sequential sort, in ⌈sweeps / L⌉ passes of n − 1 + 2(L − 1) steps for
+// L threads instead of n/2 passes of n steps by a single lane.
+template <int L>
+__global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
+                                                               const float* __restrict__ u, float pc, int n,
+                                                               int64_t* __restrict__ rank, int keys_in_lds) {
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
   volatile int* rk = s_mem;                              // the permutation, n entries
   float* l1 = reinterpret_cast<float*>(s_mem + n);       // optional copies of I1, I2, u
   float* l2 = l1 + n;
   float* lu = l2 + n;
   const int lane = threadIdx.x;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += L) {
     rk[i] = i;
     if (keys_in_lds) { l1[i] = I1[i]; l2[i] = I2[i]; lu[i] = u[i]; }
   }
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __r
   const float* K2 = keys_in_lds ? l2 : I2;
   const float* U = keys_in_lds ? lu : u;
   const int sweeps = (n + 1) / 2;
-  const int steps = (n - 1) + 2 * 63;
-  for (int s0 = 0; s0 < sweeps; s0 += 64) {
+  const int steps = (n - 1) + 2 * (L - 1);
+  for (int s0 = 0; s0 < sweeps; s0 += L) {
     const bool mine = s0 + lane < sweeps;
     int a = 0;
     float a1 = 0.f, a2 = 0.f;
@@ -243,11 +245,11 @@ __global__ __launch_bounds__(64) void stochastic_ranking_kernel(const float* __r
         }
         if (j == n - 2) rk[n - 1] = a;
       }
-      __builtin_amdgcn_wave_barrier();
+      if (L == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     }
   }
   __syncthreads();
-  for (int i = lane; i < n; i += 64) rank[i] = rk[i];
+  for (int i = lane; i < n; i += L) rank[i] = rk[i];
 }
 
 // sequential form for permutations that do not fit the LDS (n > 40 000)
@@ -401,6 +403,18 @@ EVOX_API int evox_hip_spea2_truncate(const float* dis, int n, int ld, int n_remo
   return last_launch_status();
 }
 
+template <int L>
+int launch_ranking(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
+                   int keys_in_lds, hipStream_t st) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  stochastic_ranking_kernel<L><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank, keys_in_lds);
+  return last_launch_status();
+}
+
 EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
                                          int64_t* rank, int* scratch, void* stream) {
   if (n <= 0) return 0;
@@ -409,13 +423,12 @@ EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const
     const size_t with_keys = perm * 4;
     const int keys_in_lds = with_keys <= 160 * 1024;
     const size_t lds = keys_in_lds ? with_keys : perm;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds);
-      if (e != hipSuccess) return (int)e;
-    }
-    stochastic_ranking_kernel<<<1, 64, lds, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, keys_in_lds);
-    return last_launch_status();
+    const int sweeps = (n + 1) / 2;
+    hipStream_t st = (hipStream_t)stream;
+    // as many pipeline stages as there are sweeps, up to the 1024 threads of a workgroup
+    if (sweeps <= 64) return launch_ranking<64>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
+    if (sweeps <= 256) return launch_ranking<256>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
+    return launch_ranking<1024>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
   }
   if (scratch == nullptr) return (int)hipErrorInvalidValue;
   stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);

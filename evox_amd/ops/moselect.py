@@ -28,7 +28,7 @@ _native.register_hip_api({
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
-    "evox_hip_ibea_remove_obj_lds": (I64, [I, I]),
+    "evox_hip_ibea_remove_obj_max": (I64, [I]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
 })
 
@@ -80,11 +80,11 @@ def ibea_fitness(obj, kappa):
 
 
 def ibea_remove_streaming_fits(n: int, m: int) -> bool:
-    return int(hip().evox_hip_ibea_remove_obj_lds(int(n), int(m))) <= 150 * 1024
+    return int(n) <= int(hip().evox_hip_ibea_remove_obj_max(int(m)))
 
 
 def ibea_remove_streaming(obj, fit, C, kappa, n_remove: int) -> torch.Tensor:
-    """``ibea_remove`` with the indicator rows recomputed from the (normalised) objectives held in LDS."""
+    """``ibea_remove`` with the indicator rows recomputed from the (normalised) objectives held on chip."""
     n, m = obj.shape
     obj = obj.contiguous()
     alive = torch.empty(n, dtype=torch.uint8, device=obj.device)

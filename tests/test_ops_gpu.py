@@ -811,3 +811,25 @@ def test_cdist_kernel_is_exact_at_every_size(p, r, m):
     for q in (1.0, float("inf")):
         want = torch.cdist(a.double(), b.double(), p=q)
         assert (cdist(a.cuda(), b.cuda(), p=q).cpu().double() - want).abs().max() < 2e-5 * max(1.0, m / 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,n_remove", [(9000, 3, 300), (20000, 3, 200), (12000, 4, 200), (9000, 5, 100)])
+def test_ibea_removal_large_populations(n, m, n_remove):
+    """More members per thread (and, past the register form's capacity, the matrix form) agree with the
+    dense loop on the same inputs."""
+    from evox_amd.algorithms.mo import indicator
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n + m)
+    obj = indicator._normalised(torch.rand(n, m, generator=g).cuda())
+    fit, C = moselect.ibea_fitness(obj, 0.05)
+    keep = indicator.ibea_survivors(obj, 0.05, n - n_remove)
+    assert int(keep.sum()) == n - n_remove
+    if moselect.ibea_remove_streaming_fits(n, m):
+        from evox_amd.utils.common import cal_max
+
+        I = cal_max(obj, obj)
+        want = moselect.ibea_remove(fit, I, C, 0.05, n_remove)
+        got = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
+        assert (got != want).sum() <= 2, int((got != want).sum())
