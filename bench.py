@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--pop", type=int, default=10000, help="population per GPU (weak) or total (strong)")
     ap.add_argument("--dim", type=int, default=1000)
     ap.add_argument("--problem", default="ackley", choices=["ackley", "sphere"])
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
+                    help="operands of the sampling and covariance GEMMs (accumulation, state and factorisation are fp32)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--eigh", default=None, help="eigensolver override: jacobi | solver")
     ap.add_argument("--decomp", default="newton_schulz", choices=["eigh", "newton_schulz"],
@@ -120,7 +121,9 @@ def main():
             "config": {"model": f"CMA-ES dim={args.dim} on {args.problem}", "global_batch": total_pop,
                        "pop_per_gpu": total_pop // world, "seq_len": args.dim,
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated eigh)",
-                       "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph)},
+                       "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph),
+                       "precision": ("bf16 operands in the sampling and covariance GEMMs; fp32 accumulation, state, "
+                                     "fitness and factorisation" if args.precision == "bf16" else "fp32 throughout")},
             "sigma_end": sigma,
             "factorisation_residual": getattr(getattr(algo, "_ns", None), "last_residual", None),
         }

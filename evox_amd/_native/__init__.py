@@ -45,6 +45,7 @@ _HIP_API = {
     "evox_hip_random_bits": (I, [P, P, I64, I64, P]),
     "evox_hip_uniform": (I, [P, P, I64, I64, F, F, P]),
     "evox_hip_normal": (I, [P, P, I64, I64, F, F, P]),
+    "evox_hip_normal_bf16": (I, [P, P, I64, I64, F, F, P]),
     "evox_hip_randint": (I, [P, P, I64, I64, I64, I64, P]),
     "evox_hip_split": (I, [P, P, I64, I64, P]),
     "evox_hip_fold_in": (I, [P, P, I64, I64, P]),

@@ -53,6 +53,35 @@ __global__ __launch_bounds__(256) void draw_kernel(const int32_t* __restrict__ k
   }
 }
 
+// Gaussian draws rounded (to nearest even) to bf16: the same values as the fp32 draw followed by a cast,
+// written once at half the traffic.
+__global__ __launch_bounds__(256) void normal_bf16_kernel(const int32_t* __restrict__ key, uint16_t* __restrict__ out,
+                                                          int64_t n, int64_t offset, float a, float b) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const uint64_t first = (uint64_t)offset >> 2;
+  const int64_t nblk = (int64_t)((((uint64_t)(offset + n - 1)) >> 2) - first + 1);
+  auto cvt = [](float v) -> uint32_t {
+    const uint32_t u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t blk = first + (uint64_t)t;
+    const f32x4 g = normal4(philox_block(k0, k1, blk, kStreamDraw));
+    const uint32_t v[4] = {cvt(fmaf(g.x, b, a)), cvt(fmaf(g.y, b, a)), cvt(fmaf(g.z, b, a)), cvt(fmaf(g.w, b, a))};
+    const int64_t e0 = (int64_t)(blk * 4) - offset;
+    if (e0 >= 0 && e0 + 3 < n && (offset & 3) == 0) {
+      *reinterpret_cast<uint2*>(out + e0) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    } else {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const int64_t e = e0 + l;
+        if (e >= 0 && e < n) out[e] = (uint16_t)v[l];
+      }
+    }
+  }
+}
+
 __global__ void split_kernel(const int32_t* __restrict__ keys, int32_t* __restrict__ out, int64_t nkeys,
                              int64_t n) {
   const int64_t total = nkeys * n;
@@ -101,6 +130,14 @@ EVOX_API int evox_hip_normal(const int32_t* key, float* out, int64_t n, int64_t 
   if (n <= 0) return 0;
   const int grid = stream_grid(nblocks_of(n, offset), 256);
   draw_kernel<kNormal, float><<<grid, 256, 0, (hipStream_t)stream>>>(key, out, n, offset, mean, stddev, 0, 0u);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_normal_bf16(const int32_t* key, uint16_t* out, int64_t n, int64_t offset, float mean, float stddev,
+                                  void* stream) {
+  if (n <= 0) return 0;
+  const int grid = stream_grid(nblocks_of(n, offset), 256);
+  normal_bf16_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(key, out, n, offset, mean, stddev);
   return last_launch_status();
 }
 

@@ -127,6 +127,12 @@ def normal(key: torch.Tensor, shape: Shape = (), dtype=torch.float32, mean: floa
     k = _single(key)
     shape = _shape(shape)
     n = math.prod(shape)
+    if k.is_cuda and dtype == torch.bfloat16:
+        # drawn in fp32 and rounded in the same kernel: identical to ``normal(...).to(bfloat16)``
+        out = torch.empty(n, dtype=torch.bfloat16, device=k.device)
+        _native.check(_native.hip().evox_hip_normal_bf16(k.data_ptr(), out.data_ptr(), n, offset, float(mean), float(std),
+                                                         _stream(k)), "normal_bf16")
+        return out.reshape(shape)
     out = torch.empty(n, dtype=torch.float32, device=k.device)
     if k.is_cuda:
         _native.check(_native.hip().evox_hip_normal(k.data_ptr(), out.data_ptr(), n, offset, float(mean), float(std), _stream(k)), "normal")

@@ -97,7 +97,8 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
             return mean + sigma * (zd.bfloat16() @ B.T.bfloat16()).float()
         return mean + sigma * (zd @ B.T)
     if impl != "fused" or precision == "bf16":
-        z = rnd.normal(key, (pop_size, n), offset=row_offset * n)
+        z = rnd.normal(key, (pop_size, n), offset=row_offset * n,
+                       dtype=torch.bfloat16 if precision == "bf16" else torch.float32)
         bd = B if D is None else B * D                            # (n, n): column j of B scaled by d_j
         sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
         if impl != "mfma" and _blas.available() and _epilogue_ok[0]:

@@ -833,3 +833,12 @@ def test_ibea_removal_large_populations(n, m, n_remove):
         want = moselect.ibea_remove(fit, I, C, 0.05, n_remove)
         got = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
         assert (got != want).sum() <= 2, int((got != want).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,offset", [(4096, 0), (1001, 0), (777, 5), (10, 2)])
+def test_bf16_normal_draw_equals_cast_of_fp32_draw(n, offset):
+    key = rnd.PRNGKey(11).cuda()
+    want = rnd.normal(key, (n,), offset=offset).to(torch.bfloat16)
+    got = rnd.normal(key, (n,), offset=offset, dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and torch.equal(got, want)
