@@ -139,7 +139,7 @@ class RVEAa(RVEA):
         fit = torch.cat([state.fitness, fitness], dim=0)
         # only first-front members compete for the vectors
         ranked = torch.where(torch.isnan(fit).any(1, keepdim=True), torch.full_like(fit, float("inf")), fit)
-        front = non_dominated_sort(ranked) == 0
+        front = non_dominated_sort(ranked, until=1) == 0
         fit_f = torch.where(front[:, None], fit, torch.full_like(fit, float("nan")))
         pop_f = torch.where(front[:, None], pop, torch.full_like(pop, float("nan")))
         v = state.reference_vector

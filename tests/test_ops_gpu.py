@@ -842,3 +842,28 @@ def test_bf16_normal_draw_equals_cast_of_fp32_draw(n, offset):
     want = rnd.normal(key, (n,), offset=offset).to(torch.bfloat16)
     got = rnd.normal(key, (n,), offset=offset, dtype=torch.bfloat16)
     assert got.dtype == torch.bfloat16 and torch.equal(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nv,m", [(200, 91, 3), (4000, 1953, 3), (1000, 300, 2), (600, 210, 5)])
+def test_rvea_fused_selection_matches_dense(n, nv, m):
+    from evox_amd.operators.selection import rvea_selection as rs
+
+    g = torch.Generator().manual_seed(n + nv)
+    f = torch.rand(n, m, generator=g)
+    f[::17] = float("nan")                                  # empty slots of the archive
+    x = torch.rand(n, 7, generator=g)
+    v = torch.rand(nv, m, generator=g) + 0.01
+    f, x, v = f.cuda(), x.cuda(), v.cuda()
+    fmin = torch.where(torch.isnan(f), torch.full_like(f, float("inf")), f).amin(0)
+    obj = (f - fmin).clamp_min(1e-32)
+    # the dense formulation in float64 is the truth (in fp32 its arc cosines of nearly parallel vectors are not)
+    want_x, want_f = rs._ref_vec_guided_dense(x.double(), f.double(), obj.double(), v.double(), 0.3)
+    got_x, got_f = rs.ref_vec_guided(x, f, v, 0.3)
+    want_x, want_f = want_x.float(), want_f.float()
+    empty_w, empty_g = torch.isnan(want_f).any(1), torch.isnan(got_f).any(1)
+    assert int((empty_w != empty_g).sum()) <= max(1, nv // 100)
+    same = ((got_f == want_f) | (torch.isnan(got_f) & torch.isnan(want_f))).all(1)
+    assert int((~same).sum()) <= max(1, nv // 100), int((~same).sum())
+    same_x = ((got_x == want_x) | (torch.isnan(got_x) & torch.isnan(want_x))).all(1)
+    assert torch.equal(same, same_x)
