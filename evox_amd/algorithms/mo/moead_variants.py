@@ -151,7 +151,9 @@ class MOEADM2M(MOAlgorithm):
 
     def ask(self, state):
         key, k_loc, k_glob, k_r, k_x, k_mut = rnd.split(state.key, 6)
-        scale = state.gen / self.max_gen
+        # past ``max_gen`` the operators keep their final step distribution (the reference's (1 − scale)^0.7 turns
+        # NaN there, ``moeadm2m.py:29,42``)
+        scale = min(state.gen / self.max_gen, 1.0)
         s, k, n = self.s, self.k, self.pop_size
         base = torch.arange(0, s * k, s, device=self.device).repeat_interleave(s)
         local = rnd.randint(k_loc, (n,), 0, s) + base

@@ -61,3 +61,26 @@ def test_reproducible():
     a, _ = run("NSGA2", {}, 5, DTLZ2(m=M))
     b, _ = run("NSGA2", {}, 5, DTLZ2(m=M))
     assert torch.equal(a.get_child_state("algorithm").population, b.get_child_state("algorithm").population)
+
+
+@pytest.mark.parametrize("name", ["MOEADM2M", "RVEA", "LMOCSO"])
+def test_running_past_max_gen_stays_finite(name):
+    """``max_gen`` shapes annealed operators; a run that continues beyond it must not turn NaN or complex."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    prob = problems.numerical.DTLZ2(m=3)
+    lb, ub = torch.zeros(prob.d), torch.ones(prob.d)
+    if name == "LMOCSO":
+        algo = algorithms.LMOCSO(3, lb, ub, 40, max_gen=3)
+    else:
+        algo = getattr(algorithms, name)(lb, ub, 3, 40, max_gen=3)
+    wf = workflows.StdWorkflow(algo, prob)
+    state = wf.init(ex.PRNGKey(3))
+    for _ in range(8):
+        state = wf.step(state)
+    a = state.get_child_state("algorithm")
+    assert not a.population.is_complex()
+    ok = torch.isfinite(a.fitness).all(1)
+    assert int(ok.sum()) >= 10
+    assert torch.isfinite(a.population[ok]).all()

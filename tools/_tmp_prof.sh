@@ -1,2 +1,4 @@
-set -e
-timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -k "rvea or RVEA" 2>&1 | tail -5
+for a in IMMOEA MOEADM2M KnEA EAGMOEAD BiGE TDEA; do
+timeout -k 10 200 python tools/cpu_profile_mo.py $a 2000 > gpurun_out/prof_$a.txt 2>&1 || exit $?
+head -34 gpurun_out/prof_$a.txt | grep -v "^$\|Ordered\|List reduced\|function calls" | cut -c1-150
+done
