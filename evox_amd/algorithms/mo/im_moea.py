@@ -66,31 +66,38 @@ class IMMOEA(MOAlgorithm):
         n, D, M, L = pop.shape[0], self.dim, self.n_objs, self.l
         dev = pop.device
         part = torch.argmax(cos_dist(obj, state.reference_vector), dim=1)
-        groups, copies = [], []
-        for k in range(self.k):
-            members = torch.nonzero(part == k)[:, 0]
-            nk = int(members.shape[0])
-            if nk < 2 * M:
-                copies.append(members)
-                continue
-            lo, hi = obj[members].amin(0), obj[members].amax(0)
-            f_lo, f_hi = 1.5 * lo - 0.5 * hi, 1.5 * hi - 0.5 * lo
-            share = nk // M
-            for m in range(M):
-                chosen = members[rnd.permutation(rnd.fold_in(k_part, k * M + m), nk)[:share]]
-                groups.append((chosen, m, f_lo[m], f_hi[m]))
-        parts = [pop[c] for c in copies]
+        counts = torch.bincount(part, minlength=self.k).tolist()          # the one host read of the step
+        big = [k for k in range(self.k) if counts[k] >= 2 * M]
+        parts = []
+        if len(big) < self.k:
+            # sub-populations too small for a model pass their members on unchanged
+            is_big = torch.zeros(self.k, dtype=torch.bool, device=dev)
+            if big:
+                is_big[torch.tensor(big, device=dev)] = True
+            parts.append(pop[~is_big[part]])
+        groups = bool(big)
         if groups:
-            G, P = len(groups), max(int(g[0].shape[0]) for g in groups)
-            idx = torch.zeros((G, P), dtype=torch.int64, device=dev)
-            mask = torch.zeros((G, P), dtype=torch.bool, device=dev)
-            grid = torch.zeros((G, P), device=dev)
-            m_of = torch.tensor([g[1] for g in groups], device=dev)
-            for gi, (chosen, _, a, b) in enumerate(groups):
-                p = chosen.shape[0]
-                idx[gi, :p] = chosen
-                mask[gi, :p] = True
-                grid[gi, :p] = torch.linspace(0, 1, p, device=dev) * (b - a) + a
+            # one group per (sub-population, objective): a random sample of ⌊n_k / M⌋ members, all groups
+            # drawn at once — random keys, non-members pushed behind, one batched sort
+            kb = torch.tensor(big, device=dev)
+            gk = kb.repeat_interleave(M)                                                   # (G,)
+            m_of = torch.arange(M, device=dev).repeat(len(big))                            # (G,)
+            share_host = [counts[k] // M for k in big for _ in range(M)]
+            G, P = len(share_host), max(share_host)
+            share = torch.tensor(share_host, device=dev)
+            member = part[None, :] == gk[:, None]                                          # (G, n)
+            keys = torch.where(member, rnd.bits(k_part, (G, n)).to(torch.int64), torch.full((), 1 << 40, device=dev))
+            order = torch.argsort(keys, dim=1)[:, :P]                                      # (G, P)
+            mask = torch.arange(P, device=dev)[None, :] < share[:, None]
+            idx = torch.where(mask, order, torch.zeros_like(order))
+            inf = torch.full((self.k, M), float("inf"), device=dev)
+            where = part[:, None].expand(n, M)
+            lo = inf.scatter_reduce(0, where, obj, reduce="amin")
+            hi = (-inf).scatter_reduce(0, where, obj, reduce="amax")
+            f_lo, f_hi = 1.5 * lo - 0.5 * hi, 1.5 * hi - 0.5 * lo                          # (k, M)
+            a, b = f_lo[gk, m_of], f_hi[gk, m_of]                                          # (G,)
+            t = torch.arange(P, device=dev)[None, :] / (share[:, None] - 1).clamp_min(1)
+            grid = torch.where(mask, a[:, None] + t * (b - a)[:, None], torch.zeros((), device=dev))
             x = obj[idx, m_of[:, None]]                                                    # (G,P)
             dims = torch.argsort(rnd.bits(k_dim, (G, D)), dim=1)[:, :L]                    # (G,L)
             base = pop[idx]                                                                # (G,P,D)

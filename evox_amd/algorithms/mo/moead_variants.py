@@ -9,6 +9,7 @@ import torch
 from ...ops.distance import cdist as _cdist
 
 from ...core import random as rnd
+from ...ops import nds as _nds
 from ...core.state import State
 from ...operators import crossover, selection
 from ...operators.sampling import LatinHypercubeSampling, UniformSampling
@@ -110,7 +111,36 @@ class M2MMutation:
 def m2m_associate(key, pop, obj, w, s):
     """Split the population into ``len(w)`` sub-populations of ``s`` members by the closest
     direction; under-full regions are topped up with random individuals, over-full ones keep
-    their best ``s`` by (front index, crowding distance)."""
+    their best ``s`` by (front index, crowding distance).  All regions are handled together: one
+    lexicographic sort by (region, front index, −crowding distance) and a gather of the first ``s``
+    positions of every region, without reading a count back to the host."""
+    k, n = w.shape[0], pop.shape[0]
+    dev = pop.device
+    region = torch.argmax(cos_dist(obj, w), dim=1)
+    rank = non_dominated_sort(obj)
+    filler = rnd.randint(key, (k, s), 0, n)
+    cnt = torch.bincount(region, minlength=k)
+    start = torch.cumsum(cnt, 0) - cnt
+    by_rank = torch.argsort(rank, stable=True)
+    by_rank = by_rank[torch.argsort(region[by_rank], stable=True)]          # grouped by region, ascending front index
+    # front index of each region's s-th member: the front whose members compete by crowding distance
+    worst = rank[by_rank[(start + s - 1).clamp_max(n - 1)]]
+    in_worst = (rank == worst[region]) & (cnt[region] >= s)
+    cd = _nds.segmented_crowding_distance(obj, region, in_worst, k)
+    tie = torch.where(in_worst, -cd, torch.zeros_like(cd))
+    order = torch.argsort(tie, stable=True)
+    order = order[torch.argsort(rank[order], stable=True)]
+    order = order[torch.argsort(region[order], stable=True)]                # (region, front index, −crowding)
+    j = torch.arange(s, device=dev)[None, :]
+    have = j < cnt[:, None]
+    own = order[(start[:, None] + j).clamp_max(n - 1)]
+    fill = torch.gather(filler, 1, (j - cnt[:, None]).clamp_min(0))
+    part = torch.where(have, own, fill).reshape(-1)
+    return pop[part], obj[part]
+
+
+def m2m_associate_reference(key, pop, obj, w, s):
+    """``m2m_associate`` region by region (host loop; the oracle of the batched form)."""
     k, n = w.shape[0], pop.shape[0]
     region = torch.argmax(cos_dist(obj, w), dim=1)
     rank = non_dominated_sort(obj).to(torch.float32)

@@ -21,10 +21,10 @@ from ...utils.common import cos_dist
 from ...ops._util import check as _check
 from ...ops._util import hip as _hip
 from ...ops._util import stream_of as _stream_of
+from ...ops.linalg_small import solve_small
 from .common import MOAlgorithm
 
 _native.register_hip_api({
-    "evox_hip_small_solve": (_native.I, [_native.P, _native.P, _native.I, _native.P, _native.P, _native.P]),
     "evox_hip_niche_fill": (_native.I, [_native.P, _native.P, _native.I, _native.P, _native.P, _native.P]),
 })
 
@@ -32,17 +32,8 @@ _native.register_hip_api({
 def _hyperplane_intercepts(extreme):
     """``(intercepts, ok)`` of the hyperplane through the rows of ``extreme`` (m × m): the solution of
     ``extreme · x = 1`` inverted, and whether the system was well posed."""
-    m = extreme.shape[0]
-    if extreme.is_cuda and extreme.dtype == torch.float32 and m <= 16:
-        # one tiny elimination kernel instead of the library's least-squares + rank routines
-        sol = torch.empty(m, dtype=torch.float32, device=extreme.device)
-        flag = torch.empty(1, dtype=torch.int32, device=extreme.device)
-        ones = torch.ones(m, dtype=torch.float32, device=extreme.device)
-        _check(_hip().evox_hip_small_solve(extreme.contiguous().data_ptr(), ones.data_ptr(), m, sol.data_ptr(), flag.data_ptr(),
-                                           _stream_of(extreme)), "small_solve")
-        return 1.0 / sol, flag[0] == 0
-    sol = torch.linalg.lstsq(extreme, torch.ones(m, 1, device=extreme.device)).solution[:, 0]
-    return 1.0 / sol, torch.linalg.matrix_rank(extreme) == m
+    sol, ok = solve_small(extreme, torch.ones(extreme.shape[0], dtype=extreme.dtype, device=extreme.device))
+    return 1.0 / sol, ok
 
 
 def _niche_fill(rho, cnt, k, max_level: int = 1 << 40):

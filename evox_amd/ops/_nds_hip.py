@@ -16,7 +16,8 @@ _native.register_hip_api({
 })
 
 MAX_OBJECTIVES = 8
-_ROUNDS_PER_CHECK = 4
+_ROUNDS_PER_CHECK = 4           # rounds issued before the first host check; doubles up to _MAX_ROUNDS_PER_CHECK
+_MAX_ROUNDS_PER_CHECK = 32
 
 
 def supported(x: torch.Tensor) -> bool:
@@ -45,20 +46,26 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
 
     rk = torch.full((n,), -1, dtype=torch.int32, device=dev)
     front = torch.empty((m, ld), dtype=torch.float32, device=dev)                  # objectives of the current front
-    sizes = torch.zeros(n + _ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)     # size of front k
+    sizes = torch.zeros(n + 2 * _MAX_ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)  # size of front k
     blockcnt = torch.empty(2 * blocks, dtype=torch.int32, device=dev)             # per-block counts | running totals
     target = n if until is None else min(int(until), n)
     cur = 0
+    batch = _ROUNDS_PER_CHECK
     while True:
-        for _ in range(_ROUNDS_PER_CHECK):
+        # peeling rounds are issued in growing batches between host checks: populations with dozens of fronts
+        # then cost a handful of read-backs, and rounds issued past the last front find nothing to do
+        before = cur
+        for _ in range(batch):
             check(lib.evox_hip_nds_round(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), front.data_ptr(),
                                          sizes[cur:].data_ptr(), blockcnt.data_ptr(), blockcnt[blocks:].data_ptr(),
                                          cur, s), "nds_round")
             cur += 1
         done = sizes[:cur].cumsum(0)
         host = done.cpu()                                   # one small read-back per batch of rounds
-        if int(host[-1]) >= target or cur >= n or int(host[-1]) == int(host[-_ROUNDS_PER_CHECK - 1] if cur > _ROUNDS_PER_CHECK else 0):
+        ranked = int(host[-1])
+        if ranked >= target or cur >= n or ranked == (int(host[before - 1]) if before > 0 else 0):
             break
+        batch = min(2 * batch, _MAX_ROUNDS_PER_CHECK)
     host_sizes = host.tolist()
     # the front at which the target was reached; everything later collapses into one index
     cut = next((k for k, c in enumerate(host_sizes) if c >= target), cur - 1)
@@ -67,8 +74,6 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     rk64 = rk.to(torch.int64)
     last = cut + 1
     rk64 = torch.where((rk64 < 0) | (rk64 > cut), torch.full_like(rk64, last), rk64)
-    if until is None and int(host_sizes[-1]) == n:
-        pass
     out = torch.empty_like(rk64)
     out[order] = rk64
     if with_info:

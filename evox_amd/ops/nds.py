@@ -122,6 +122,32 @@ def crowding_distance(costs: torch.Tensor, mask: Optional[torch.Tensor] = None) 
     return crowding_distance_reference(costs, mask)
 
 
+def segmented_crowding_distance(costs: torch.Tensor, group: torch.Tensor, mask: torch.Tensor, n_groups: int) -> torch.Tensor:
+    """``crowding_distance`` of several disjoint sets at once: among the rows selected by ``mask``, those with
+    the same ``group`` (int64 in ``[0, n_groups)``) form one set with its own extremes and spans.  Two stable
+    sorts per objective for all sets together; rows outside ``mask`` get ``-inf``."""
+    n, m = costs.shape
+    dev = costs.device
+    c = costs.float()
+    g = torch.where(mask, group, torch.full_like(group, n_groups))
+    where = g[:, None].expand(n, m)
+    inf = torch.full((n_groups + 1, m), float("inf"), device=dev)
+    span = (-inf).scatter_reduce(0, where, c, reduce="amax") - inf.scatter_reduce(0, where, c, reduce="amin")
+    total = torch.zeros(n, device=dev)
+    for k in range(m):
+        o = torch.argsort(c[:, k], stable=True)
+        o = o[torch.argsort(g[o], stable=True)]                          # grouped, ascending inside a group
+        gs, v = g[o], c[o, k]
+        edge = torch.ones(n, dtype=torch.bool, device=dev)
+        edge[1:] = gs[1:] != gs[:-1]
+        tail = torch.ones(n, dtype=torch.bool, device=dev)
+        tail[:-1] = edge[1:]
+        gap = (torch.roll(v, -1) - torch.roll(v, 1)) / span[gs, k]
+        gap = torch.where(edge | tail, torch.full_like(gap, float("inf")), gap)
+        total[o] += gap
+    return torch.where(mask, total, torch.full_like(total, float("-inf")))
+
+
 _CROWD_KERNEL_MAX = 16384        # front sizes up to which the scan-based crowding kernel is used
 
 
