@@ -569,6 +569,9 @@ class ASEBO(_ESBase):
         grad = 0.5 * ((fitness[:h] - fitness[h:]) @ noise_1)
         if state.gen_counter > self.subspace_dims:
             alpha = torch.linalg.vector_norm(grad @ state.UUT_ort) / torch.linalg.vector_norm(grad @ state.UUT)
+            # undefined (0/0: no gradient mass in either subspace, e.g. an empty orthogonal complement when the
+            # population is larger than the gradient history) or infinite → isotropic sampling
+            alpha = torch.nan_to_num(alpha, nan=1.0, posinf=1.0)
         else:
             alpha = torch.ones_like(state.alpha)
         subspace = torch.cat([state.grad_subspace[1:], grad[None, :]], dim=0)

@@ -96,10 +96,8 @@ class CR_FM_NES(Algorithm):
         weights_dist = w_tmp / w_tmp.sum() - 1.0 / lam
         moving = ps_norm >= self.chi_N
         weights = torch.where(moving, weights_dist, state.w_rank)
-        lrate_sigma = torch.where(moving, torch.tensor(self.lrate_move_sigma, device=z.device),
-                                  torch.tensor(self.lrate_stag_sigma, device=z.device))
-        lrate_sigma = torch.where(ps_norm >= 0.1 * self.chi_N, lrate_sigma,
-                                  torch.tensor(self.lrate_conv_sigma, device=z.device))
+        lrate_sigma = torch.where(moving, float(self.lrate_move_sigma), float(self.lrate_stag_sigma))
+        lrate_sigma = torch.where(ps_norm >= 0.1 * self.chi_N, lrate_sigma, float(self.lrate_conv_sigma))
         wxm = (x - state.center[:, None]) @ weights
         p_c = (1.0 - self.c_c) * state.p_c + math.sqrt(self.c_c * (2.0 - self.c_c) * self.mu_eff) * wxm / state.sigma
         center = state.center + self.lrate_mean * wxm[:, 0]
@@ -311,7 +309,9 @@ class LES(Algorithm):
         g, s = _es.weighted_noise_sum(state.noise_key, weights, self.num_dims, v=weights)
         weight_noise = g
         weight_diff = state.sigma * g
-        ts = self.timescales.to(dev)
+        if self.timescales.device != dev:
+            self.timescales = self.timescales.to(dev)         # once: a copy per generation would block graph capture
+        ts = self.timescales
         path_c = (1 - ts) * state.path_c + (1 - ts) * weight_diff[:, None]
         path_sigma = (1 - ts) * state.path_sigma + (1 - ts) * weight_noise[:, None]
         time_embed = tanh_timestamp(state.gen_counter).to(dev)
@@ -324,8 +324,6 @@ class LES(Algorithm):
         weighted_sigma = torch.sqrt(state.sigma ** 2 * (s + 1.0) + 1e-10)
         mean = state.mean + lr_mean * (weighted_mean - state.mean)
         sigma = torch.clamp(state.sigma + lr_sigma * (weighted_sigma - state.sigma), min=0)
-        i = torch.argmin(fitness)
-        improved = fitness[i] < state.best_fitness
-        best_fitness = torch.where(improved, fitness[i], state.best_fitness)
+        best_fitness = torch.minimum(fitness.min(), state.best_fitness)
         return state.replace(mean=mean, sigma=sigma, path_c=path_c, path_sigma=path_sigma, best_fitness=best_fitness,
                              gen_counter=state.gen_counter + 1)

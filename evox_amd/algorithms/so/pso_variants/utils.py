@@ -46,8 +46,8 @@ def update_bests(population, fitness, pbest, pbest_fit, gbest, gbest_fit):
     better = fitness < pbest_fit
     pbest = torch.where(better[:, None], population, pbest)
     pbest_fit = torch.minimum(pbest_fit, fitness)
-    i = torch.argmin(fitness)
-    take = fitness[i] < gbest_fit.reshape(())
-    gbest = torch.where(take, population[i], gbest)
-    gbest_fit = torch.where(take, fitness[i], gbest_fit.reshape(())).reshape(gbest_fit.shape)
+    best_fit, i = torch.min(fitness, dim=0)                   # 0-d tensors; no index is read back to the host
+    take = best_fit < gbest_fit.reshape(())
+    gbest = torch.where(take, population.index_select(0, i.reshape(1))[0], gbest)
+    gbest_fit = torch.where(take, best_fit, gbest_fit.reshape(())).reshape(gbest_fit.shape)
     return pbest, pbest_fit, gbest, gbest_fit

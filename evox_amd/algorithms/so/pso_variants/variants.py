@@ -84,10 +84,10 @@ class _SLPSO(_SwarmBase):
         key, k_r, k_d = rnd.split(state.key, 3)
         n = self.pop_size
         r = rnd.uniform(k_r, (3, n, self.dim))
-        i = torch.argmin(fitness)
-        take = fitness[i] < state.global_best_fitness.reshape(())
-        gbest = torch.where(take, state.population[i], state.global_best_location)
-        gfit = torch.where(take, fitness[i], state.global_best_fitness.reshape(())).reshape(1)
+        best_fit, i = torch.min(fitness, dim=0)               # 0-d tensors; no index is read back to the host
+        take = best_fit < state.global_best_fitness.reshape(())
+        gbest = torch.where(take, state.population.index_select(0, i.reshape(1))[0], state.global_best_location)
+        gfit = torch.where(take, best_fit, state.global_best_fitness.reshape(())).reshape(1)
         ranked = state.population[torch.argsort(fitness, descending=True, stable=True)]
         x_k = ranked[self._demonstrator_index(k_d)]
         x_avg = state.population.mean(0)
@@ -238,16 +238,18 @@ class FIPS(_SwarmBase):
         else:
             raise NotImplementedError(self.topology)
         phi = torch.full((self.pop_size, 1), float(self.max_phi), device=dev)
+        # the topology is fixed after setup: its padded neighbour lists are built once, not every generation
+        nbr, nbr_mask = topo.build_adjacancy_list_from_matrix(adj)
         return State(population=pop, velocity=vel, local_best_location=pop, local_best_fitness=self._inf(),
                      neighbour_best_location=pop, neighbour_best_fitness=self._inf(), adjacancy_matrix=adj,
-                     key=sk, chi=_constriction(phi), phi=phi)
+                     adjacancy_list=nbr, adjacancy_mask=nbr_mask, key=sk, chi=_constriction(phi), phi=phi)
 
     def tell(self, state, fitness):
         key, k_phi = rnd.split(state.key)
         better = fitness < state.local_best_fitness
         lbest = torch.where(better[:, None], state.population, state.local_best_location)
         lbest_fit = torch.minimum(state.local_best_fitness, fitness)
-        nbr, mask = topo.build_adjacancy_list_from_matrix(state.adjacancy_matrix)
+        nbr, mask = state.adjacancy_list, state.adjacancy_mask
         n, k = nbr.shape
         if self.weight_type == "Constant":
             w = torch.ones((n, k), device=nbr.device)
@@ -285,9 +287,10 @@ class SwmmPSO(_SwarmBase):
         if self.topology != "Circles":
             raise NotImplementedError(self.topology)
         adj = topo.get_circles_neighbour(ka, pop, K=2, shortcut=self.shortcut)
+        nbr, nbr_mask = topo.build_adjacancy_list_from_matrix(adj)      # fixed topology: built once
         return State(population=pop, velocity=vel, local_best_location=pop, local_best_fitness=self._inf(),
                      neighbour_best_location=pop, neighbour_best_fitness=self._inf(), adjacancy_matrix=adj,
-                     key=sk, chi=_constriction(phi), phi=phi)
+                     adjacancy_list=nbr, adjacancy_mask=nbr_mask, key=sk, chi=_constriction(phi), phi=phi)
 
     def tell(self, state, fitness):
         key, k1, k2 = rnd.split(state.key, 3)
@@ -297,7 +300,7 @@ class SwmmPSO(_SwarmBase):
         better = fitness < state.local_best_fitness
         lbest = torch.where(better[:, None], state.population, state.local_best_location)
         lbest_fit = torch.minimum(state.local_best_fitness, fitness)
-        nbr, _ = topo.build_adjacancy_list_from_matrix(state.adjacancy_matrix)
+        nbr = state.adjacancy_list
         nbest_fit, nbest_i = topo.get_neighbour_best_fitness(lbest_fit, nbr)
         nbest = lbest[nbest_i]
         vel = state.chi * (state.velocity + phi1 * (lbest - state.population) + phi2 * (nbest - state.population))

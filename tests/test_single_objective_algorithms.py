@@ -124,3 +124,15 @@ def test_opt_direction_max():
     for _ in range(100):
         state = wf.step(state)
     assert -0.1 < float(mon.get_best_fitness()) <= 0.0
+
+
+def test_asebo_population_larger_than_gradient_history_stays_finite():
+    """With more directions requested than the gradient history holds, the orthogonal complement is empty and
+    the subspace weight is 0/0; sampling must fall back to the isotropic distribution instead of failing."""
+    algo = A.ASEBO(64, torch.full((12,), 3.0), lr=0.05, sigma=0.1, subspace_dims=6)
+    wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin())
+    state = wf.init(ex.PRNGKey(5))
+    for _ in range(12):
+        state = wf.step(state)
+    a = state.get_child_state("algorithm")
+    assert torch.isfinite(a.center).all() and torch.isfinite(a.alpha)

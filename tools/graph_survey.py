@@ -32,6 +32,17 @@ def make(name, dim, pop, dev):
         "SNES": lambda: A.SNES(pop, c), "XNES": lambda: A.XNES(c, torch.eye(dim, device=dev), pop_size=pop),
         "MAES": lambda: A.MAES(c, 1.0, pop_size=pop), "ARS": lambda: A.ARS(pop, c), "DES": lambda: A.DES(pop, c),
         "CR_FM_NES": lambda: A.CR_FM_NES(pop, c, 1.0),
+        "DMSPSOEL": lambda: A.DMSPSOEL(lb, ub, pop // 16, 8, pop // 2, 5, 300, 0.7, 1.5, 1.5, 1.0, 1.0),
+        "SwmmPSO": lambda: A.SwmmPSO(lb, ub, pop, shortcut=5), "FSPSO": lambda: A.FSPSO(lb, ub, pop),
+        "IPOPCMAES": lambda: A.IPOPCMAES(c, 1.0, pop_size=pop), "BIPOPCMAES": lambda: A.BIPOPCMAES(c, 1.0, pop_size=pop),
+        "LMMAES": lambda: A.LMMAES(c, 1.0, pop_size=pop), "AMaLGaM": lambda: A.AMaLGaM(c, 1.0, pop_size=pop),
+        "IndependentAMaLGaM": lambda: A.IndependentAMaLGaM(c, 1.0, pop_size=pop), "RMES": lambda: A.RMES(c, 1.0, pop_size=pop),
+        "ESMC": lambda: A.ESMC(pop + 1, c, lr=0.1, sigma=0.1), "SeparableNES": lambda: A.SeparableNES(c, torch.ones(dim, device=dev), pop),
+        "GuidedES": lambda: A.GuidedES(pop, c, lrate_init=0.5, sigma_init=0.1),
+        "Noise_reuse_es": lambda: A.Noise_reuse_es(pop, c, lr=0.1, sigma=0.1),
+        "PersistentES": lambda: A.PersistentES(pop, c, lr=0.1, sigma=0.1, T=10, K=10),
+        "ASEBO": lambda: A.ASEBO(pop, c, lr=0.05, sigma=0.1, subspace_dims=min(50, dim)),
+        "LES": lambda: A.LES(pop, c, sigma_init=1.0, net_params=A.init_les_params(ex.PRNGKey(0).to(dev))),
     }
     return table[name]()
 
@@ -61,7 +72,9 @@ if __name__ == "__main__":
     dev = torch.device("cuda")
     names = args.only.split(",") if args.only else ["PSO", "CSO", "CLPSO", "SLPSOGS", "SLPSOUS", "FIPS", "DE", "ODE", "JaDE", "SHADE",
                                                      "SaDE", "CoDE", "CMAES", "SepCMAES", "OpenES", "PGPE", "SNES", "XNES", "MAES",
-                                                     "ARS", "DES", "CR_FM_NES"]
+                                                     "ARS", "DES", "CR_FM_NES", "DMSPSOEL", "SwmmPSO", "FSPSO", "IPOPCMAES",
+                                                     "BIPOPCMAES", "LMMAES", "AMaLGaM", "IndependentAMaLGaM", "RMES", "ESMC",
+                                                     "SeparableNES", "GuidedES", "Noise_reuse_es", "PersistentES", "ASEBO", "LES"]
     if not args.only:
         # one process per algorithm: a refused recording must not disturb the next measurement
         import subprocess
