@@ -49,5 +49,28 @@ for _ in range(3):
     Fv, CRv = de_adapt.draw_params(key, key, key, torch.full((100,), 0.5, device=dev), torch.full((100,), 0.5, device=dev), 50000)
     de_adapt.select_and_adapt(pop20, pop20 + 1, fc + 1, fc, Fv, CRv, torch.full((100,), 0.5, device=dev),
                               torch.full((100,), 0.5, device=dev), strict=True, weight_by_gain=True, mode="shade")
+# selection-loop, indicator, distance and reference-vector kernels
+from evox_amd.algorithms.mo import indicator, nsga3
+from evox_amd.ops import distance, moselect, linalg_small, swarm
+from evox_amd.operators.selection import rvea_selection
+from evox_amd.core import random as _rnd
+obj4k = torch.rand(4000, 3, device=dev)
+for _ in range(2):
+    d = distance.cdist(torch.rand(20000, 3, device=dev), torch.rand(10000, 3, device=dev))     # cdist_small_kernel
+    d = distance.cdist(torch.rand(2048, 100, device=dev), torch.rand(2048, 100, device=dev))    # cdist_kernel
+    keep = indicator.ibea_survivors(obj4k, 0.05, 2000)                       # ibea_fitness_kernel, ibea_remove_reg_kernel
+    sf = indicator.spea2_fitness(obj4k)                                      # spea2_density_kernel, spea2_raw_kernel
+    keep = moselect.spea2_truncate(obj4k, sf < 2, 1000)                      # spea2_truncate_kernel
+    I1, I2, u = torch.rand(4000, device=dev), torch.rand(4000, device=dev), torch.rand(4000, device=dev)
+    rk = moselect.stochastic_ranking(I1, I2, u, 0.45)                        # stochastic_ranking_kernel
+    dd = distance.cdist(obj4k, obj4k); dd.fill_diagonal_(float("inf"))
+    br = (dd / torch.sort(dd, dim=1).values[:, 2].mean()).clamp_max(1.0)
+    keep = moselect.crowd_remove(br, 1500)                                   # crowd_remove_kernel
+    v = torch.rand(2000, 3, device=dev) + 0.01
+    xs, fs = rvea_selection.ref_vec_guided(torch.rand(4000, 12, device=dev), obj4k, v, 0.3)   # rvea_assoc_kernel
+    slots = nsga3._niche_fill(torch.randint(0, 5, (2000,), device=dev), torch.randint(0, 5, (2000,), device=dev),
+                              torch.tensor(900, device=dev))                 # niche_fill_kernel
+    x3, ok3 = linalg_small.solve_small(torch.rand(3, 3, device=dev) + torch.eye(3, device=dev), torch.ones(3, device=dev))
+    zb = _rnd.normal(key, (lam, n), dtype=torch.bfloat16)                    # normal_bf16_kernel
 torch.cuda.synchronize()
 print("done")
