@@ -206,24 +206,26 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(const float* __restr
 // one step earlier, so a workgroup barrier separates the steps (a wave barrier when one wave suffices).
 // The result is exactly that of the sequential sort, in ⌈sweeps / L⌉ passes of n − 1 + 2(L − 1) steps for
 // L threads instead of n/2 passes of n steps by a single lane.
-template <int L>
+// KEYS: the two key vectors and the coin flips are staged in LDS too (each instantiation addresses one memory
+// space only, so the loop compiles to LDS / global instructions rather than generic ones).
+template <int L, bool KEYS>
 __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
                                                                const float* __restrict__ u, float pc, int n,
-                                                               int64_t* __restrict__ rank, int keys_in_lds) {
+                                                               int64_t* __restrict__ rank) {
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
-  volatile int* rk = s_mem;                              // the permutation, n entries
-  float* l1 = reinterpret_cast<float*>(s_mem + n);       // optional copies of I1, I2, u
+  int* rk = s_mem;                                       // the permutation, n entries
+  float* l1 = reinterpret_cast<float*>(s_mem + n);       // copies of I1, I2, u when KEYS
   float* l2 = l1 + n;
   float* lu = l2 + n;
   const int lane = threadIdx.x;
   for (int i = lane; i < n; i += L) {
     rk[i] = i;
-    if (keys_in_lds) { l1[i] = I1[i]; l2[i] = I2[i]; lu[i] = u[i]; }
+    if constexpr (KEYS) { l1[i] = I1[i]; l2[i] = I2[i]; lu[i] = u[i]; }
   }
   __syncthreads();
-  const float* K1 = keys_in_lds ? l1 : I1;
-  const float* K2 = keys_in_lds ? l2 : I2;
-  const float* U = keys_in_lds ? lu : u;
+  auto key1 = [&](int i) { if constexpr (KEYS) return l1[i]; else return I1[i]; };
+  auto key2 = [&](int i) { if constexpr (KEYS) return l2[i]; else return I2[i]; };
+  auto coin = [&](int j) { if constexpr (KEYS) return lu[j]; else return u[j]; };
   const int sweeps = (n + 1) / 2;
   const int steps = (n - 1) + 2 * (L - 1);
   for (int s0 = 0; s0 < sweeps; s0 += L) {
@@ -233,10 +235,10 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
     for (int t = 0; t < steps; ++t) {
       const int j = t - 2 * lane;
       if (mine && j >= 0 && j < n - 1) {
-        if (j == 0) { a = rk[0]; a1 = K1[a]; a2 = K2[a]; }
+        if (j == 0) { a = rk[0]; a1 = key1(a); a2 = key2(a); }
         const int b = rk[j + 1];
-        const float b1 = K1[b], b2 = K2[b];
-        const bool first = U[j] < pc;
+        const float b1 = key1(b), b2 = key2(b);
+        const bool first = coin(j) < pc;
         if ((first ? a1 : a2) < (first ? b1 : b2)) {
           rk[j] = b;                                       // b moves left, a keeps bubbling right
         } else {
@@ -245,10 +247,9 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
         }
         if (j == n - 2) rk[n - 1] = a;
       }
-      if (L == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+      __syncthreads();                                     // the next step reads what this one wrote
     }
   }
-  __syncthreads();
   for (int i = lane; i < n; i += L) rank[i] = rk[i];
 }
 
@@ -406,12 +407,13 @@ EVOX_API int evox_hip_spea2_truncate(const float* dis, int n, int ld, int n_remo
 template <int L>
 int launch_ranking(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
                    int keys_in_lds, hipStream_t st) {
+  const void* fn = keys_in_lds ? (const void*)stochastic_ranking_kernel<L, true> : (const void*)stochastic_ranking_kernel<L, false>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  stochastic_ranking_kernel<L><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank, keys_in_lds);
+  if (keys_in_lds) stochastic_ranking_kernel<L, true><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank);
+  else stochastic_ranking_kernel<L, false><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank);
   return last_launch_status();
 }
 
