@@ -80,6 +80,41 @@ EVOX_API int evox_hip_dtlz(const float* x, int64_t ldx, int n, int d, int m, int
   return evox::last_launch_status();
 }
 
+// ZDT1, 2, 3, 4, 6 (kind): f1 = f1(x_0), f2 = g(x_1..) · h(f1, g), one thread per row.
+namespace {
+__global__ __launch_bounds__(256) void zdt_kernel(const float* __restrict__ x, int64_t ldx, int n, int d, int kind,
+                                                  float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = x + (int64_t)i * ldx;
+  const float x0 = r[0];
+  float acc = 0.f;
+  if (kind == 4) {
+    for (int j = 1; j < d; ++j) acc += r[j] * r[j] - 10.f * cosf(4.f * kPi * r[j]);
+  } else {
+    for (int j = 1; j < d; ++j) acc += r[j];
+  }
+  float f1 = x0, g;
+  if (kind == 4) g = 1.f + 10.f * (float)(d - 1) + acc;
+  else if (kind == 6) g = 1.f + 9.f * powf(acc / 9.f, 0.25f);
+  else g = 1.f + 9.f * acc / (float)(d - 1);
+  if (kind == 6) { const float sn = sinf(6.f * kPi * x0); const float s2 = sn * sn; f1 = 1.f - expf(-4.f * x0) * s2 * s2 * s2; }
+  const float q = f1 / g;
+  float h;
+  if (kind == 2 || kind == 6) h = 1.f - q * q;
+  else if (kind == 3) h = 1.f - sqrtf(q) - q * sinf(10.f * kPi * f1);
+  else h = 1.f - sqrtf(q);
+  out[2 * (int64_t)i] = f1;
+  out[2 * (int64_t)i + 1] = g * h;
+}
+}  // namespace
+
+EVOX_API int evox_hip_zdt(const float* x, int64_t ldx, int n, int d, int kind, float* out, void* stream) {
+  if (n <= 0 || d < 2 || !(kind == 1 || kind == 2 || kind == 3 || kind == 4 || kind == 6)) return (int)hipErrorInvalidValue;
+  zdt_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, ldx, n, d, kind, out);
+  return evox::last_launch_status();
+}
+
 // CEC-style prologue z = M·((x − o)·rate), optionally with the output coordinates permuted
 // (z'_j = z_{perm[j]}): three tensor ops and a K = d ≤ 128 GEMM that the library runs far below its
 // rate, as one pass with the rotation matrix staged in LDS.

@@ -7,7 +7,14 @@ import math
 
 import torch
 
+from ... import _native
 from ...core.problem import Problem
+from ...ops._util import check as _check
+from ...ops._util import hip as _hip
+from ...ops._util import stream_of as _stream_of
+
+_native.register_hip_api({"evox_hip_zdt": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.I, _native.P,
+                                                      _native.P])})
 
 
 class ZDTTestSuit(Problem):
@@ -25,7 +32,16 @@ class ZDTTestSuit(Problem):
     def _h(self, f1, g):
         return 1 - torch.sqrt(f1 / g)
 
+    _KIND = 0                                  # fused-kernel selector of the concrete problem (0: none)
+
     def evaluate(self, state, X):
+        if self._KIND and X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.stride(1) == 1 and X.shape[1] >= 2:
+            # one pass over the rows (csrc/moproblems.hip::zdt_kernel) instead of a dozen tensor operations
+            n, d = X.shape
+            out = torch.empty((n, 2), dtype=torch.float32, device=X.device)
+            if n:
+                _check(_hip().evox_hip_zdt(X.data_ptr(), X.stride(0), n, d, self._KIND, out.data_ptr(), _stream_of(X)), "zdt")
+            return out, state
         f1 = self._f1(X)
         g = self._g(X)
         return torch.stack([f1, g * self._h(f1, g)], dim=1), state
@@ -36,10 +52,12 @@ class ZDTTestSuit(Problem):
 
 
 class ZDT1(ZDTTestSuit):
-    pass
+    _KIND = 1
 
 
 class ZDT2(ZDTTestSuit):
+    _KIND = 2
+
     def _h(self, f1, g):
         return 1 - (f1 / g) ** 2
 
@@ -49,6 +67,8 @@ class ZDT2(ZDTTestSuit):
 
 
 class ZDT3(ZDTTestSuit):
+    _KIND = 3
+
     def _h(self, f1, g):
         return 1 - torch.sqrt(f1 / g) - (f1 / g) * torch.sin(10 * math.pi * f1)
 
@@ -62,12 +82,16 @@ class ZDT3(ZDTTestSuit):
 
 
 class ZDT4(ZDTTestSuit):
+    _KIND = 4
+
     def _g(self, x):
         r = x[:, 1:]
         return 1 + 10 * (self.n - 1) + (r ** 2 - 10 * torch.cos(4 * math.pi * r)).sum(1)
 
 
 class ZDT6(ZDTTestSuit):
+    _KIND = 6
+
     def _f1(self, x):
         return 1 - torch.exp(-4 * x[:, 0]) * torch.sin(6 * math.pi * x[:, 0]) ** 6
 
