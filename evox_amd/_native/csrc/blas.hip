@@ -281,13 +281,18 @@ __global__ __launch_bounds__(256) void ns_matvec_kernel(const float* __restrict_
   }
 }
 
+// 1 + e/2 + 3e²/8 + 5e³/16 + 35e⁴/128 with e = I − M, in powers of M
+constexpr float kP4c0 = 315.f / 128.f, kP4c1 = -420.f / 128.f, kP4c2 = 378.f / 128.f, kP4c3 = -180.f / 128.f, kP4c4 = 35.f / 128.f;
+
 // Y0 = C/s, T = 1.5 I − 0.5 Y0; block 0 also stores s and the normalised power vector.
+// With Q != nullptr (degree-4 first step) T = c0 I + c1 Y0 and Q = c2 I + c3 Y0 instead: the two linear parts
+// of  p(M) = (c0 I + c1 M) + M² ((c2 I + c3 M) + c4 M²),  the degree-4 Taylor polynomial of M^{-1/2} about I.
 // safe: s = max(tr C/n, ‖C‖∞/1.9) (spectrum of Y0 provably inside (0, 1.9]); otherwise s is the
 // power-iteration estimate ‖C v‖ (‖v‖ = 1), which never exceeds λmax — iterates with eigenvalues
 // up to 3 still converge, so an under-estimate by less than that factor is harmless.
 __global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__ C, int n, float* __restrict__ Y,
                                                        float* __restrict__ T, float* scal, float* vec, int steps,
-                                                       int safe, int mv_blocks) {
+                                                       int safe, int mv_blocks, float* __restrict__ Q) {
   __shared__ float red[4];
   const float inf_norm = block_reduce(part_row(scal, kRowInf), mv_blocks, true, red);
   const float trace = block_reduce(part_row(scal, kRowDiag), mv_blocks, false, red);
@@ -301,7 +306,12 @@ __global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__
     const float y = C[i] * is;
     const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
     Y[i] = y;
-    T[i] = (r == c ? 1.5f : 0.f) - 0.5f * y;
+    if (Q != nullptr) {
+      T[i] = (r == c ? kP4c0 : 0.f) + kP4c1 * y;
+      Q[i] = (r == c ? kP4c2 : 0.f) + kP4c3 * y;
+    } else {
+      T[i] = (r == c ? 1.5f : 0.f) - 0.5f * y;
+    }
   }
   if (blockIdx.x == 0) {
     if (threadIdx.x == 0) scal[13] = s;
@@ -309,6 +319,21 @@ __global__ __launch_bounds__(256) void ns_scale_kernel(const float* __restrict__
     const float inv = rsqrtf(fmaxf(last, 1e-38f));
     for (int j = threadIdx.x; j < n; j += blockDim.x) vec[j] = w[j] * inv;
   }
+}
+
+// q += c · a  (n² elements)
+__global__ __launch_bounds__(256) void ns_axpy_kernel(const float* __restrict__ a, float c, float* __restrict__ q, int64_t total) {
+  const int64_t n4 = total >> 2;
+  const float4* a4 = reinterpret_cast<const float4*>(a);
+  float4* q4 = reinterpret_cast<float4*>(q);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 x = a4[i];
+    float4 y = q4[i];
+    y.x += c * x.x; y.y += c * x.y; y.z += c * x.z; y.w += c * x.w;
+    q4[i] = y;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    q[i] += c * a[i];
 }
 
 __global__ __launch_bounds__(256) void ns_residual_kernel(const float* __restrict__ T, int n, float* scal) {
@@ -422,9 +447,14 @@ EVOX_API int evox_hip_gemm_plan_info(int in_dtype, int transA, int transB, int64
 // max(tr C/n, ‖C‖∞/1.9) instead (always convergent, more iterations).
 EVOX_API int evox_hip_ns_scal_floats() { return kScalFloats; }
 
+//
+// first_step = 1 replaces iteration 1 (Z₀ = I, so everything is a polynomial in Y₀) by the fifth-order step
+// Z₁ = p(Y₀), Y₁ = Y₀ p(Y₀) with the degree-4 polynomial above: 3 GEMMs and one elementwise pass instead of 1
+// GEMM, after which one standard iteration reaches what took two (error e → ≈ e⁵/2 instead of ¾e²).
 EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps, int safe, float* work,
                               const float* eye, float* vec, float* scal, const float* prev_sqrt,
-                              const float* prev_inv, float* out_sqrt, float* out_inv, int tune, void* stream_) {
+                              const float* prev_inv, float* out_sqrt, float* out_inv, int tune, int first_step,
+                              void* stream_) {
   if (n <= 0 || iters < 1 || power_steps < 1 || power_steps > kMaxPow) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nn = (size_t)n * n;
@@ -435,17 +465,33 @@ EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps,
   if (mv_blocks > kPartRow) mv_blocks = kPartRow;
   for (int j = 0; j < power_steps; ++j)
     ns_matvec_kernel<<<mv_blocks, 256, 0, stream>>>(C, n, vec + (j & 1) * n, vec + ((j + 1) & 1) * n, scal, j);
+  const bool poly4 = first_step == 1 && (nn & 3) == 0;
   ns_scale_kernel<<<evox::stream_grid((int64_t)nn, 256), 256, 0, stream>>>(C, n, Yb[0], Tb[0], scal, vec, power_steps,
-                                                                            safe, mv_blocks);
+                                                                            safe, mv_blocks, poly4 ? Zb[0] : nullptr);
   int e = evox::last_launch_status();
   if (e) return e;
-  // iteration 1 with Z₀ = I: Y₁ = Y₀ T, Z₁ = T
-  e = gemm(0, 0, 0, n, n, n, 1.f, Yb[0], n, Tb[0], n, 0.f, Yb[1], n, Yb[1], n, tune, stream);
-  if (e) return e;
-  const float* Y = Yb[1];
+  const float* Y;
   const float* Z = Tb[0];
   const float* Tlast = Tb[0];
   int yi = 0, zi = 0;
+  if (poly4) {
+    // A2 = Y₀², q = (c2 I + c3 Y₀) + c4 A2, p = (c0 I + c1 Y₀) + A2 q (in place over its linear part), Y₁ = Y₀ p
+    e = gemm(0, 0, 0, n, n, n, 1.f, Yb[0], n, Yb[0], n, 0.f, Yb[1], n, Yb[1], n, tune, stream);
+    if (e) return e;
+    ns_axpy_kernel<<<evox::stream_grid((int64_t)(nn >> 2), 256), 256, 0, stream>>>(Yb[1], kP4c4, Zb[0], (int64_t)nn);
+    e = evox::last_launch_status();
+    if (e) return e;
+    e = gemm(0, 0, 0, n, n, n, 1.f, Yb[1], n, Zb[0], n, 1.f, Tb[0], n, Tb[0], n, tune, stream);
+    if (e) return e;
+    e = gemm(0, 0, 0, n, n, n, 1.f, Yb[0], n, Tb[0], n, 0.f, Zb[1], n, Zb[1], n, tune, stream);
+    if (e) return e;
+    Y = Zb[1];
+  } else {
+    // iteration 1 with Z₀ = I: Y₁ = Y₀ T, Z₁ = T
+    e = gemm(0, 0, 0, n, n, n, 1.f, Yb[0], n, Tb[0], n, 0.f, Yb[1], n, Yb[1], n, tune, stream);
+    if (e) return e;
+    Y = Yb[1];
+  }
   for (int it = 1; it < iters; ++it) {
     float* Tn = Tb[it & 1];
     e = gemm(0, 0, 0, n, n, n, -0.5f, Z, n, Y, n, 1.5f, eye, n, Tn, n, tune, stream);

@@ -34,7 +34,9 @@ def _shape(shape: Shape):
 
 
 def _stream(t: torch.Tensor) -> int:
-    return torch.cuda.current_stream(t.device).cuda_stream
+    from ..ops._util import stream_of
+
+    return stream_of(t)
 
 
 def PRNGKey(seed: int, device=None) -> torch.Tensor:

@@ -6,7 +6,15 @@ import torch
 from .. import _native
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(t: torch.Tensor) -> int:
+    """Handle of the current HIP stream of ``t``'s device.  The raw query is used when the build has it:
+    constructing a ``torch.cuda.Stream`` object costs 4–5 µs, and a generation asks a dozen times."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

@@ -197,7 +197,7 @@ class NewtonSchulzSqrt:
                 self._host = torch.empty(2, dtype=torch.float32, pin_memory=True)
                 self._event = torch.cuda.Event()
             self._host.copy_(self._ws.scal[14:16], non_blocking=True)
-            self._event.record(torch.cuda.current_stream(C.device))
+            self._event.record()
             self._pending = (self._event, self._host, self.iters)
         return out
 
@@ -245,7 +245,7 @@ class NewtonSchulzSqrt:
                     self._host = torch.empty(1, dtype=torch.float32, pin_memory=True)
                     self._event = torch.cuda.Event()
                 self._host.copy_(res.reshape(1), non_blocking=True)
-                self._event.record(torch.cuda.current_stream(C.device))
+                self._event.record()
                 self._pending = (self._event, self._host, self.iters)
         else:
             self._pending = (None, res.reshape(1), self.iters)

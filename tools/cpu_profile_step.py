@@ -8,7 +8,8 @@ from evox_amd import algorithms, problems, workflows
 
 dev = torch.device("cuda")
 center = torch.zeros(1000, device=dev) + 2.0
-algo = algorithms.CMAES(center_init=center, init_stdev=1.0, pop_size=10000, decomposition="newton_schulz")
+precision = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+algo = algorithms.CMAES(center_init=center, init_stdev=1.0, pop_size=10000, decomposition="newton_schulz", precision=precision)
 wf = workflows.StdWorkflow(algo, problems.numerical.Ackley())
 state = wf.init(ex.PRNGKey(0))
 for _ in range(20):
@@ -28,5 +29,5 @@ for _ in range(300):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
 print(s.getvalue()[:9000])
