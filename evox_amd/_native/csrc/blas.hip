@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256) void ns_residual_kernel(const float* __restric
 __global__ __launch_bounds__(256) void ns_finish_kernel(const float* __restrict__ Y, const float* __restrict__ Z, int n,
                                                         float* scal, const float* __restrict__ prev_sqrt,
                                                         const float* __restrict__ prev_inv, float* __restrict__ out_sqrt,
-                                                        float* __restrict__ out_inv, int res_blocks) {
+                                                        float* __restrict__ out_inv, int res_blocks,
+                                                        uint16_t* __restrict__ out_sqrt_bf16) {
   __shared__ float ty[32][33], tz[32][33];
   __shared__ float red[4];
   const float res = 4.f * block_reduce(part_row(scal, kRowRes), res_blocks, false, red) / (float)n;  // (2‖T−I‖_F/√n)²
@@ -378,12 +379,12 @@ __global__ __launch_bounds__(256) void ns_finish_kernel(const float* __restrict_
     const int r = by + k, c = bx + tx;
     if (r < n && c < n) {
       const size_t i = (size_t)r * n + c;
-      if (keep) {
-        out_sqrt[i] = prev_sqrt[i];
-        out_inv[i] = prev_inv[i];
-      } else {
-        out_sqrt[i] = 0.5f * (Y[i] + ty[tx][k]) * rs;
-        out_inv[i] = 0.5f * (Z[i] + tz[tx][k]) * irs;
+      const float vs = keep ? prev_sqrt[i] : 0.5f * (Y[i] + ty[tx][k]) * rs;
+      out_sqrt[i] = vs;
+      out_inv[i] = keep ? prev_inv[i] : 0.5f * (Z[i] + tz[tx][k]) * irs;
+      if (out_sqrt_bf16 != nullptr) {                   // rounded copy for bf16-operand consumers (to nearest even)
+        const uint32_t u = __float_as_uint(vs);
+        out_sqrt_bf16[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
       }
     }
   }
@@ -454,7 +455,7 @@ EVOX_API int evox_hip_ns_scal_floats() { return kScalFloats; }
 EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps, int safe, float* work,
                               const float* eye, float* vec, float* scal, const float* prev_sqrt,
                               const float* prev_inv, float* out_sqrt, float* out_inv, int tune, int first_step,
-                              void* stream_) {
+                              void* out_sqrt_bf16, void* stream_) {
   if (n <= 0 || iters < 1 || power_steps < 1 || power_steps > kMaxPow) return (int)hipErrorInvalidValue;
   hipStream_t stream = (hipStream_t)stream_;
   const size_t nn = (size_t)n * n;
@@ -509,6 +510,7 @@ EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps,
   if (res_blocks > kPartRow) res_blocks = kPartRow;
   ns_residual_kernel<<<res_blocks, 256, 0, stream>>>(Tlast, n, scal);
   dim3 grid((n + 31) / 32, (n + 31) / 32);
-  ns_finish_kernel<<<grid, 256, 0, stream>>>(Y, Z, n, scal, prev_sqrt, prev_inv, out_sqrt, out_inv, res_blocks);
+  ns_finish_kernel<<<grid, 256, 0, stream>>>(Y, Z, n, scal, prev_sqrt, prev_inv, out_sqrt, out_inv, res_blocks,
+                                             (uint16_t*)out_sqrt_bf16);
   return evox::last_launch_status();
 }

@@ -57,7 +57,7 @@ class CMAES(Algorithm):
         if decomposition not in ("eigh", "newton_schulz"):
             raise ValueError("decomposition must be 'eigh' or 'newton_schulz'")
         self.decomposition = decomposition
-        self._ns = _cma.NewtonSchulzSqrt() if decomposition == "newton_schulz" else None
+        self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16") if decomposition == "newton_schulz" else None
         self.pop_size = 4 + math.floor(3 * math.log(self.dim)) if pop_size is None else int(pop_size)
         dev = self.center_init.device
         if recombination_weights is None:

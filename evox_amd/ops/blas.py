@@ -26,7 +26,7 @@ _native.register_hip_api({
     "evox_hip_gemm": (I, [I, I, I, I64, I64, I64, F, P, I64, P, I64, F, P, I64, P, I64, P, P, I, P]),
     "evox_hip_gemm_plan_info": (I, [I, I, I, I64, I64, I64, I64, I64, I64, I64, I, P]),
     "evox_hip_ns_scal_floats": (I, []),
-    "evox_hip_ns_sqrt": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P]),
+    "evox_hip_ns_sqrt": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P]),
 })
 
 _ready = None
@@ -149,12 +149,14 @@ def _first_step_default() -> str:
 
 
 def ns_sqrt(C: torch.Tensor, ws: NSWorkspace, iters: int, *, power_steps: int = 1, safe: bool = False,
-            prev: tuple | None = None, first_step: str | None = None):
+            prev: tuple | None = None, first_step: str | None = None, bf16_copy: bool = False):
     """``(sqrtC, invsqrtC)`` of the SPD matrix ``C`` after ``iters`` coupled Newton–Schulz steps.
 
     ``first_step``: ``"poly4"`` (default, or ``EVOX_AMD_NS_FIRST``) makes the first of them the fifth-order
     step built on the degree-4 Taylor polynomial of the inverse square root (3 products instead of 1, worth two
-    ordinary steps); ``"newton"`` keeps every step quadratic.
+    ordinary steps); ``"newton"`` keeps every step quadratic.  ``bf16_copy``: the final pass also writes the
+    square root rounded to bf16 and attaches it to the returned fp32 tensor as ``_evox_bf16`` (consumers that
+    feed it to a bf16 GEMM skip their own conversion pass).
 
     ``ws.scal[13:16]`` afterwards holds the scale used, the residual bound and a flag telling that
     the iteration failed to contract and ``prev`` (the previous factors) was passed through."""
@@ -170,9 +172,13 @@ def ns_sqrt(C: torch.Tensor, ws: NSWorkspace, iters: int, *, power_steps: int = 
         power_steps = 8          # first call: let the power vector settle
         ws.fresh = False
     ps, pi = (prev[0].contiguous(), prev[1].contiguous()) if prev is not None else (None, None)
+    out_b = torch.empty((n, n), dtype=torch.bfloat16, device=C.device) if bf16_copy else None
     check(hip().evox_hip_ns_sqrt(C.data_ptr(), n, int(iters), int(power_steps), int(bool(safe)), ws.work.data_ptr(),
                                  ws.eye.data_ptr(), ws.vec.data_ptr(), ws.scal.data_ptr(),
                                  ps.data_ptr() if ps is not None else None, pi.data_ptr() if pi is not None else None,
                                  out_s.data_ptr(), out_i.data_ptr(), _tune(),
-                                 int((first_step or _first_step_default()) == "poly4"), stream_of(C)), "ns_sqrt")
+                                 int((first_step or _first_step_default()) == "poly4"),
+                                 out_b.data_ptr() if out_b is not None else None, stream_of(C)), "ns_sqrt")
+    if out_b is not None:
+        out_s._evox_bf16 = out_b
     return out_s, out_i

@@ -127,8 +127,10 @@ class NewtonSchulzSqrt:
     raises or lowers its iteration count.  Since the covariance drifts slowly between
     generations the controller tracks the need with one generation of lag."""
 
-    def __init__(self, tol: float = 2e-6, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6):
+    def __init__(self, tol: float = 2e-6, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6,
+                 bf16_copy: bool = False):
         self.tol, self.min_iters, self.max_iters = tol, min_iters, max_iters
+        self.bf16_copy = bf16_copy        # also emit the square root rounded to bf16 (native driver only)
         self.iters = start_iters
         self._pending = None          # (event, host residual record, iters used)
         self.last_residual = None
@@ -189,7 +191,7 @@ class NewtonSchulzSqrt:
         safe = self.safe_calls > 0
         if safe and not capturing:
             self.safe_calls -= 1
-        out = _blas.ns_sqrt(C, self._ws, max(1, self.iters), power_steps=1, safe=safe, prev=prev)
+        out = _blas.ns_sqrt(C, self._ws, max(1, self.iters), power_steps=1, safe=safe, prev=prev, bf16_copy=self.bf16_copy)
         if capturing:
             self._graph_residual = self._ws.scal[14]
         elif self._pending is None:

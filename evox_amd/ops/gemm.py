@@ -106,7 +106,10 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
             # epilogue's bias vector
             try:
                 if precision == "bf16":
-                    return _blas.gemm(z.bfloat16(), bd.bfloat16(), trans_b=True, alpha=sig, bias=mean)
+                    # the factorisation may have left a rounded copy of B next to it
+                    b16 = getattr(B, "_evox_bf16", None) if D is None else None
+                    return _blas.gemm(z.bfloat16(), b16 if b16 is not None else bd.bfloat16(), trans_b=True, alpha=sig,
+                                      bias=mean)
                 return _blas.gemm(z, bd, trans_b=True, alpha=sig, bias=mean)
             except RuntimeError as e:
                 # a hipBLASLt build without this epilogue / scale mode: say so once, use the plain product
