@@ -14,6 +14,8 @@ from typing import Optional, Union
 
 import torch
 
+from ....ops.cma import small_svd_vt as _small_svd_vt
+
 from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.module import Stateful, use_state
@@ -547,7 +549,7 @@ class ASEBO(_ESBase):
         key, k_noise = rnd.split(state.key)
         h = self.pop_size // 2
         X = state.grad_subspace - state.grad_subspace.mean(0)
-        _, _, Vt = torch.linalg.svd(X, full_matrices=False)
+        Vt = _small_svd_vt(X)
         U, U_ort = Vt[:h], Vt[h:]
         ready = state.gen_counter > self.subspace_dims
         UUT = U.T @ U if ready else torch.zeros_like(state.UUT)
