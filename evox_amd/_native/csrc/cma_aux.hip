@@ -25,40 +25,49 @@ __global__ __launch_bounds__(256) void gather_scale_kernel(const float* __restri
                                                            const float* __restrict__ rowscale, const float* __restrict__ sigma,
                                                            T* __restrict__ out, float* __restrict__ colsum, int mu, int n) {
   const float inv_sigma = 1.0f / sigma[0];
-  if constexpr (sizeof(T) == 4) {
-    // rows on 16-byte boundaries: four columns per lane, two rows in flight
-    if ((n & 3) == 0 && (ldpop & 3) == 0 && (((uintptr_t)pop | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)colsum) & 15) == 0) {
-      for (int c = threadIdx.x * 4; c < n; c += blockDim.x * 4) {
-        const float4 m = *reinterpret_cast<const float4*>(mean + c);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int i = blockIdx.x;
-        for (; i + (int)gridDim.x < mu; i += 2 * gridDim.x) {
-          const int i2 = i + gridDim.x;
-          const float r1 = rowscale[i], r2 = rowscale[i2];
-          const float4 x1 = *reinterpret_cast<const float4*>(pop + order[i] * ldpop + c);
-          const float4 x2 = *reinterpret_cast<const float4*>(pop + order[i2] * ldpop + c);
-          const float4 d1 = make_float4(x1.x - m.x, x1.y - m.y, x1.z - m.z, x1.w - m.w);
-          const float4 d2 = make_float4(x2.x - m.x, x2.y - m.y, x2.z - m.z, x2.w - m.w);
-          const float s1 = r1 * inv_sigma, s2 = r2 * inv_sigma;
-          *reinterpret_cast<float4*>((float*)out + (int64_t)i * n + c) = make_float4(d1.x * s1, d1.y * s1, d1.z * s1, d1.w * s1);
-          *reinterpret_cast<float4*>((float*)out + (int64_t)i2 * n + c) = make_float4(d2.x * s2, d2.y * s2, d2.z * s2, d2.w * s2);
-          const float q1 = r1 * r1, q2 = r2 * r2;
-          acc.x = fmaf(q1, d1.x, acc.x); acc.y = fmaf(q1, d1.y, acc.y); acc.z = fmaf(q1, d1.z, acc.z); acc.w = fmaf(q1, d1.w, acc.w);
-          acc.x = fmaf(q2, d2.x, acc.x); acc.y = fmaf(q2, d2.y, acc.y); acc.z = fmaf(q2, d2.z, acc.z); acc.w = fmaf(q2, d2.w, acc.w);
-        }
-        for (; i < mu; i += gridDim.x) {
-          const float r1 = rowscale[i];
-          const float4 x1 = *reinterpret_cast<const float4*>(pop + order[i] * ldpop + c);
-          const float4 d1 = make_float4(x1.x - m.x, x1.y - m.y, x1.z - m.z, x1.w - m.w);
-          const float s1 = r1 * inv_sigma;
-          *reinterpret_cast<float4*>((float*)out + (int64_t)i * n + c) = make_float4(d1.x * s1, d1.y * s1, d1.z * s1, d1.w * s1);
-          const float q1 = r1 * r1;
-          acc.x = fmaf(q1, d1.x, acc.x); acc.y = fmaf(q1, d1.y, acc.y); acc.z = fmaf(q1, d1.z, acc.z); acc.w = fmaf(q1, d1.w, acc.w);
-        }
-        *reinterpret_cast<float4*>(colsum + (int64_t)blockIdx.x * n + c) = acc;
-      }
-      return;
+  // rows on 16-byte boundaries: four columns per lane (one 16-byte load; a 16- or 8-byte store), two rows in flight
+  auto store4 = [&](int64_t row, int c, float4 v) {
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>((float*)out + row * n + c) = v;
+    } else {
+      const uint32_t lo = (uint32_t)to_bf16(v.x) | ((uint32_t)to_bf16(v.y) << 16);
+      const uint32_t hi = (uint32_t)to_bf16(v.z) | ((uint32_t)to_bf16(v.w) << 16);
+      *reinterpret_cast<uint2*>((uint16_t*)out + row * n + c) = make_uint2(lo, hi);
     }
+  };
+  constexpr uintptr_t kOutAlign = sizeof(T) == 4 ? 15 : 7;
+  if ((n & 3) == 0 && (ldpop & 3) == 0 && (((uintptr_t)pop | (uintptr_t)mean | (uintptr_t)colsum) & 15) == 0 &&
+      ((uintptr_t)out & kOutAlign) == 0) {
+    for (int c = threadIdx.x * 4; c < n; c += blockDim.x * 4) {
+      const float4 m = *reinterpret_cast<const float4*>(mean + c);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      int i = blockIdx.x;
+      for (; i + (int)gridDim.x < mu; i += 2 * gridDim.x) {
+        const int i2 = i + gridDim.x;
+        const float r1 = rowscale[i], r2 = rowscale[i2];
+        const float4 x1 = *reinterpret_cast<const float4*>(pop + order[i] * ldpop + c);
+        const float4 x2 = *reinterpret_cast<const float4*>(pop + order[i2] * ldpop + c);
+        const float4 d1 = make_float4(x1.x - m.x, x1.y - m.y, x1.z - m.z, x1.w - m.w);
+        const float4 d2 = make_float4(x2.x - m.x, x2.y - m.y, x2.z - m.z, x2.w - m.w);
+        const float s1 = r1 * inv_sigma, s2 = r2 * inv_sigma;
+        store4(i, c, make_float4(d1.x * s1, d1.y * s1, d1.z * s1, d1.w * s1));
+        store4(i2, c, make_float4(d2.x * s2, d2.y * s2, d2.z * s2, d2.w * s2));
+        const float q1 = r1 * r1, q2 = r2 * r2;
+        acc.x = fmaf(q1, d1.x, acc.x); acc.y = fmaf(q1, d1.y, acc.y); acc.z = fmaf(q1, d1.z, acc.z); acc.w = fmaf(q1, d1.w, acc.w);
+        acc.x = fmaf(q2, d2.x, acc.x); acc.y = fmaf(q2, d2.y, acc.y); acc.z = fmaf(q2, d2.z, acc.z); acc.w = fmaf(q2, d2.w, acc.w);
+      }
+      for (; i < mu; i += gridDim.x) {
+        const float r1 = rowscale[i];
+        const float4 x1 = *reinterpret_cast<const float4*>(pop + order[i] * ldpop + c);
+        const float4 d1 = make_float4(x1.x - m.x, x1.y - m.y, x1.z - m.z, x1.w - m.w);
+        const float s1 = r1 * inv_sigma;
+        store4(i, c, make_float4(d1.x * s1, d1.y * s1, d1.z * s1, d1.w * s1));
+        const float q1 = r1 * r1;
+        acc.x = fmaf(q1, d1.x, acc.x); acc.y = fmaf(q1, d1.y, acc.y); acc.z = fmaf(q1, d1.z, acc.z); acc.w = fmaf(q1, d1.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(colsum + (int64_t)blockIdx.x * n + c) = acc;
+    }
+    return;
   }
   for (int c = threadIdx.x; c < n; c += blockDim.x) {
     const float m = mean[c];
