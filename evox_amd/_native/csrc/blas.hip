@@ -336,19 +336,26 @@ __global__ __launch_bounds__(256) void ns_axpy_kernel(const float* __restrict__ 
     q[i] += c * a[i];
 }
 
+// Mean-square deviation of T from the identity, estimated from every kResStride-th row (the deviation is
+// spread over the whole matrix — it is a polynomial in the scaled covariance — and a non-finite entry reaches
+// every row within one product, so a row sample serves both the iteration control and the output guard).
+constexpr int kResStride = 8;
+
 __global__ __launch_bounds__(256) void ns_residual_kernel(const float* __restrict__ T, int n, float* scal) {
-  const int64_t total = (int64_t)n * n;
+  const int rows = (n + kResStride - 1) / kResStride;
+  const int64_t total = (int64_t)rows * n;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
-    const float d = T[i] - (r == c ? 1.f : 0.f);
+    const int r = (int)(i / n) * kResStride, c = (int)(i % n);
+    const float d = T[(int64_t)r * n + c] - (r == c ? 1.f : 0.f);
     acc += d * d;
   }
   acc = evox::wave_sum(acc);
   __shared__ float part[4];
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) part_row(scal, kRowRes)[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+  if (threadIdx.x == 0)
+    part_row(scal, kRowRes)[blockIdx.x] = ((part[0] + part[1]) + (part[2] + part[3])) * ((float)n / (float)rows);
 }
 
 // sqrtC = ½(Y+Yᵀ)√s, invsqrtC = ½(Z+Zᵀ)/√s through 32×32 LDS tiles; when the residual shows the
@@ -506,7 +513,7 @@ EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps,
     Y = Yn; Z = Zn; Tlast = Tn;
     yi ^= 1; zi ^= 1;
   }
-  int res_blocks = evox::stream_grid((int64_t)nn, 256);
+  int res_blocks = evox::stream_grid((int64_t)((n + kResStride - 1) / kResStride) * n, 256);
   if (res_blocks > kPartRow) res_blocks = kPartRow;
   ns_residual_kernel<<<res_blocks, 256, 0, stream>>>(Tlast, n, scal);
   dim3 grid((n + 31) / 32, (n + 31) / 32);

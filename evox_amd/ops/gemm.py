@@ -151,7 +151,7 @@ def cma_elite_factor(pop, order, mean, sigma, sqrt_w, precision="fp32"):
     sig = torch.as_tensor(sigma, dtype=torch.float32, device=dev).reshape(1)
     bf16 = precision == "bf16"
     out = torch.empty((mu, n), dtype=torch.bfloat16 if bf16 else torch.float32, device=dev)
-    blocks = max(1, min(mu, 512))
+    blocks = max(1, min(mu, int(os.environ.get("EVOX_AMD_GATHER_BLOCKS", "512"))))
     colsum = torch.empty((blocks, n), dtype=torch.float32, device=dev)
     check(hip().evox_hip_cma_gather_scale(pop.data_ptr(), pop.stride(0), order.contiguous().data_ptr(),
                                           mean.contiguous().data_ptr(), sqrt_w.contiguous().data_ptr(), sig.data_ptr(),
