@@ -52,3 +52,51 @@ def test_cast_population_keeps_shape_and_values():
 def test_fused_variation_is_not_claimed_on_host():
     x = torch.rand(10, 4)
     assert not variation.sbx_pm_supported(x, torch.zeros(4), torch.ones(4))
+
+
+def test_cdist_host_paths_and_argument_checks():
+    from evox_amd.ops.distance import cdist
+
+    g = torch.Generator().manual_seed(0)
+    a, b = torch.rand(7, 3, generator=g), torch.rand(5, 3, generator=g)
+    ref = (a[:, None, :] - b[None, :, :])
+    assert torch.allclose(cdist(a, b), ref.square().sum(-1).sqrt(), atol=1e-6)
+    assert torch.allclose(cdist(a, b, squared=True), ref.square().sum(-1), atol=1e-6)
+    assert torch.allclose(cdist(a, b, p=1.0), ref.abs().sum(-1), atol=1e-6)
+    assert torch.allclose(cdist(a, b, p=float("inf")), ref.abs().amax(-1), atol=1e-6)
+    with pytest.raises(ValueError):
+        cdist(a, b, p=3.0)
+    with pytest.raises(ValueError):
+        cdist(a, b[:, :2])
+
+
+def test_segmented_crowding_equals_per_group_crowding():
+    from evox_amd.ops import nds
+
+    g = torch.Generator().manual_seed(1)
+    costs = torch.rand(60, 3, generator=g)
+    group = torch.randint(0, 4, (60,), generator=g)
+    mask = torch.rand(60, generator=g) < 0.8
+    got = nds.segmented_crowding_distance(costs, group, mask, 4)
+    for k in range(4):
+        sel = mask & (group == k)
+        want = nds.crowding_distance(costs, sel)
+        assert torch.allclose(got[sel], want[sel], atol=1e-6, equal_nan=True)
+    assert torch.isinf(got[~mask]).all() and (got[~mask] < 0).all()
+
+
+def test_small_solve_host_path_and_crowd_remove_reference():
+    from evox_amd.ops import linalg_small, moselect
+
+    A = torch.tensor([[2.0, 1.0, 0.0], [0.0, 3.0, 1.0], [1.0, 0.0, 4.0]])
+    x, ok = linalg_small.solve_small(A, torch.ones(3))
+    assert bool(ok) and torch.allclose(A @ x, torch.ones(3), atol=1e-5)
+    _, ok = linalg_small.solve_small(torch.ones(3, 3), torch.ones(3))
+    assert not bool(ok)
+    g = torch.Generator().manual_seed(2)
+    pts = torch.rand(30, 2, generator=g)
+    d = torch.cdist(pts, pts)
+    d.fill_diagonal_(float("inf"))
+    big_r = (d / d.amin(1).mean() / 2).clamp_max(1.0)
+    keep = moselect.crowd_remove(big_r, 12)                 # host tensors: the reference loop
+    assert keep.dtype == torch.bool and int(keep.sum()) == 18
