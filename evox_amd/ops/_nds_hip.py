@@ -18,6 +18,7 @@ _native.register_hip_api({
 MAX_OBJECTIVES = 8
 _ROUNDS_PER_CHECK = 4           # rounds issued before the first host check; doubles up to _MAX_ROUNDS_PER_CHECK
 _MAX_ROUNDS_PER_CHECK = 32
+_GROW_BATCH_MAX_N = 16384        # beyond this a peeling round costs more than a read-back: no speculative rounds
 
 
 def supported(x: torch.Tensor) -> bool:
@@ -52,8 +53,9 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     cur = 0
     batch = _ROUNDS_PER_CHECK
     while True:
-        # peeling rounds are issued in growing batches between host checks: populations with dozens of fronts
-        # then cost a handful of read-backs, and rounds issued past the last front find nothing to do
+        # small populations: peeling rounds are issued in growing batches between host checks, so that dozens of
+        # fronts cost a handful of read-backs (a round past the target is cheap there; for large populations it
+        # is not, and the batch stays at four)
         before = cur
         for _ in range(batch):
             check(lib.evox_hip_nds_round(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), front.data_ptr(),
@@ -65,7 +67,8 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
         ranked = int(host[-1])
         if ranked >= target or cur >= n or ranked == (int(host[before - 1]) if before > 0 else 0):
             break
-        batch = min(2 * batch, _MAX_ROUNDS_PER_CHECK)
+        if n <= _GROW_BATCH_MAX_N:
+            batch = min(2 * batch, _MAX_ROUNDS_PER_CHECK)
     host_sizes = host.tolist()
     # the front at which the target was reached; everything later collapses into one index
     cut = next((k for k, c in enumerate(host_sizes) if c >= target), cur - 1)
