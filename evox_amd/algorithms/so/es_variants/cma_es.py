@@ -137,7 +137,12 @@ class CMAES(Algorithm):
         z = self._whiten(state, delta) / state.sigma
         ps = (1 - self.cs) * state.ps + math.sqrt(self.cs * (2 - self.cs) * self.mueff) * z
         ps_norm = torch.linalg.vector_norm(ps)
-        denom = math.sqrt(1 - (1 - self.cs) ** (2 * state.count_iter))
+        try:
+            # device-side generation counter: the bias correction then follows the counter when the step is
+            # replayed from a recorded graph (a Python integer would be frozen into the recording)
+            denom = torch.sqrt(1 - (1 - self.cs) ** (2 * state.count_iter_dev))
+        except AttributeError:
+            denom = math.sqrt(1 - (1 - self.cs) ** (2 * state.count_iter))
         hsig = (ps_norm / denom < (1.4 + 2 / (self.dim + 1)) * self.chiN).to(torch.float32)
         pc = (1 - self.cc) * state.pc + hsig * math.sqrt(self.cc * (2 - self.cc) * self.mueff) * delta / state.sigma
         sigma = state.sigma * torch.exp((self.cs / self.damps) * (ps_norm / self.chiN - 1))
@@ -282,6 +287,7 @@ class SepCMAES(CMAES):
         dev = self.center_init.device
         return State(pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev),
                      C=torch.ones(self.dim, device=dev), count_iter=0, mean=self.center_init,
+                     count_iter_dev=torch.zeros((), device=dev),
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
@@ -291,11 +297,15 @@ class SepCMAES(CMAES):
     def graph_signature(self, state):
         return ()
 
+    def graph_host_counters(self):
+        return ("count_iter",)                 # only counts; the device work reads count_iter_dev
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
         noise = rnd.normal(sample_key, (self.pop_size, self.dim))
         population = state.mean + state.sigma * torch.sqrt(state.C) * noise
-        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
 
     def _whiten(self, state, delta):
         return delta / torch.sqrt(state.C)

@@ -22,6 +22,7 @@ class MAES(CMAES):
         dev = self.center_init.device
         return State(pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev),
                      M=torch.eye(self.dim, device=dev), count_iter=0, mean=self.center_init,
+                     count_iter_dev=torch.zeros((), device=dev),
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
@@ -31,11 +32,15 @@ class MAES(CMAES):
     def graph_signature(self, state):
         return ()
 
+    def graph_host_counters(self):
+        return ("count_iter",)                 # only counts; the device work reads count_iter_dev
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
         ones = torch.ones(self.dim, device=state.M.device)
         population = _cma.sample(sample_key, state.mean, state.sigma, state.M, ones, self.pop_size, self.precision)
-        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
 
     def _whiten(self, state, delta):
         return state.M @ delta
@@ -128,16 +133,21 @@ class IndependentAMaLGaM(AMaLGaM):
         dev = self.center_init.device
         return State(pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev),
                      C=torch.ones(self.dim, device=dev), count_iter=0, mean=self.center_init,
+                     count_iter_dev=torch.zeros((), device=dev),
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev), noise_key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
     def graph_signature(self, state):
         return ()
 
+    def graph_host_counters(self):
+        return ("count_iter",)                 # only counts; the device work reads count_iter_dev
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
         population = _es.perturb(sample_key, state.mean, state.sigma * torch.sqrt(state.C), self.pop_size)
-        return population, state.replace(population=population, count_iter=state.count_iter + 1, key=key)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
 
     def _whiten(self, state, delta):
         return delta / torch.sqrt(state.C)
