@@ -43,7 +43,7 @@ class JaDE(DEBase):
 
     def _fused_tell_ok(self, state):
         # the fused kernels replace the whole population at once
-        return (_adapt.supported(state.population) and self.batch_size == self.pop_size and state.start_index == 0)
+        return (_adapt.supported(state.population) and self.batch_size == self.pop_size)
 
     def ask(self, state):
         key, k_var, kF, kCR = rnd.split(state.key, 4)
@@ -72,7 +72,7 @@ class JaDE(DEBase):
         # the previous means instead
         F_u = torch.where(n_ok > 0, (1 - self.c) * state.F_u + self.c * _nan_to(lehmer), state.F_u)
         CR_u = torch.where(n_ok > 0, (1 - self.c) * state.CR_u + self.c * _nan_to(mean_cr), state.CR_u)
-        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start, start_index_dev=self._next_start_dev(state),
                              F_u=F_u, CR_u=CR_u)
 
 
@@ -127,7 +127,7 @@ class SHADE(JaDE):
         rolled = torch.cat([torch.stack([M_F, M_CR])[:, None], rolled[:, 1:]], dim=1)
         valid = (total > 0) & torch.isfinite(M_F) & torch.isfinite(M_CR)
         memory = torch.where(valid, rolled, state.Memory_FCR)
-        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start, start_index_dev=self._next_start_dev(state),
                              Memory_FCR=memory)
 
     def migrate(self, state, foreign_population, foreign_fitness):
@@ -216,7 +216,7 @@ class SaDE(DEBase):
         pos = torch.arange(LP, device=dev)[:, None]
         shifted = torch.gather(state.CR_memory, 0, (pos - cnt).clamp_min(0))
         CR_memory = torch.where(pos < cnt, vals, shifted)
-        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start, start_index_dev=self._next_start_dev(state),
                              success_memory=success_memory, failure_memory=failure_memory, CR_memory=CR_memory)
 
 
@@ -259,4 +259,4 @@ class CoDE(DEBase):
         best_fit = fit3[which, cols]
         best_vec = state.trial_vectors.reshape(3, b, self.dim)[which, cols]
         population, fitness, best_index, start, _, _ = self._select(state, best_vec, best_fit)
-        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start, start_index_dev=self._next_start_dev(state))

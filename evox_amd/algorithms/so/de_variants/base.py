@@ -45,13 +45,21 @@ class DEBase(Algorithm):
         state_key, init_key = rnd.split(key.to(dev))
         pop, fit = self._init_population(init_key, getattr(self, "mean", None), getattr(self, "stdvar", None))
         return State(population=pop, fitness=fit, best_index=torch.zeros((), dtype=torch.int64, device=dev),
-                     start_index=0, key=state_key,
+                     start_index=0, start_index_dev=torch.zeros((), dtype=torch.int64, device=dev), key=state_key,
                      trial_vectors=torch.zeros((trial_rows or self.batch_size, self.dim), device=dev), **extra)
 
     def _window(self, state):
-        s = state.start_index
-        idx = torch.arange(s, s + self.batch_size, device=self.lb.device)
-        return idx % self.pop_size if s + self.batch_size > self.pop_size else idx
+        """Rows varied this generation.  The offset is read from its device copy, so a recorded step follows
+        the moving window when it is replayed."""
+        if self.batch_size == self.pop_size:
+            return torch.arange(self.pop_size, device=self.lb.device)
+        return (torch.arange(self.batch_size, device=self.lb.device) + state.start_index_dev) % self.pop_size
+
+    def _next_start_dev(self, state):
+        return (state.start_index_dev + self.batch_size) % self.pop_size
+
+    def graph_host_counters(self):
+        return (("start_index", self.pop_size),)      # wraps around; the device work reads start_index_dev
 
     def _select(self, state, trial_vectors, trial_fitness):
         """Greedy replacement inside the window; returns (population, fitness, best_index,
@@ -61,7 +69,7 @@ class DEBase(Algorithm):
         better = trial_fitness < parent_fit if self.strict_improvement else trial_fitness <= parent_fit
         new_rows = torch.where(better[:, None], trial_vectors, state.population[idx])
         new_fit = torch.where(better, trial_fitness, parent_fit)
-        if self.batch_size == self.pop_size and state.start_index == 0:
+        if self.batch_size == self.pop_size:
             population, fitness = new_rows, new_fit
         else:
             population = state.population.index_copy(0, idx, new_rows)
@@ -72,7 +80,8 @@ class DEBase(Algorithm):
 
     def tell(self, state, trial_fitness):
         population, fitness, best_index, start, _, _ = self._select(state, state.trial_vectors, trial_fitness)
-        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start)
+        return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+                             start_index_dev=self._next_start_dev(state))
 
     # -- batched strategy evaluation -----------------------------------------------------
     def _strategy_trials(self, key, state, idx, prim, sec, num_diff, cross, F, CR, diff_padding_num, replace=False,

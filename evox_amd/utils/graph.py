@@ -47,10 +47,12 @@ class GraphedStep:
     def __init__(self, fn: Callable, warmup: int = 2, clone_outputs: bool = True, host_counters=()):
         """``host_counters``: tree paths (as reported by ``tree_paths``) of integer state leaves that
         the step advances by a constant and never uses in its device work – they are advanced on
-        the host at replay.  Any other host value that changes makes the capture fail, because
+        the host at replay; a ``(path, modulus)`` pair names a counter that wraps around.  Any other host value that changes makes the capture fail, because
         a branch or a coefficient derived from it would be frozen into the recording."""
         self.fn, self.warmup, self.clone_outputs = fn, warmup, clone_outputs
-        self.host_counters = set(host_counters)
+        # path -> modulus (None: plain counter); entries are paths or (path, modulus) pairs
+        self.host_counters = {(c if isinstance(c, str) else c[0]): (None if isinstance(c, str) else int(c[1]))
+                              for c in host_counters}
         self.graph = None
         self._sig = None
         self.replays = 0
@@ -101,7 +103,8 @@ class GraphedStep:
                 continue
             name = paths[i] if i < len(paths) else f"#{i}"
             if name in self.host_counters and isinstance(old, int) and isinstance(new, int) and not isinstance(old, bool):
-                self._counters[i] = new - old
+                mod = self.host_counters[name]
+                self._counters[i] = (new - old, None) if mod is None else ((new - old) % mod, mod)
             else:
                 self.graph = None
                 raise GraphCaptureError(f"host value {name!r} of the state changes during the step ({old!r} -> {new!r}); "
@@ -119,7 +122,7 @@ class GraphedStep:
         self.graph.replay()
         self.replays += 1
         outs = [(l.clone() if self.clone_outputs else l) if isinstance(l, torch.Tensor) else l for l in self._static_out]
-        for i, delta in self._counters.items():          # state leaves come first in the output
-            outs[i] = leaves[i] + delta
+        for i, (delta, mod) in self._counters.items():   # state leaves come first in the output
+            outs[i] = leaves[i] + delta if mod is None else (leaves[i] + delta) % mod
         out = _tree.tree_unflatten(self._out_treedef, outs)
         return out

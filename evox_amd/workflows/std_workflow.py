@@ -218,7 +218,10 @@ class StdWorkflow(Workflow):
             if self.migrate_helper is not None or self.external_problem:
                 raise ValueError("graph_step cannot record host-side evaluation or migration")
             extra = getattr(self.algorithm, "graph_host_counters", None)
-            counters = ["fields/generation"] + [f"children/algorithm/fields/{c}" for c in (extra() if extra else ())]
+            counters = ["fields/generation"]
+            for c in (extra() if extra else ()):         # names, or (name, modulus) for counters that wrap around
+                counters.append(f"children/algorithm/fields/{c}" if isinstance(c, str)
+                                else (f"children/algorithm/fields/{c[0]}", c[1]))
             self._graphed = GraphedStep(self._bare_step, host_counters=counters)
         hooks = self.registered_hooks
         for m in hooks["pre_step"]:

@@ -885,3 +885,24 @@ def test_zdt_kernel_matches_tensor_formulation(name):
     got2, _ = prob.evaluate(None, view)
     want2, _ = prob.evaluate(None, view.cpu().double())
     assert torch.allclose(got2.cpu().double(), want2, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_graph_replay_follows_a_wrapping_de_window():
+    """DE varies a window of ``batch_size`` rows that moves (and wraps) every generation: the recorded step reads
+    the offset from its device copy and the host copy is advanced modulo the population size at replay."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    dev = torch.device("cuda")
+    lb, ub = torch.full((6,), -5.0, device=dev), torch.full((6,), 5.0, device=dev)
+    finals = []
+    for graph in (False, True):
+        wf = workflows.StdWorkflow(algorithms.DE(lb, ub, 50, batch_size=20), problems.numerical.Rastrigin(), graph_step=graph)
+        state = wf.init(ex.PRNGKey(9).to(dev))
+        for _ in range(14):                                  # the window wraps several times
+            state = wf.step(state)
+        finals.append(state.get_child_state("algorithm"))
+    a, b = finals
+    assert a.start_index == b.start_index == int(b.start_index_dev)
+    assert torch.equal(a.population, b.population) and torch.equal(a.fitness, b.fitness)
