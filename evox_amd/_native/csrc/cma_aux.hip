@@ -134,8 +134,11 @@ __global__ __launch_bounds__(1024) void cma_paths_kernel(const float* __restrict
     mean_out[c] = fmaf(k.cm, st, mean[c]);
     pc_out[c] = (1.f - k.cc) * pc[c] + b * st;
   }
+  const float sigma_new = sg * expf((k.cs / k.damps) * (norm / k.chiN - 1.f));
+  // scalars[4 .. 4+n): sigma' repeated — the per-column scale vector the sampling GEMM's epilogue reads
+  for (int c = threadIdx.x; c < n; c += blockDim.x) scalars[4 + c] = sigma_new;
   if (threadIdx.x == 0) {
-    scalars[0] = sg * expf((k.cs / k.damps) * (norm / k.chiN - 1.f));                         // sigma'
+    scalars[0] = sigma_new;                                                                   // sigma'
     scalars[1] = (1.f - k.c1 - k.cmu) + k.c1 * (1.f - hsig) * k.cc * (2.f - k.cc);            // alpha
     scalars[2] = hsig;
     scalars[3] = norm;

@@ -101,6 +101,11 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
                        dtype=torch.bfloat16 if precision == "bf16" else torch.float32)
         bd = B if D is None else B * D                            # (n, n): column j of B scaled by d_j
         sig = torch.as_tensor(sigma, dtype=torch.float32, device=mean.device).reshape(1)
+        vec = getattr(sigma, "_evox_vec", None)         # σ already expanded by the path kernel
+        if vec is not None and vec.numel() == n and vec.data_ptr() % 16 == 0 and vec.device == mean.device:
+            sig_vec = vec
+        else:
+            sig_vec = sig
         if impl != "mfma" and _blas.available() and _epilogue_ok[0]:
             # mean + σ·Z·(B∘d)ᵀ from the GEMM alone: σ is read on the device, the mean is the
             # epilogue's bias vector
@@ -108,9 +113,9 @@ def cma_sample(key, mean, sigma, B, D, pop_size, precision="fp32", row_offset=0)
                 if precision == "bf16":
                     # the factorisation may have left a rounded copy of B next to it
                     b16 = getattr(B, "_evox_bf16", None) if D is None else None
-                    return _blas.gemm(z.bfloat16(), b16 if b16 is not None else bd.bfloat16(), trans_b=True, alpha=sig,
+                    return _blas.gemm(z.bfloat16(), b16 if b16 is not None else bd.bfloat16(), trans_b=True, alpha=sig_vec,
                                       bias=mean)
-                return _blas.gemm(z, bd, trans_b=True, alpha=sig, bias=mean)
+                return _blas.gemm(z, bd, trans_b=True, alpha=sig_vec, bias=mean)
             except RuntimeError as e:
                 # a hipBLASLt build without this epilogue / scale mode: say so once, use the plain product
                 import warnings
@@ -169,14 +174,16 @@ def cma_paths(mean, step, whitened, ps, pc, sigma, iter_dev, consts):
     n = mean.shape[0]
     dev = mean.device
     mean_out, ps_out, pc_out = torch.empty_like(mean), torch.empty_like(ps), torch.empty_like(pc)
-    scalars = torch.empty(4, dtype=torch.float32, device=dev)
+    scalars = torch.empty(4 + n, dtype=torch.float32, device=dev)         # 4 scalars, then sigma' repeated n times
     c_arr = (ctypes.c_float * 8)(*[float(v) for v in consts])
     check(hip().evox_hip_cma_paths(mean.contiguous().data_ptr(), step.contiguous().data_ptr(),
                                    whitened.contiguous().data_ptr(), ps.contiguous().data_ptr(), pc.contiguous().data_ptr(),
                                    sigma.reshape(1).data_ptr(), iter_dev.reshape(1).data_ptr(), ctypes.addressof(c_arr), n,
                                    mean_out.data_ptr(), ps_out.data_ptr(), pc_out.data_ptr(), scalars.data_ptr(),
                                    stream_of(mean)), "cma_paths")
-    return mean_out, ps_out, pc_out, scalars[0], scalars[1], scalars[2]
+    sigma_new = scalars[0]
+    sigma_new._evox_vec = scalars[4:]                  # consumed by cma_sample (scale vector of the GEMM epilogue)
+    return mean_out, ps_out, pc_out, sigma_new, scalars[1], scalars[2]
 
 
 def cma_covariance_base(C, pc, alpha, c1):
