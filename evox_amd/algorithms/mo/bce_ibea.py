@@ -14,13 +14,12 @@ from __future__ import annotations
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...ops import moselect as _sel
+from ...ops.distance import cdist as _cdist
 from .common import MOAlgorithm
 from .indicator import ibea_fitness_only, ibea_survivors
 

@@ -11,8 +11,6 @@ import math
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-
 from ... import _native
 from ...core import random as rnd
 from ...core.state import State
@@ -22,6 +20,7 @@ from ...ops import moselect as _sel
 from ...ops._util import check as _check
 from ...ops._util import hip as _hip
 from ...ops._util import stream_of as _stream_of
+from ...ops.distance import cdist as _cdist
 from ...utils.common import cal_max, dominate_relation
 from .common import MOAlgorithm
 

@@ -4,14 +4,13 @@ from __future__ import annotations
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-from ...ops.linalg_small import solve_small
-
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import selection
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
+from ...ops.distance import cdist as _cdist
+from ...ops.linalg_small import solve_small
 from ...utils.common import cos_dist
 from .common import MOAlgorithm
 

@@ -12,12 +12,11 @@ import math
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
 from ...operators.sampling import LatinHypercubeSampling, UniformSampling
+from ...ops.distance import cdist as _cdist
 from ...utils.common import AggregationFunction
 from .common import MOAlgorithm
 

@@ -6,14 +6,13 @@ import math
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-
 from ...core import random as rnd
-from ...ops import nds as _nds
 from ...core.state import State
 from ...operators import crossover, selection
 from ...operators.sampling import LatinHypercubeSampling, UniformSampling
 from ...operators.selection.non_dominate import crowding_distance, non_dominated_sort
+from ...ops import nds as _nds
+from ...ops.distance import cdist as _cdist
 from ...utils.common import AggregationFunction, cos_dist
 from .common import MOAlgorithm, rank_crowding_truncate
 from .moead import _scatter_best

@@ -14,13 +14,12 @@ from typing import Optional, Union
 
 import torch
 
-from ....ops.cma import small_svd_vt as _small_svd_vt
-
 from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.module import Stateful, use_state
 from ....core.state import State
 from ....ops import es as _es
+from ....ops.cma import small_svd_vt as _small_svd_vt
 from ....utils import optimizers as optim
 
 

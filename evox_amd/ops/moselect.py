@@ -7,8 +7,6 @@ persistent single-workgroup launch on the GPU (``csrc/moselect.hip``).  The ``*_
 functions are straightforward PyTorch versions used as oracles."""
 from __future__ import annotations
 
-import ctypes
-
 import torch
 
 from .. import _native

@@ -14,12 +14,11 @@ import math
 
 import torch
 
-from ...ops.distance import cdist as _cdist
-
 from ...core.problem import Problem
 from ...core.state import State
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
+from ...ops.distance import cdist as _cdist
 from .dtlz import _chain, _multimodal_g
 from .lsmop import _dtlz7_front, _griewank, _rastrigin, _rosenbrock, _sphere, chaotic_group_sizes, grouped_g
 
