@@ -10,6 +10,7 @@ import torch
 
 from ....core import random as rnd
 from ....ops import de_adapt as _adapt
+from ....ops import sort as _sort
 from .base import ARITH, BEST, BIN, CURRENT, EXP, PBEST, RAND, DEBase
 
 
@@ -133,7 +134,7 @@ class SHADE(JaDE):
     def migrate(self, state, foreign_population, foreign_fitness):
         """Island-model hook: the immigrants replace the worst residents they improve on."""
         k = foreign_fitness.shape[0]
-        worst = torch.topk(state.fitness, k, largest=True).indices
+        worst = _sort.select_indices(state.fitness, k, largest=True)
         better = foreign_fitness < state.fitness[worst]
         pop = state.population.index_copy(0, worst, torch.where(better[:, None], foreign_population,
                                                                 state.population[worst]))

@@ -13,6 +13,7 @@ import torch
 from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.state import State
+from ....ops import sort as _sort
 
 # base-vector codes of the strategy tables (rand, best, pbest, current) and crossover codes
 RAND, BEST, PBEST, CURRENT = 0, 1, 2, 3
@@ -110,7 +111,7 @@ class DEBase(Algorithm):
             pbest_rows = None
             if not static_nd or PBEST in (prim, sec):
                 top = max(int(self.pop_size * 0.05), 1)
-                best = torch.topk(fit, top, largest=False).indices
+                best = _sort.select_indices(fit, top)          # the p-best set, in index order
                 pbest_rows = best[rnd.randint(k_pb, (b,), 0, top)]
             return _de.de_trial(key, pop, idx, state.best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks,
                                 self.lb, self.ub, cross)

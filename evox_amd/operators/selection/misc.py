@@ -64,7 +64,9 @@ def select_rand_pbest(key, percent, population, fitness, num=None):
         raise ValueError("percent must be in (0, 1]")
     n = population.shape[0]
     top = max(int(n * percent), 1)
-    best = torch.topk(fitness, top, largest=False).indices
+    from ...ops.sort import select_indices
+
+    best = select_indices(fitness, top)                   # the top set, in index order
     pick = rnd.randint(key, (1 if num is None else num,), 0, top)
     rows = population[best[pick]]
     return rows[0] if num is None else rows

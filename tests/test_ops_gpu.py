@@ -906,3 +906,29 @@ def test_graph_replay_follows_a_wrapping_de_window():
     a, b = finals
     assert a.start_index == b.start_index == int(b.start_index_dev)
     assert torch.equal(a.population, b.population) and torch.equal(a.fitness, b.fitness)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (1000, 50), (4097, 4000), (50000, 2500), (50000, 1), (262144, 13107)])
+@pytest.mark.parametrize("largest", [False, True])
+def test_radix_select_matches_sorted_selection(n, k, largest, monkeypatch):
+    from evox_amd.ops import sort as _sort
+
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(n, generator=g)
+    if n >= 1000:
+        x[::7] = x[3]                                        # many ties, possibly at the threshold
+        x[5::501] = float("nan")
+        x[11] = float("inf"); x[12] = float("-inf"); x[13] = 0.0; x[14] = -0.0
+    want = _sort.select_indices(x, k, largest=largest)       # host formulation (stable sort)
+    monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 1 << 20)  # the kernel itself, whatever the routing threshold
+    got = _sort.select_indices(x.cuda(), k, largest=largest).cpu()
+    assert got.shape == (k,)
+    assert torch.equal(got, want)
+    # the library route (large inputs, graph recording) returns the same set when no keys tie at the threshold
+    if n >= 1000:
+        y = torch.randn(n, generator=g).cuda()
+        monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 0)
+        lib = _sort.select_indices(y, k, largest=largest)
+        monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 1 << 20)
+        assert torch.equal(torch.sort(lib).values, _sort.select_indices(y, k, largest=largest))
