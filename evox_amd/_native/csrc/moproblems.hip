@@ -199,3 +199,88 @@ EVOX_API int evox_hip_small_solve(const float* A, const float* b, int m, float* 
   small_solve_kernel<<<1, 64, 0, (hipStream_t)stream>>>(A, b, m, x, flag);
   return evox::last_launch_status();
 }
+
+// CEC2022 F1, F2, F4, F5 in one launch: shift, scale and rotate (z = M·((x − o)·rate)) and the basic function
+// (Zakharov, Rosenbrock, Rastrigin, Levy) per row, rotation matrix and shift staged in LDS, the row and its image
+// in registers (the suite is defined for D ∈ {2, 10, 20} only).  Values below `floor` are reported as zero.
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(256) void cec_simple_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ o,
+                                                         const float* __restrict__ M, float rate, int kind, float floor_,
+                                                         int n, float* __restrict__ out) {
+  __shared__ float sm[D * D];
+  __shared__ float so[D];
+  for (int t = threadIdx.x; t < D * D; t += blockDim.x) sm[t] = M[t];
+  for (int t = threadIdx.x; t < D; t += blockDim.x) so[t] = o[t];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = x + (int64_t)i * ldx;
+  float y[D], z[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) y[k] = (r[k] - so[k]) * rate;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc = fmaf(sm[j * D + k], y[k], acc);
+    z[j] = acc;
+  }
+  float f;
+  if (kind == 1) {                                      // Zakharov
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { t1 = fmaf(z[j], z[j], t1); t2 = fmaf(0.5f * (float)(j + 1), z[j], t2); }
+    const float q = t2 * t2;
+    f = t1 + q + q * q;
+  } else if (kind == 2) {                               // Rosenbrock (shifted to the optimum at 1)
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j + 1 < D; ++j) {
+      const float u = z[j] + 1.f, v = z[j + 1] + 1.f;
+      const float d = u * u - v;
+      a = fmaf(d, d, a);
+      b = fmaf(1.f - u, 1.f - u, b);
+    }
+    f = 100.f * a + b;
+  } else if (kind == 4) {                               // Rastrigin
+    f = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float v = z[j] * 0.0512f;
+      f += v * v - 10.f * cospif(2.f * v) + 10.f;
+    }
+  } else {                                              // Levy
+    const float w0 = 1.f + z[0] * 0.25f, wl = 1.f + z[D - 1] * 0.25f;
+    const float s0 = sinpif(w0);
+    float acc = s0 * s0;
+#pragma unroll
+    for (int j = 0; j + 1 < D; ++j) {
+      const float w = 1.f + z[j] * 0.25f;
+      const float sn = sinf(kPi * w + 1.f);
+      acc += (w - 1.f) * (w - 1.f) * (1.f + 10.f * sn * sn);
+    }
+    const float sl = sinpif(2.f * wl);
+    f = acc + (wl - 1.f) * (wl - 1.f) * (1.f + sl * sl);
+  }
+  out[i] = f < floor_ ? 0.f : f;
+}
+
+}  // namespace
+
+// kind: 1 Zakharov, 2 Rosenbrock, 4 Rastrigin, 5 Levy (the function numbers); d ∈ {2, 10, 20}.
+EVOX_API int evox_hip_cec_simple(const float* x, int64_t ldx, const float* o, const float* M, float rate, int kind,
+                                 float floor_, int n, int d, float* out, void* stream) {
+  if (n <= 0) return 0;
+  if (!(kind == 1 || kind == 2 || kind == 4 || kind == 5)) return (int)hipErrorInvalidValue;
+  const int blocks = (n + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d) {
+    case 2: cec_simple_kernel<2><<<blocks, 256, 0, st>>>(x, ldx, o, M, rate, kind, floor_, n, out); break;
+    case 10: cec_simple_kernel<10><<<blocks, 256, 0, st>>>(x, ldx, o, M, rate, kind, floor_, n, out); break;
+    case 20: cec_simple_kernel<20><<<blocks, 256, 0, st>>>(x, ldx, o, M, rate, kind, floor_, n, out); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  return evox::last_launch_status();
+}

@@ -29,6 +29,9 @@ from ...ops._util import stream_of as _stream_of
 _native.register_hip_api({"evox_hip_shift_rotate": (_native.I, [_native.P, _native.I64, _native.P, _native.P, _native.P,
                                                                _native.F, _native.I, _native.I, _native.P, _native.P])})
 
+_native.register_hip_api({"evox_hip_cec_simple": (_native.I, [_native.P, _native.I64, _native.P, _native.P, _native.F, _native.I,
+                                                             _native.F, _native.I, _native.I, _native.P, _native.P])})
+
 _DATA = Path(__file__).parent / "data" / "cec2022.npz"
 
 
@@ -228,6 +231,19 @@ def _simple(num, basic, rate=1.0):
 
         def _f(self, x, c):
             return basic(self._ssr(x, c["o"][0], c["M"][0], rate))
+
+        def evaluate(self, state, X):
+            if X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.shape[1] in (2, 10, 20) and X.shape[0] > 0:
+                # shift, rotate, basic function and the zero floor in one launch (csrc/moproblems.hip::cec_simple_kernel)
+                c = self._consts(X.shape[1], X)
+                if X.stride(1) != 1:
+                    X = X.contiguous()
+                out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+                _check(_hip().evox_hip_cec_simple(X.data_ptr(), X.stride(0), c["o"][0].contiguous().data_ptr(),
+                                                  c["M"][0].contiguous().data_ptr(), float(rate), num, float(self.floor),
+                                                  X.shape[0], X.shape[1], out.data_ptr(), _stream_of(X)), "cec_simple")
+                return out, state
+            return super().evaluate(state, X)
     _F.__name__ = _F.__qualname__ = f"F{num}_CEC2022"
     return _F
 

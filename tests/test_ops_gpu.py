@@ -932,3 +932,26 @@ def test_radix_select_matches_sorted_selection(n, k, largest, monkeypatch):
         lib = _sort.select_indices(y, k, largest=largest)
         monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 1 << 20)
         assert torch.equal(torch.sort(lib).values, _sort.select_indices(y, k, largest=largest))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("func", [1, 2, 4, 5])
+@pytest.mark.parametrize("d", [2, 10, 20])
+def test_cec2022_fused_simple_functions(func, d):
+    """F1, F2, F4, F5 in one launch against the float64 tensor formulation; strided rows; the optimum maps to 0."""
+    from evox_amd import problems
+
+    prob = problems.numerical.CEC2022TestSuit.create(func)
+    g = torch.Generator().manual_seed(func * 100 + d)
+    x = torch.rand(700, d, generator=g) * 200 - 100
+    ref, _ = prob.evaluate(None, x.double())
+    got, _ = prob.evaluate(None, x.cuda())
+    assert got.shape == (700,)
+    assert torch.allclose(got.cpu().double(), ref, rtol=2e-4, atol=1e-4 * float(ref.abs().median()) + 1e-3)
+    view = (torch.rand(300, 32, generator=g) * 200 - 100).cuda()[:, :d]
+    got2, _ = prob.evaluate(None, view)
+    ref2, _ = prob.evaluate(None, view.cpu().double())
+    assert torch.allclose(got2.cpu().double(), ref2, rtol=2e-4, atol=1e-4 * float(ref2.abs().median()) + 1e-3)
+    opt = torch.as_tensor(prob._shift[0, :d], dtype=torch.float32)[None, :].cuda()
+    at_opt, _ = prob.evaluate(None, opt)
+    assert float(at_opt[0]) == 0.0
