@@ -259,3 +259,197 @@ EVOX_API int evox_hip_select(const float* x, int n, int k, int largest, int64_t*
   select_kernel<<<1, kSelThreads, lds, (hipStream_t)stream>>>(x, n, k, largest, out);
   return evox::last_launch_status();
 }
+
+// The same selection spread over the chip for long key vectors (a single workgroup needs 1.3 ns per key): every
+// pass is one launch of many workgroups that histogram their slice in LDS and add it to a global histogram; the
+// workgroup that finishes last (a ticket counter) scans the histogram and stores the refined prefix for the next
+// launch.  Two more launches count the selected keys per block (the last block scans the counts) and write the
+// indices out in ascending order.  Five launches and one small zeroed workspace per call.
+namespace {
+
+constexpr int kMsThreads = 256;
+constexpr int kMsPerBlock = 4096;      // keys per workgroup: 16 per thread, in chunks of 256 consecutive keys
+
+struct SelState {
+  unsigned int prefix, mask, remaining, ticket;
+  unsigned int hist[3][kSelBins];
+};
+
+__device__ __forceinline__ unsigned int agent_load(const unsigned int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kMsThreads) void ms_hist_kernel(const float* __restrict__ x, int n, int largest, int k, int pass,
+                                                             SelState* __restrict__ st) {
+  __shared__ unsigned int hist[kSelBins];
+  __shared__ unsigned int wave_tot[kMsThreads / 64];
+  __shared__ unsigned int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lg = largest != 0;
+  const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+  const uint32_t bins = pass == 2 ? 1024u : 2048u;
+  const uint32_t prefix = pass == 0 ? 0u : st->prefix, mask = pass == 0 ? 0u : st->mask;
+  for (int b = tid; b < kSelBins; b += kMsThreads) hist[b] = 0;
+  __syncthreads();
+  const int base = blockIdx.x * kMsPerBlock;
+  uint32_t kk[kMsPerBlock / kMsThreads];
+#pragma unroll
+  for (int u = 0; u < kMsPerBlock / kMsThreads; ++u) {
+    const int i = base + u * kMsThreads + tid;
+    kk[u] = i < n ? select_key(x[i], lg) : 0xffffffffu;
+  }
+#pragma unroll
+  for (int u = 0; u < kMsPerBlock / kMsThreads; ++u) {
+    const bool valid = base + u * kMsThreads + tid < n;
+    if (pass == 0) hist_add<true>(hist, kk[u] >> 21, valid);
+    else hist_add<false>(hist, (kk[u] >> shift) & (bins - 1), valid && (kk[u] & mask) == prefix);
+  }
+  __syncthreads();
+  for (int b = tid; b < kSelBins; b += kMsThreads)
+    if (hist[b]) atomicAdd(&st->hist[pass][b], hist[b]);
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  // last workgroup: scan the complete histogram (eight bins per thread) and refine the prefix
+  __threadfence();
+  const unsigned int remaining = pass == 0 ? (unsigned int)k : st->remaining;
+  unsigned int h[kSelBins / kMsThreads], incl = 0;
+#pragma unroll
+  for (int q = 0; q < kSelBins / kMsThreads; ++q) { h[q] = agent_load(&st->hist[pass][tid * (kSelBins / kMsThreads) + q]); incl += h[q]; }
+  const unsigned int mine = incl;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned int start = incl - mine;
+  for (int w = 0; w < wave; ++w) start += wave_tot[w];
+#pragma unroll
+  for (int q = 0; q < kSelBins / kMsThreads; ++q) {
+    if (start < remaining && remaining <= start + h[q]) {
+      st->prefix = prefix | ((uint32_t)(tid * (kSelBins / kMsThreads) + q) << shift);
+      st->mask = mask | ((bins - 1) << shift);
+      st->remaining = remaining - start;
+    }
+    start += h[q];
+  }
+  if (tid == 0) st->ticket = 0;
+}
+
+// blockcnt[2b], [2b+1]: keys of block b below / equal to the threshold; the last block turns them into exclusive
+// offsets (blocks in index order).
+__global__ __launch_bounds__(kMsThreads) void ms_count_kernel(const float* __restrict__ x, int n, int largest,
+                                                              SelState* __restrict__ st, unsigned int* __restrict__ blockcnt) {
+  __shared__ unsigned int red[kMsThreads / 64][2];
+  __shared__ unsigned int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lg = largest != 0;
+  const uint32_t T = st->prefix;
+  const int base = blockIdx.x * kMsPerBlock;
+  unsigned int lt = 0, eq = 0;
+#pragma unroll
+  for (int u = 0; u < kMsPerBlock / kMsThreads; ++u) {
+    const int i = base + u * kMsThreads + tid;
+    if (i < n) { const uint32_t key = select_key(x[i], lg); lt += key < T; eq += key == T; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); eq += __shfl_xor(eq, o, 64); }
+  if (lane == 0) { red[wave][0] = lt; red[wave][1] = eq; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int a = 0, b = 0;
+    for (int w = 0; w < kMsThreads / 64; ++w) { a += red[w][0]; b += red[w][1]; }
+    __hip_atomic_store(&blockcnt[2 * blockIdx.x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&blockcnt[2 * blockIdx.x + 1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    s_last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // exclusive scan of the per-block counts, kMsThreads blocks at a time
+  unsigned int run_lt = 0, run_eq = 0;
+  const int blocks = gridDim.x;
+  for (int b0 = 0; b0 < blocks; b0 += kMsThreads) {
+    const int b = b0 + tid;
+    const unsigned int c_lt = b < blocks ? agent_load(&blockcnt[2 * b]) : 0u, c_eq = b < blocks ? agent_load(&blockcnt[2 * b + 1]) : 0u;
+    unsigned int i_lt = c_lt, i_eq = c_eq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int a = __shfl_up(i_lt, o, 64), e = __shfl_up(i_eq, o, 64);
+      if (lane >= o) { i_lt += a; i_eq += e; }
+    }
+    __syncthreads();
+    if (lane == 63) { red[wave][0] = i_lt; red[wave][1] = i_eq; }
+    __syncthreads();
+    unsigned int b_lt = run_lt, b_eq = run_eq, t_lt = 0, t_eq = 0;
+    for (int w = 0; w < kMsThreads / 64; ++w) {
+      if (w < wave) { b_lt += red[w][0]; b_eq += red[w][1]; }
+      t_lt += red[w][0]; t_eq += red[w][1];
+    }
+    if (b < blocks) { blockcnt[2 * b] = b_lt + i_lt - c_lt; blockcnt[2 * b + 1] = b_eq + i_eq - c_eq; }
+    run_lt += t_lt; run_eq += t_eq;
+  }
+  if (tid == 0) st->ticket = 0;
+}
+
+__global__ __launch_bounds__(kMsThreads) void ms_emit_kernel(const float* __restrict__ x, int n, int largest,
+                                                             const SelState* __restrict__ st,
+                                                             const unsigned int* __restrict__ blockoff, int64_t* __restrict__ out) {
+  __shared__ unsigned int cnt[kMsPerBlock / kMsThreads][kMsThreads / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lg = largest != 0;
+  const uint32_t T = st->prefix;
+  const unsigned int remaining = st->remaining;
+  const int base = blockIdx.x * kMsPerBlock;
+  uint32_t kk[kMsPerBlock / kMsThreads];
+  unsigned long long blt[kMsPerBlock / kMsThreads], beq[kMsPerBlock / kMsThreads];
+#pragma unroll
+  for (int u = 0; u < kMsPerBlock / kMsThreads; ++u) {
+    const int i = base + u * kMsThreads + tid;
+    kk[u] = i < n ? select_key(x[i], lg) : 0xffffffffu;
+    blt[u] = __ballot(i < n && kk[u] < T);
+    beq[u] = __ballot(i < n && kk[u] == T);
+    if (lane == 0) { cnt[u][wave][0] = __popcll(blt[u]); cnt[u][wave][1] = __popcll(beq[u]); }
+  }
+  __syncthreads();
+  const unsigned long long below = (1ull << lane) - 1ull;
+  unsigned int off_lt = blockoff[2 * blockIdx.x], off_eq = blockoff[2 * blockIdx.x + 1];
+#pragma unroll
+  for (int u = 0; u < kMsPerBlock / kMsThreads; ++u) {
+    unsigned int w_lt = 0, w_eq = 0, t_lt = 0, t_eq = 0;
+    for (int w = 0; w < kMsThreads / 64; ++w) {
+      if (w < wave) { w_lt += cnt[u][w][0]; w_eq += cnt[u][w][1]; }
+      t_lt += cnt[u][w][0]; t_eq += cnt[u][w][1];
+    }
+    const int i = base + u * kMsThreads + tid;
+    const bool lt = i < n && kk[u] < T, eq = i < n && kk[u] == T;
+    const unsigned int my_lt = off_lt + w_lt + __popcll(blt[u] & below);
+    const unsigned int my_eq = off_eq + w_eq + __popcll(beq[u] & below);
+    if (lt) out[my_lt + min(my_eq, remaining)] = i;
+    else if (eq && my_eq < remaining) out[my_lt + my_eq] = i;
+    off_lt += t_lt; off_eq += t_eq;
+  }
+}
+
+}  // namespace
+
+// Bytes of zero-initialised workspace evox_hip_select_wide needs for n keys.
+EVOX_API int64_t evox_hip_select_wide_ws(int n) {
+  const int blocks = (n + kMsPerBlock - 1) / kMsPerBlock;
+  return (int64_t)sizeof(SelState) + (int64_t)blocks * 2 * sizeof(unsigned int);
+}
+
+// Like evox_hip_select, over many workgroups; ws: zeroed workspace of evox_hip_select_wide_ws(n) bytes.
+EVOX_API int evox_hip_select_wide(const float* x, int n, int k, int largest, int64_t* out, void* ws, void* stream) {
+  if (n <= 0 || k < 1 || k > n || ws == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  SelState* st = (SelState*)ws;
+  unsigned int* blockcnt = (unsigned int*)((char*)ws + sizeof(SelState));
+  const int blocks = (n + kMsPerBlock - 1) / kMsPerBlock;
+  for (int pass = 0; pass < 3; ++pass) ms_hist_kernel<<<blocks, kMsThreads, 0, s>>>(x, n, largest, k, pass, st);
+  ms_count_kernel<<<blocks, kMsThreads, 0, s>>>(x, n, largest, st, blockcnt);
+  ms_emit_kernel<<<blocks, kMsThreads, 0, s>>>(x, n, largest, st, blockcnt, out);
+  return evox::last_launch_status();
+}

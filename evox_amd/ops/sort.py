@@ -10,7 +10,9 @@ from .. import _native
 from ._util import check, hip, stream_of
 
 P, I = _native.P, _native.I
-_native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P])})
+_native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
+                          "evox_hip_select_wide_ws": (_native.I64, [I]),
+                          "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
 _RANK_SORT_MAX = 16384
 
@@ -29,37 +31,35 @@ def _rank_sort(keys: torch.Tensor, want_rank: bool):
     return order, rank
 
 
-_SELECT_MAX_EAGER = 1 << 16   # measured (µs, kernel vs library top-k): 10 000 keys 24 vs 37, 50 000 keys 78 vs 49
-_SELECT_MAX_GRAPH = 1 << 14
+# Device time (µs): one workgroup 24 / 78 at 10 000 / 50 000 keys, the five-launch form ≈20 at 50 000 and 90 at 10⁶,
+# the library's top-k 37 / 50 / 222.  A DE generation is a dozen launches, so up to 65 536 keys the single launch wins
+# on the wall clock (SHADE at 50 000: 0.21 ms per generation against 0.26 with either multi-launch form).
+_SELECT_ONE_WG_MAX = 1 << 16
 
 
 def select_indices(keys: torch.Tensor, k: int, largest: bool = False) -> torch.Tensor:
-    """Indices (int64) of the ``k`` smallest — or largest — entries of the 1-D ``keys``: a SET, for callers that
-    draw from it or scatter into it.  NaN entries are taken last, ties at the threshold go to the lower index; the
-    indices come in ascending order except on the library route described below, which leaves them unordered.
+    """Indices (int64, ascending) of the ``k`` smallest — or largest — entries of the 1-D ``keys``; NaN entries are
+    taken last, ties at the threshold go to the lower index.
 
-    On the GPU: a radix select in ONE launch by one persistent workgroup (``csrc/sort.hip::select_kernel``).  Its
-    device time grows with 1.3 ns per key (the instruction issue of a single compute unit), so beyond 16 384 keys
-    the library's multi-kernel top-k is faster on the device — but it costs eight launches, and an eagerly issued
-    generation of a DE variant is bound by launches.  Hence the kernel is used up to 65 536 keys when work is
-    issued eagerly and up to 16 384 while a HIP graph is being recorded (launches are free at replay, and sorting
-    the library's result by index would cost more than it saves); the two routes return the same set unless
-    several keys tie exactly at the threshold."""
+    On the GPU a radix select (``csrc/sort.hip``) instead of a sort: up to 65 536 keys ONE launch of one persistent
+    workgroup (three histogram passes in LDS, then an ordered write-out); longer vectors the same passes spread over
+    the chip, five launches whose last-finishing workgroup scans the global histogram / the per-block counts."""
     n = keys.shape[0]
     k = int(k)
     if not 1 <= k <= n:
         raise ValueError("k must be in [1, n]")
     if keys.is_cuda and keys.dtype == torch.float32 and keys.dim() == 1:
-        limit = _SELECT_MAX_GRAPH if torch.cuda.is_current_stream_capturing() else _SELECT_MAX_EAGER
-        if n <= limit:
-            keys = keys.contiguous()
-            out = torch.empty(k, dtype=torch.int64, device=keys.device)
+        keys = keys.contiguous()
+        out = torch.empty(k, dtype=torch.int64, device=keys.device)
+        if n <= _SELECT_ONE_WG_MAX:
             check(hip().evox_hip_select(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), stream_of(keys)), "select")
-            return out
-        clean = torch.where(torch.isnan(keys), torch.full_like(keys, float("-inf") if largest else float("inf")), keys)
-        return torch.topk(clean, k, largest=largest, sorted=False).indices
+        else:
+            ws = torch.zeros((int(hip().evox_hip_select_wide_ws(n)) + 3) // 4, dtype=torch.int32, device=keys.device)
+            check(hip().evox_hip_select_wide(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), ws.data_ptr(),
+                                             stream_of(keys)), "select_wide")
+        return out
     clean = torch.where(torch.isnan(keys), torch.full_like(keys, float("-inf") if largest else float("inf")), keys)
-    # stable order: ties at the threshold go to the lower index, as in the kernel
+    # stable order: ties at the threshold go to the lower index, as in the kernels
     order = torch.argsort(-clean if largest else clean, stable=True)[:k]
     return torch.sort(order).values
 

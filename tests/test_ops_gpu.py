@@ -328,11 +328,15 @@ def test_cmaes_graph_step_matches_eager(cuda):
     _, se, means_e = run(False)
     wfg, sg, means_g = run(True)
     assert wfg._graphed is not None and wfg._graphed.replays >= 8
+    # The library GEMMs of the factorisation differ in the last bit between the two runs (measured: 2.4e-7 in
+    # C^{1/2} from the second generation on, on the recording's side stream as well as at replay), and ten
+    # generations amplify that to 1e-6 .. a few 1e-5 depending on which GEMM algorithms the plan timing picked
+    # in this process; the tolerance covers that, not a difference in the recorded work.
     for k, (a, b) in enumerate(zip(means_e, means_g)):
-        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6, msg=f"generation {k}")
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5, msg=f"generation {k}")
     ae, ag = se.get_child_state("algorithm"), sg.get_child_state("algorithm")
     assert ae.count_iter == ag.count_iter == 10 and ae.count_eigen == ag.count_eigen
-    torch.testing.assert_close(ae.C, ag.C, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ae.C, ag.C, rtol=2e-4, atol=2e-5)
 
 
 @pytest.mark.parametrize("algo_name,dim,pop", [("SHADE", 20, 5000), ("JaDE", 7, 300), ("DE_rand", 33, 1000),
@@ -909,11 +913,15 @@ def test_graph_replay_follows_a_wrapping_de_window():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (1000, 50), (4097, 4000), (50000, 2500), (50000, 1), (262144, 13107)])
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (1000, 50), (4097, 4000), (50000, 2500), (50000, 1), (50000, 50000),
+                                 (262144, 13107), (1000003, 77777)])
 @pytest.mark.parametrize("largest", [False, True])
-def test_radix_select_matches_sorted_selection(n, k, largest, monkeypatch):
+@pytest.mark.parametrize("route", ["one_workgroup", "wide"])
+def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch):
     from evox_amd.ops import sort as _sort
 
+    if route == "one_workgroup" and n > (1 << 20):
+        pytest.skip("the single-workgroup kernel takes at most 2^20 keys")
     g = torch.Generator().manual_seed(n + k)
     x = torch.randn(n, generator=g)
     if n >= 1000:
@@ -921,17 +929,13 @@ def test_radix_select_matches_sorted_selection(n, k, largest, monkeypatch):
         x[5::501] = float("nan")
         x[11] = float("inf"); x[12] = float("-inf"); x[13] = 0.0; x[14] = -0.0
     want = _sort.select_indices(x, k, largest=largest)       # host formulation (stable sort)
-    monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 1 << 20)  # the kernel itself, whatever the routing threshold
+    monkeypatch.setattr(_sort, "_SELECT_ONE_WG_MAX", (1 << 20) if route == "one_workgroup" else 0)
     got = _sort.select_indices(x.cuda(), k, largest=largest).cpu()
     assert got.shape == (k,)
     assert torch.equal(got, want)
-    # the library route (large inputs, graph recording) returns the same set when no keys tie at the threshold
-    if n >= 1000:
-        y = torch.randn(n, generator=g).cuda()
-        monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 0)
-        lib = _sort.select_indices(y, k, largest=largest)
-        monkeypatch.setattr(_sort, "_SELECT_MAX_EAGER", 1 << 20)
-        assert torch.equal(torch.sort(lib).values, _sort.select_indices(y, k, largest=largest))
+    clustered = (torch.rand(n, generator=g) * 600 + 400).cuda()     # keys that share their leading bits
+    got = _sort.select_indices(clustered, k, largest=largest).cpu()
+    assert torch.equal(got, _sort.select_indices(clustered.cpu(), k, largest=largest))
 
 
 @pytest.mark.gpu
