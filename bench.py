@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                     help="cpu: rehearsal of the multi-process path over gloo (not a benchmark)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
+    ap.add_argument("--prime", type=int, default=40,
+                    help="untimed set-up generations on a throw-away state (GEMM plan timing, iteration control)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
                          "rehearses the multi-rank path on a single GPU")
@@ -81,6 +83,14 @@ def main():
     else:
         wf = workflows.StdWorkflow(algo, problem, graph_step=args.graph)
     state = wf.init(key)
+    # One-time setup, the counterpart of a tracing compiler's compilation: the first generations time the candidate
+    # GEMM algorithms of every shape (plans are cached afterwards) and let the factorisation's iteration control settle
+    # from its conservative start.  Done on a throw-away state so that the measured run starts from the initial state
+    # whatever --warmup is.
+    scratch = state
+    for _ in range(args.prime):
+        scratch = wf.step(scratch)
+    del scratch
 
     def sync():
         dist.barrier()
@@ -122,6 +132,7 @@ def main():
                        "pop_per_gpu": total_pop // world, "seq_len": args.dim,
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated eigh)",
                        "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph),
+                       "setup_generations_before_warmup": args.prime,
                        "precision": ("bf16 operands in the sampling and covariance GEMMs; fp32 accumulation, state, "
                                      "fitness and factorisation" if args.precision == "bf16" else "fp32 throughout")},
             "sigma_end": sigma,
