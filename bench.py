@@ -130,7 +130,7 @@ def main():
             "data": "synthetic (Ackley objective, random initial mean; no data set)",
             "config": {"model": f"CMA-ES dim={args.dim} on {args.problem}", "global_batch": total_pop,
                        "pop_per_gpu": total_pop // world, "seq_len": args.dim,
-                       "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated eigh)",
+                       "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated factorisation)",
                        "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph),
                        "setup_generations_before_warmup": args.prime,
                        "precision": ("bf16 operands in the sampling and covariance GEMMs; fp32 accumulation, state, "
