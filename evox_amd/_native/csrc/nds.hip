@@ -199,6 +199,118 @@ __global__ __launch_bounds__(NT) void nds_peel_kernel(const float* __restrict__ 
   }
 }
 
+// Many fronts in a small population: a round of three launches costs its launch latencies (about 15 us), whatever
+// the work.  Here ONE workgroup of 1024 threads finishes the sort from the current state: a thread keeps four
+// consecutive points (objectives and remaining dominator count) in registers, the front being removed sits in LDS
+// and is read by all lanes at the same address.  Per round: flags, one block scan, copy of the front into LDS (in
+// index order, so sorted by the first objective like the points), then every thread tests its points against the
+// members (all-<=; a member never equals an unranked point).  A wave stops at the first member whose first
+// objective exceeds that of its last point, and a wave whose 256 points are all ranked skips the members
+// altogether.  A ranked point's count is -1 and only falls, so it needs no branch.
+constexpr int kPaThreads = 1024;
+constexpr int kPaQ = 4;
+constexpr int kPaMaxN = kPaThreads * kPaQ;
+
+template <int M>
+__global__ __launch_bounds__(kPaThreads) void nds_peel_all_kernel(const float* __restrict__ obj, int64_t ld, int n,
+                                                                  const int* __restrict__ count, int* __restrict__ rank,
+                                                                  int cur, int ranked, int target, int* __restrict__ sizes,
+                                                                  int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) float s_front[];          // M x cap floats, then cap front sizes
+  __shared__ int s_wave[2][kPaThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cap = (n + 3) & ~3;
+  int* s_sizes = reinterpret_cast<int*>(s_front + M * cap);
+  float b[kPaQ][M];
+  int cnt[kPaQ], got[kPaQ];
+#pragma unroll
+  for (int q = 0; q < kPaQ; ++q) {
+    const int i = tid * kPaQ + q;
+    const bool live = i < n && rank[i] < 0;
+    cnt[q] = live ? count[i] : -1;
+    got[q] = -1;
+#pragma unroll
+    for (int k = 0; k < M; ++k) b[q][k] = live ? obj[k * ld + i] : 0.f;
+  }
+  // largest first objective among this wave's points (the points are sorted by it; NaN keys sort last)
+  float wmax = obj[min(n - 1, (wave + 1) * 64 * kPaQ - 1)];
+  if (wmax != wmax) wmax = INFINITY;
+  // No global store inside the loop (a barrier would wait for it to land: microseconds per round): front indices
+  // stay in registers and front sizes in LDS until the end.  Two barriers per round: the per-wave counts alternate
+  // between two buffers, and a wave still reading round r's members has not reached the first barrier of round
+  // r+1, behind which the next members are written.
+  int f = cur;
+  while (true) {
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < kPaQ; ++q) mine += cnt[q] == 0 ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    int* sw = s_wave[f & 1];
+    if (lane == 63) sw[wave] = incl;
+    __syncthreads();
+    int pos = incl - mine, total = 0;
+#pragma unroll
+    for (int w = 0; w < kPaThreads / 64; ++w) { const int c = sw[w]; total += c; if (w < wave) pos += c; }
+    if (total == 0) break;                             // nothing left that can be ranked
+#pragma unroll
+    for (int q = 0; q < kPaQ; ++q) {
+      if (cnt[q] == 0) {
+#pragma unroll
+        for (int k = 0; k < M; ++k) s_front[k * cap + pos] = b[q][k];
+        got[q] = f;
+        cnt[q] = -1;
+        ++pos;
+      }
+    }
+    // pad the member list to a multiple of four with NaN (compares false against everything)
+    if (tid < ((4 - (total & 3)) & 3)) s_front[total + tid] = __builtin_nanf("");
+    if (tid == 0) s_sizes[f - cur] = total;
+    ranked += total;
+    ++f;
+    if (ranked >= target) break;
+    __syncthreads();
+    bool any_live = false;
+#pragma unroll
+    for (int q = 0; q < kPaQ; ++q) any_live |= cnt[q] > 0;
+    if (__ballot(any_live) == 0ull) continue;          // wave-uniform
+    for (int j = 0; j < total; j += 4) {
+      float4 a[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) a[k] = *reinterpret_cast<const float4*>(s_front + k * cap + j);
+      if (a[0].x > wmax) break;                        // wave-uniform: this member and all later ones lie behind
+#pragma unroll
+      for (int q = 0; q < kPaQ; ++q) {
+        bool d0 = true, d1 = true, d2 = true, d3 = true;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          d0 &= a[k].x <= b[q][k]; d1 &= a[k].y <= b[q][k]; d2 &= a[k].z <= b[q][k]; d3 &= a[k].w <= b[q][k];
+        }
+        cnt[q] -= (d0 ? 1 : 0) + (d1 ? 1 : 0) + (d2 ? 1 : 0) + (d3 ? 1 : 0);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kPaQ; ++q)
+    if (got[q] >= 0) rank[tid * kPaQ + q] = got[q];
+  for (int t = tid; t < f - cur; t += kPaThreads) sizes[cur + t] = s_sizes[t];
+  if (tid == 0) { info[0] = f; info[1] = ranked; }
+}
+
+template <int M>
+int launch_peel_all(const float* obj, int64_t ld, int n, const int* count, int* rank, int cur, int ranked, int target,
+                    int* sizes, int* info, hipStream_t s) {
+  const size_t lds = (size_t)(M + 1) * ((n + 3) & ~3) * sizeof(float);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)nds_peel_all_kernel<M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  nds_peel_all_kernel<M><<<1, kPaThreads, lds, s>>>(obj, ld, n, count, rank, cur, ranked, target, sizes, info);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_count(const float* obj, int64_t ld, int n, int* count, int ysplit, hipStream_t s) {
   dim3 grid((n + NT - 1) / NT, ysplit);
@@ -247,6 +359,28 @@ EVOX_API int evox_hip_nds_round(const float* obj, int64_t ld, int n, int m, int*
                                 int* nf, int* blockcnt, int* blockend, int cur, void* stream) {
   if (n <= 0 || ld < n || ld % 16) return (int)hipErrorInvalidValue;
   EVOX_NDS_DISPATCH(launch_round, obj, ld, n, count, rank, front_obj, nf, blockcnt, blockend, cur, (hipStream_t)stream)
+}
+
+// `rounds` consecutive peeling rounds from one host call (fronts cur .. cur+rounds-1; their sizes go to
+// nf[0 .. rounds)).  A round whose front is empty changes nothing, so issuing rounds past the last front is safe.
+EVOX_API int evox_hip_nds_rounds(const float* obj, int64_t ld, int n, int m, int* count, int* rank, float* front_obj,
+                                 int* nf, int* blockcnt, int* blockend, int cur, int rounds, void* stream) {
+  if (rounds < 0) return (int)hipErrorInvalidValue;
+  for (int r = 0; r < rounds; ++r) {
+    const int st = evox_hip_nds_round(obj, ld, n, m, count, rank, front_obj, nf + r, blockcnt, blockend, cur + r, stream);
+    if (st) return st;
+  }
+  return 0;
+}
+
+// The rest of the sort from one workgroup (n <= 4096): fronts cur, cur+1, ... until `target` points are ranked or no
+// unranked point is free of dominators.  count / rank: the state after front cur-1 was removed (cur = 0: straight
+// after evox_hip_nds_count); ranked: points in fronts < cur.  sizes[f] receives the size of every front collected
+// here, info[0] the number of fronts collected in all, info[1] the number of ranked points.
+EVOX_API int evox_hip_nds_peel_all(const float* obj, int64_t ld, int n, int m, const int* count, int* rank, int cur,
+                                   int ranked, int target, int* sizes, int* info, void* stream) {
+  if (n <= 0 || n > kPaMaxN || ld < n || cur < 0) return (int)hipErrorInvalidValue;
+  EVOX_NDS_DISPATCH(launch_peel_all, obj, ld, n, count, rank, cur, ranked, target, sizes, info, (hipStream_t)stream)
 }
 
 // Crowding distance of one front from per-objective orders.  The caller ranks every objective with

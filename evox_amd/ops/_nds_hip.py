@@ -12,6 +12,8 @@ P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_nds_count": (I, [P, _native.I64, I, I, P, I, P]),
     "evox_hip_nds_round": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, P]),
+    "evox_hip_nds_rounds": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, I, P]),
+    "evox_hip_nds_peel_all": (I, [P, _native.I64, I, I, P, P, I, I, I, P, P, P]),
     "evox_hip_crowding": (I, [P, P, P, I, I, P, P]),
 })
 
@@ -19,6 +21,8 @@ MAX_OBJECTIVES = 8
 _ROUNDS_PER_CHECK = 4           # rounds issued before the first host check; doubles up to _MAX_ROUNDS_PER_CHECK
 _MAX_ROUNDS_PER_CHECK = 32
 _GROW_BATCH_MAX_N = 16384        # beyond this a peeling round costs more than a read-back: no speculative rounds
+_PEEL_ALL_MAX_N = 4096           # up to here one workgroup finishes a sort that the first batch of rounds did not
+_PEEL_ALL_DIRECT_N = 2048        # ... and up to here it does the whole peeling (its work is a few microseconds)
 
 
 def supported(x: torch.Tensor) -> bool:
@@ -47,9 +51,11 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
 
     rk = torch.full((n,), -1, dtype=torch.int32, device=dev)
     front = torch.empty((m, ld), dtype=torch.float32, device=dev)                  # objectives of the current front
-    sizes = torch.zeros(n + 2 * _MAX_ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)  # size of front k
+    buf = torch.zeros(2 + n + 2 * _MAX_ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)
+    info, sizes = buf[:2], buf[2:]                                                 # (fronts, ranked) | size of front k
     blockcnt = torch.empty(2 * blocks, dtype=torch.int32, device=dev)             # per-block counts | running totals
     target = n if until is None else min(int(until), n)
+    blockend_ptr = blockcnt[blocks:].data_ptr()
     cur = 0
     batch = _ROUNDS_PER_CHECK
     while True:
@@ -57,11 +63,19 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
         # fronts cost a handful of read-backs (a round past the target is cheap there; for large populations it
         # is not, and the batch stays at four)
         before = cur
-        for _ in range(batch):
-            check(lib.evox_hip_nds_round(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), front.data_ptr(),
-                                         sizes[cur:].data_ptr(), blockcnt.data_ptr(), blockcnt[blocks:].data_ptr(),
-                                         cur, s), "nds_round")
-            cur += 1
+        if n <= _PEEL_ALL_MAX_N and (cur > 0 or n <= _PEEL_ALL_DIRECT_N):
+            # many fronts in a small population: three launches per round cost more than the round's work
+            check(lib.evox_hip_nds_peel_all(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), cur,
+                                            ranked if cur > 0 else 0, target, sizes.data_ptr(), info.data_ptr(), s),
+                  "nds_peel_all")
+            hb = buf[:2 + n].cpu()
+            cur = int(hb[0])
+            host = hb[2:2 + cur].cumsum(0)
+            break
+        check(lib.evox_hip_nds_rounds(obj.data_ptr(), ld, n, m, count.data_ptr(), rk.data_ptr(), front.data_ptr(),
+                                      sizes[cur:].data_ptr(), blockcnt.data_ptr(), blockend_ptr, cur, batch, s),
+              "nds_rounds")
+        cur += batch
         done = sizes[:cur].cumsum(0)
         host = done.cpu()                                   # one small read-back per batch of rounds
         ranked = int(host[-1])

@@ -219,7 +219,8 @@ def test_graph_step_replays_match_eager(cuda, algo_name):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,m", [(11, 2), (700, 2), (3000, 3), (2500, 5), (1500, 8), (5000, 3)])
+@pytest.mark.parametrize("n,m", [(11, 2), (700, 2), (1024, 4), (3000, 3), (2500, 5), (1500, 8), (4096, 2), (4000, 8),
+                                 (5000, 3)])
 def test_nd_sort_kernel_matches_reference(cuda, n, m):
     from evox_amd.ops import nds
     g = torch.Generator().manual_seed(n + m)
@@ -233,6 +234,20 @@ def test_nd_sort_kernel_matches_reference(cuda, n, m):
         want_u = nds.non_dominated_rank_reference(x, until=until)
         got_u = nds.non_dominated_rank(x.to(cuda), until=until)
         assert torch.equal(got_u.cpu(), want_u), until
+
+
+@pytest.mark.parametrize("n", [900, 3500])
+def test_nd_sort_kernel_with_nan_rows_matches_reference(cuda, n):
+    """Rows holding a NaN are neither dominated nor dominating in any route (the one-workgroup finish of small
+    populations included)."""
+    from evox_amd.ops import nds
+    g = torch.Generator().manual_seed(n)
+    x = torch.rand(n, 2, generator=g)
+    x[5::97, 0] = float("nan")
+    x[11::89, 1] = float("nan")
+    want = nds.non_dominated_rank_reference(x)
+    got = nds.non_dominated_rank(x.to(cuda))
+    assert torch.equal(got.cpu(), want), (got.cpu() != want).sum()
 
 
 def test_nd_sort_kernel_golden_and_chain(cuda):
@@ -630,7 +645,7 @@ def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, d
     center = net.init(rnd.PRNGKey(1)).to(cuda)
     pop = es.perturb(rnd.PRNGKey(2).to(cuda), center, 0.05, pop_n, mirrored=True, out_dtype=dtype)
     assert getattr(pop, "_evox_mirror", None) is not None
-    obs = torch.randn(pop_n, E, sizes[0], device=cuda)
+    obs = torch.randn(pop_n, E, sizes[0], generator=torch.Generator().manual_seed(pop_n + E)).to(cuda)
     got = net.batched_apply(pop, obs)
     monkeypatch.setenv("EVOX_AMD_MLP_MIRROR", "0")
     ref = net.batched_apply(pop, obs)
@@ -644,7 +659,7 @@ def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, d
         exact = net.batched_apply(es.perturb(rnd.PRNGKey(2).to(cuda), center, 0.05, pop_n, mirrored=True), obs)
         err_rows = float((ref[h:] - exact[h:]).abs().max())
         err_pair = float((got[h:] - exact[h:]).abs().max())
-        assert err_pair <= 2.5 * err_rows + 5e-3, (err_pair, err_rows)
+        assert err_pair <= 3.0 * err_rows + 1e-2, (err_pair, err_rows)
 
 
 @pytest.mark.parametrize("n", [2, 3, 64, 129, 700, 5000])
