@@ -299,6 +299,92 @@ __global__ __launch_bounds__(kPaThreads) void nds_peel_all_kernel(const float* _
   if (tid == 0) { info[0] = f; info[1] = ranked; }
 }
 
+// The whole sort of a small population (n <= 1024) in one launch and without a read-back: one point per thread,
+// dominator counts by all pairs from an LDS copy of the points (no ordering needed), then the same peeling loop
+// with the LDS copy reused for the front.  Writes the final int64 front indices in the caller's row order (points
+// behind the front that reached `target` share the next index) and (last front kept apart, points in front of it,
+// its size) into info.
+constexpr int kSmThreads = 1024;
+
+template <int M>
+__global__ __launch_bounds__(kSmThreads) void nds_small_kernel(const float* __restrict__ x, int64_t ldx, int n, int target,
+                                                               int64_t* __restrict__ rank_out, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) float s_pts[M][kSmThreads];
+  __shared__ int s_wave[2][kSmThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool have = tid < n;
+  const int n4 = (n + 3) & ~3;
+  float b[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    b[k] = have ? x[(int64_t)tid * ldx + k] : __builtin_nanf("");
+    if (tid < n4) s_pts[k][tid] = b[k];
+  }
+  __syncthreads();
+  int cnt = 0;
+  for (int j = 0; j < n4; j += 4) {
+    float4 a[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) a[k] = *reinterpret_cast<const float4*>(&s_pts[k][j]);
+    bool le0 = true, le1 = true, le2 = true, le3 = true, lt0 = false, lt1 = false, lt2 = false, lt3 = false;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      le0 &= a[k].x <= b[k]; le1 &= a[k].y <= b[k]; le2 &= a[k].z <= b[k]; le3 &= a[k].w <= b[k];
+      lt0 |= a[k].x < b[k]; lt1 |= a[k].y < b[k]; lt2 |= a[k].z < b[k]; lt3 |= a[k].w < b[k];
+    }
+    cnt += ((le0 & lt0) ? 1 : 0) + ((le1 & lt1) ? 1 : 0) + ((le2 & lt2) ? 1 : 0) + ((le3 & lt3) ? 1 : 0);
+  }
+  if (!have) cnt = -1;
+  int got = -1, f = 0, ranked = 0, total = 0, before = 0, last_total = 0;
+  while (true) {
+    const bool flag = cnt == 0;
+    const unsigned long long bal = __ballot(flag);
+    int* sw = s_wave[f & 1];
+    if (lane == 0) sw[wave] = __popcll(bal);
+    __syncthreads();                                   // also: every reader of the points / previous front is done
+    int pos = __popcll(bal & ((1ull << lane) - 1ull));
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < kSmThreads / 64; ++w) { const int c = sw[w]; total += c; if (w < wave) pos += c; }
+    if (total == 0) break;
+    if (flag) {
+#pragma unroll
+      for (int k = 0; k < M; ++k) s_pts[k][pos] = b[k];
+      got = f;
+      cnt = -1;
+    }
+    if (tid < ((4 - (total & 3)) & 3)) s_pts[0][total + tid] = __builtin_nanf("");
+    before = ranked;
+    last_total = total;
+    ranked += total;
+    ++f;
+    if (ranked >= target) break;
+    __syncthreads();
+    if (__ballot(cnt > 0) == 0ull) continue;           // wave-uniform
+    for (int j = 0; j < total; j += 4) {
+      float4 a[M];
+#pragma unroll
+      for (int k = 0; k < M; ++k) a[k] = *reinterpret_cast<const float4*>(&s_pts[k][j]);
+      bool d0 = true, d1 = true, d2 = true, d3 = true;
+#pragma unroll
+      for (int k = 0; k < M; ++k) { d0 &= a[k].x <= b[k]; d1 &= a[k].y <= b[k]; d2 &= a[k].z <= b[k]; d3 &= a[k].w <= b[k]; }
+      cnt -= (d0 ? 1 : 0) + (d1 ? 1 : 0) + (d2 ? 1 : 0) + (d3 ? 1 : 0);
+    }
+  }
+  if (have) rank_out[tid] = got >= 0 ? got : f;
+  if (tid == 0) {
+    info[0] = f - 1;
+    info[1] = before;
+    info[2] = last_total;
+  }
+}
+
+template <int M>
+int launch_small(const float* x, int64_t ldx, int n, int target, int64_t* rank_out, int* info, hipStream_t s) {
+  nds_small_kernel<M><<<1, kSmThreads, 0, s>>>(x, ldx, n, target, rank_out, info);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_peel_all(const float* obj, int64_t ld, int n, const int* count, int* rank, int cur, int ranked, int target,
                     int* sizes, int* info, hipStream_t s) {
@@ -371,6 +457,13 @@ EVOX_API int evox_hip_nds_rounds(const float* obj, int64_t ld, int n, int m, int
     if (st) return st;
   }
   return 0;
+}
+
+// x: n x m row-major (row stride ldx), n <= 1024.  See nds_small_kernel.
+EVOX_API int evox_hip_nds_small(const float* x, int64_t ldx, int n, int m, int target, int64_t* rank_out, int* info,
+                                void* stream) {
+  if (n <= 0 || n > kSmThreads || ldx < m) return (int)hipErrorInvalidValue;
+  EVOX_NDS_DISPATCH(launch_small, x, ldx, n, target, rank_out, info, (hipStream_t)stream)
 }
 
 // The rest of the sort from one workgroup (n <= 4096): fronts cur, cur+1, ... until `target` points are ranked or no

@@ -13,6 +13,7 @@ _native.register_hip_api({
     "evox_hip_nds_count": (I, [P, _native.I64, I, I, P, I, P]),
     "evox_hip_nds_round": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, P]),
     "evox_hip_nds_rounds": (I, [P, _native.I64, I, I, P, P, P, P, P, P, I, I, P]),
+    "evox_hip_nds_small": (I, [P, _native.I64, I, I, I, P, P, P]),
     "evox_hip_nds_peel_all": (I, [P, _native.I64, I, I, P, P, I, I, I, P, P, P]),
     "evox_hip_crowding": (I, [P, P, P, I, I, P, P]),
 })
@@ -21,6 +22,7 @@ MAX_OBJECTIVES = 8
 _ROUNDS_PER_CHECK = 4           # rounds issued before the first host check; doubles up to _MAX_ROUNDS_PER_CHECK
 _MAX_ROUNDS_PER_CHECK = 32
 _GROW_BATCH_MAX_N = 16384        # beyond this a peeling round costs more than a read-back: no speculative rounds
+_SMALL_MAX_N = 1024              # up to here the whole sort is one launch of one workgroup, with no read-back
 _PEEL_ALL_MAX_N = 4096           # up to here one workgroup finishes a sort that the first batch of rounds did not
 _PEEL_ALL_DIRECT_N = 2048        # ... and up to here it does the whole peeling (its work is a few microseconds)
 
@@ -37,6 +39,18 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     peeling loop has read anyway)."""
     n, m = x.shape
     dev = x.device
+    if n <= _SMALL_MAX_N:
+        xs = x.float()
+        if xs.stride(1) != 1:
+            xs = xs.contiguous()
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        info = torch.empty(3, dtype=torch.int32, device=dev)
+        check(hip().evox_hip_nds_small(xs.data_ptr(), xs.stride(0), n, m, n if until is None else max(1, min(int(until), n)),
+                                       out.data_ptr(), info.data_ptr(), stream_of(xs)), "nds_small")
+        if with_info:
+            cut, n_before, cut_size = info.tolist()
+            return out, (cut, n_before, cut_size)
+        return out
     # ascending first objective: a dominator never sits behind the point it dominates
     order = torch.argsort(x[:, 0].float(), stable=True)
     ld = (n + 15) // 16 * 16
