@@ -77,5 +77,7 @@ for _ in range(2):
     top = sort.select_indices(torch.rand(1000000, device=dev), 50000)        # ms_hist / ms_count / ms_emit kernels
     fz1, _ = problems.numerical.ZDT1(n=30).evaluate(None, torch.rand(100000, 30, device=dev))   # zdt_kernel
     fc1, _ = cec.evaluate(None, pop20)                                       # cec_simple_kernel<20>
+    r1 = nds.non_dominated_rank(torch.rand(800, 3, device=dev))             # nds_small_kernel (one launch)
+    r2 = nds.non_dominated_rank(torch.rand(4000, 2, device=dev))            # four rounds, then nds_peel_all_kernel
 torch.cuda.synchronize()
 print("done")
