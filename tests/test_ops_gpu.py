@@ -250,6 +250,21 @@ def test_nd_sort_kernel_with_nan_rows_matches_reference(cuda, n):
     assert torch.equal(got.cpu(), want), (got.cpu() != want).sum()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 1023, 1024, 1025, 2048, 2049, 4096, 4097])
+def test_nd_sort_kernel_route_boundaries(cuda, n):
+    """Population sizes on both sides of every route switch (one-launch sort, one-workgroup finish with and
+    without a first batch of rounds, multi-workgroup rounds), with and without an early stop."""
+    from evox_amd.ops import nds
+    g = torch.Generator().manual_seed(7 * n + 1)
+    x = torch.rand(n, 2, generator=g)
+    x[:, 1] = (x[:, 1] * 40).round() / 40
+    want = nds.non_dominated_rank_reference(x)
+    got = nds.non_dominated_rank(x.to(cuda))
+    assert torch.equal(got.cpu(), want), (got.cpu() != want).sum()
+    until = max(1, n // 2)
+    assert torch.equal(nds.non_dominated_rank(x.to(cuda), until=until).cpu(), nds.non_dominated_rank_reference(x, until=until))
+
+
 def test_nd_sort_kernel_golden_and_chain(cuda):
     from evox_amd.ops import nds
     x = torch.tensor([[0.5, 4], [1, 2], [2, 1], [3, 1], [4, 1], [5, 0.5], [1, 4], [2, 3], [3, 2], [3, 3], [4, 4]])
