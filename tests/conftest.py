@@ -27,3 +27,13 @@ def cuda():
     import torch
 
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_generators():
+    """Every test starts from the same state of the tensor library's global generators (CPU and GPU), so a test
+    that draws from them sees the same numbers whichever tests ran before it."""
+    import torch
+
+    torch.manual_seed(1234)
+    yield
