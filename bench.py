@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a HIP graph")
     ap.add_argument("--prime", type=int, default=40,
                     help="untimed set-up generations on a throw-away state (GEMM plan timing, iteration control)")
+    ap.add_argument("--resync-every", type=int, default=0,
+                    help="multi-GPU: broadcast rank 0's replicated algorithm state every k generations (0 = never; the "
+                         "replicas are computed from identical all-reduced statistics and differ at rounding level at most)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
                          "rehearses the multi-rank path on a single GPU")
@@ -79,7 +82,7 @@ def main():
     if world > 1:
         from evox_amd.workflows import ShardedWorkflow
 
-        wf = ShardedWorkflow(algo, problem)
+        wf = ShardedWorkflow(algo, problem, resync_every=args.resync_every)
     else:
         wf = workflows.StdWorkflow(algo, problem, graph_step=args.graph)
     state = wf.init(key)

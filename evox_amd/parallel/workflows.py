@@ -30,11 +30,30 @@ def supports_sharding(algorithm) -> bool:
 
 
 class ShardedWorkflow(StdWorkflow):
+    """``resync_every = k > 0``: every k generations rank 0's copy of the replicated algorithm state (every floating
+    tensor of the algorithm's state except the row-local ones, ``algorithm.sharded_fields``, default
+    ``("population",)``) is broadcast to the other ranks.  The replicas are computed from identical all-reduced
+    statistics, but by library GEMMs whose algorithm each rank picks by its own timing, so they may differ in the
+    last bits; the differences stay at rounding level (the covariance update contracts them), and the broadcast,
+    a few MB every k generations, removes them altogether."""
+
     def __init__(self, algorithm, problem, monitors=(), opt_direction="min", candidate_transforms=(),
-                 fitness_transforms=(), **kwargs):
+                 fitness_transforms=(), resync_every: int = 0, **kwargs):
         super().__init__(algorithm, problem, monitors, opt_direction, candidate_transforms, fitness_transforms, **kwargs)
         self.row_sharded = supports_sharding(algorithm)
         self.pmap_axis_name = dist.POP_AXIS_NAME
+        self.resync_every = int(resync_every)
+
+    def resync(self, state):
+        """Rank 0's replicated algorithm state on every rank (collective: all ranks call it)."""
+        alg = state.get_child_state("algorithm")
+        local = set(getattr(self.algorithm, "sharded_fields", ("population",)))
+        fresh = {}
+        for name in alg.keys():
+            v = getattr(alg, name)
+            if isinstance(v, torch.Tensor) and v.is_floating_point() and name not in local:
+                fresh[name] = dist.broadcast(v, src=0)
+        return state.replace_child("algorithm", alg.replace(**fresh)) if fresh else state
 
     def init(self, key=None, no_state: bool = False):
         state = super().init(key, no_state)
@@ -73,6 +92,8 @@ class ShardedWorkflow(StdWorkflow):
         for m in hooks["post_tell"]:
             m.post_tell(state)
         state = state.replace(generation=state.generation + 1, first_step=False)
+        if self.resync_every > 0 and state.world_size > 1 and state.generation % self.resync_every == 0:
+            state = self.resync(state)
         for m in hooks["post_step"]:
             m.post_step(state)
         return state

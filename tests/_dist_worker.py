@@ -26,22 +26,29 @@ def main():
     c = torch.full((dim,), 3.0, device=dev)
     lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}
-    if case in ("cmaes", "cmaes_wide", "openes", "pgpe", "pso_replicated"):
-        algo = {"cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
+    if case in ("cmaes", "cmaes_resync", "cmaes_wide", "openes", "pgpe", "pso_replicated"):
+        algo = {"cmaes_resync": lambda: A.CMAES(c, 1.0, pop_size=16),
+                "cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
                 # local shares wide enough that only the rank-ordered head of the local rows is processed
                 "cmaes_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
                 "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
                 "pgpe": lambda: A.PGPE(16, c, "adam"), "pso_replicated": lambda: A.PSO(lb, ub, 16)}[case]()
         mon = monitors.EvalMonitor()
-        wf = ShardedWorkflow(algo, problems.numerical.Ackley(), monitors=[mon])
+        wf = ShardedWorkflow(algo, problems.numerical.Ackley(), monitors=[mon],
+                             resync_every=5 if case == "cmaes_resync" else 0)
         state = wf.init(ex.PRNGKey(3))
-        for _ in range(30):
+        for g in range(30):
             state = wf.step(state)
+            if case == "cmaes_resync" and g == 11 and rank == 1:
+                # a replica that has drifted: the next broadcast (generation 15) must bring it back
+                a = state.get_child_state("algorithm")
+                state = state.replace_child("algorithm", a.replace(C=a.C * 1.001, sigma=a.sigma * 1.001))
         alg = state.get_child_state("algorithm")
-        vec = alg.mean if case in ("cmaes", "cmaes_wide") else (alg.global_best_location if case == "pso_replicated" else alg.center)
+        vec = alg.mean if case in ("cmaes", "cmaes_resync", "cmaes_wide") else (alg.global_best_location if case == "pso_replicated" else alg.center)
         result = {"vec": vec.tolist(), "world": state.world_size, "rank": state.rank,
                   "row_sharded": wf.row_sharded, "best": float(mon.get_best_fitness()),
-                  "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_wide") else None}
+                  "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_resync", "cmaes_wide") else None,
+                  "cov": alg.C.reshape(-1).tolist() if case == "cmaes_resync" else None}
     elif case == "std_multi_device":
         wf = workflows.StdWorkflow(A.PSO(lb, ub, 16), problems.numerical.Sphere())
         state = wf.enable_multi_devices(wf.init(ex.PRNGKey(5)))

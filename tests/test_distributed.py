@@ -61,6 +61,14 @@ def test_row_sharded_matches_single_process(case, tmp_path):
             assert res[0]["local_rows"] == 16 // world
 
 
+def test_resync_brings_a_drifted_replica_back(tmp_path):
+    """``resync_every``: rank 1's covariance and step size are nudged at generation 12; after the broadcast at
+    generation 15 the replicas are bit-identical again and stay so."""
+    res = launch("cmaes_resync", 2, tmp_path)
+    assert res[0]["row_sharded"]
+    assert res[0]["vec"] == res[1]["vec"] and res[0]["cov"] == res[1]["cov"]
+
+
 def test_replicated_mode_for_algorithms_without_sharding(tmp_path):
     base = launch("pso_replicated", 1, tmp_path)[0]
     res = launch("pso_replicated", 2, tmp_path)
