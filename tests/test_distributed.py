@@ -136,6 +136,15 @@ def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
 
 
 @pytest.mark.gpu
+def test_resync_on_gpu_leaves_identical_replicas(tmp_path):
+    """Two ranks on the one GPU (gloo, device tensors staged through the host): a nudged replica and whatever
+    last-bit differences the ranks' library GEMMs produce are gone after the broadcast that ends generation 30."""
+    res = launch("cmaes_resync", 2, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    assert res[0]["row_sharded"]
+    assert res[0]["vec"] == res[1]["vec"] and res[0]["cov"] == res[1]["cov"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
 def test_one_shot_p2p_collectives(world, tmp_path):
     """all_gather / all_reduce through IPC-mapped receive buffers with flag hand-shakes, ranks sharing
