@@ -253,6 +253,7 @@ __global__ __launch_bounds__(kPaThreads) void nds_peel_all_kernel(const float* _
     int pos = incl - mine, total = 0;
 #pragma unroll
     for (int w = 0; w < kPaThreads / 64; ++w) { const int c = sw[w]; total += c; if (w < wave) pos += c; }
+    total = __builtin_amdgcn_readfirstlane(total);     // the same in every lane: keep it (and the loops over it) scalar
     if (total == 0) break;                             // nothing left that can be ranked
 #pragma unroll
     for (int q = 0; q < kPaQ; ++q) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(kSmThreads) void nds_small_kernel(const float* __re
     total = 0;
 #pragma unroll
     for (int w = 0; w < kSmThreads / 64; ++w) { const int c = sw[w]; total += c; if (w < wave) pos += c; }
+    total = __builtin_amdgcn_readfirstlane(total);     // the same in every lane: keep it (and the loops over it) scalar
     if (total == 0) break;
     if (flag) {
 #pragma unroll
