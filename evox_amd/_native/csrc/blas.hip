@@ -22,6 +22,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "bf16_gemm.h"
 #include "hip_common.h"
 
 namespace {
@@ -520,4 +521,257 @@ EVOX_API int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps,
   ns_finish_kernel<<<grid, 256, 0, stream>>>(Y, Z, n, scal, prev_sqrt, prev_inv, out_sqrt, out_inv, res_blocks,
                                              (uint16_t*)out_sqrt_bf16);
   return evox::last_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------
+// The same iteration on the bf16 matrix cores (hand-written products, bf16_gemm.h).
+//
+// Every iterate is a symmetric polynomial in C, so a product of two of them is symmetric: only the tiles on and
+// above the diagonal are multiplied and each result is mirrored on write.  The ORDER of the factors still matters:
+// Y <- Y T and Z <- T Z is the coupled form whose first-order error propagation is idempotent and maps symmetric
+// errors to symmetric errors (so mirroring the upper triangle does not disturb it); Z <- Z T amplifies the error
+// component between eigenvalues l_i << l_j by (sqrt(l_j / l_i) - 1) / 2 per step and diverges at cond(C) ~ 10^3.  An fp32 matrix is carried as NSP bf16
+// planes (x = hi + lo [+ lo2], each plane the rounding of what the previous ones left), and a product is the sum
+// of the plane products whose orders add up to less than NSP: 16 (NSP = 2) or 24 (NSP = 3) significant bits per
+// operand at 3 or 6 matrix instructions per tile step, against 16 times fewer flops per clock for fp32 inputs.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+using namespace evox::bg;
+
+// Y0 = C / s as planes; T0 = c0 I + c1 Y0 and Q0 = c2 I + c3 Y0 in fp32 (addends of the first products)
+template <int NSP>
+__global__ __launch_bounds__(256) void ns_scale_planes_kernel(const float* __restrict__ C, int n, int64_t ldp,
+                                                              uint16_t* __restrict__ y0, int64_t plane, float* __restrict__ T0,
+                                                              float* __restrict__ Q0, float* scal, float* vec, int steps,
+                                                              int safe, int mv_blocks) {
+  __shared__ float red[4];
+  const float inf_norm = block_reduce(part_row(scal, kRowInf), mv_blocks, true, red);
+  const float trace = block_reduce(part_row(scal, kRowDiag), mv_blocks, false, red);
+  const float last = block_reduce(part_row(scal, steps - 1), mv_blocks, false, red);
+  const float safe_s = fmaxf(trace / (float)n, inf_norm / 1.9f);
+  const float lam = sqrtf(last) * 1.02f;
+  const float s = (!safe && lam > 0.f && lam < 3.0e38f) ? fminf(lam, safe_s * 1.9f) : safe_s;
+  const float is = 1.f / s;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float y = C[i] * is;
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    float rem = y;
+#pragma unroll
+    for (int p = 0; p < NSP; ++p) {
+      const uint32_t b = f32_to_bf16_bits(rem);
+      y0[p * plane + (int64_t)r * ldp + c] = (uint16_t)b;
+      rem -= bf16_bits_to_f32(b);
+    }
+    T0[i] = (r == c ? kP4c0 : 0.f) + kP4c1 * y;
+    Q0[i] = (r == c ? kP4c2 : 0.f) + kP4c3 * y;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) scal[13] = s;
+    const float* w = vec + (steps & 1) * n;
+    const float inv = rsqrtf(fmaxf(last, 1e-38f));
+    for (int j = threadIdx.x; j < n; j += blockDim.x) vec[j] = w[j] * inv;
+  }
+}
+
+// residual bound from the partials of ns_residual_kernel, the keep flag and the output scales
+__global__ __launch_bounds__(256) void ns_flags_kernel(float* scal, int n, int res_blocks, int have_prev) {
+  __shared__ float red[4];
+  const float res = 4.f * block_reduce(part_row(scal, kRowRes), res_blocks, false, red) / (float)n;
+  if (threadIdx.x == 0) {
+    const bool good = res < 0.25f;                        // false for NaN
+    const float rs = sqrtf(scal[13]);
+    scal[14] = res;
+    scal[15] = (!good && have_prev) ? 1.f : 0.f;
+    scal[12] = rs;
+    scal[11] = 1.f / rs;
+  }
+}
+
+template <int NSP, int NPO>
+int ns_product(const uint16_t* a0, const uint16_t* a1, const uint16_t* b0, const uint16_t* b1, int batch, int64_t plane,
+               int64_t ldp, int n, const EpiAffine<NPO>& epi, hipStream_t st) {
+  Args<NSP> g{};
+  for (int p = 0; p < NSP; ++p) {
+    g.a[0][p] = a0 + p * plane;
+    g.b[0][p] = b0 + p * plane;
+    g.a[1][p] = (batch > 1 ? a1 : a0) + p * plane;
+    g.b[1][p] = (batch > 1 ? b1 : b0) + p * plane;
+  }
+  g.lda = g.ldb = ldp;
+  g.M = g.N = n;
+  g.ksteps = (n + 63) / 64;
+  g.ksteps_per_split = g.ksteps;
+  const int T = (n + 63) / 64;
+  g.tiles_m = g.tiles_n = T;
+  return launch<64, 64, 2, 4, NSP, true, 2, EpiAffine<NPO>>(g, epi, upper_tiles(T), 1, batch, st);
+}
+
+template <int NPO>
+EpiAffine<NPO> affine(int n, int64_t ldp) {
+  EpiAffine<NPO> e{};
+  e.nout = 1;
+  e.ldf = n;
+  e.ldp = ldp;
+  e.M = e.N = n;
+  e.keep = nullptr;
+  return e;
+}
+
+template <int NPO>
+void set_planes(typename EpiAffine<NPO>::Out& o, int z, uint16_t* base, int64_t plane) {
+  for (int p = 0; p < NPO; ++p) o.pl[z][p] = base + p * plane;
+}
+
+template <int NSP>
+int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_steps, int safe, uint16_t* planes, float* f32ws,
+                   float* vec, float* scal, const float* prev_sqrt, const float* prev_inv, float* out_sqrt, float* out_inv,
+                   uint16_t* out_sqrt_bf16, hipStream_t stream) {
+  const int64_t nn = (int64_t)n * n;
+  const int64_t plane = (int64_t)n * ldp;               // elements of one bf16 plane
+  const int64_t sm = plane * NSP;                       // one split matrix
+  uint16_t* Y0 = planes;
+  uint16_t* A2 = planes + sm;
+  uint16_t* Qp = planes + 2 * sm;
+  uint16_t* Pp = planes + 3 * sm;
+  uint16_t* Y1 = planes + 4 * sm;
+  uint16_t* Tp = planes + 5 * sm;
+  uint16_t* Yb[2] = {planes + 6 * sm, planes + 8 * sm};
+  uint16_t* Zb[2] = {planes + 7 * sm, planes + 9 * sm};
+  float* T0 = f32ws;
+  float* Q0 = f32ws + nn;
+  float* Tf = f32ws + 2 * nn;
+
+  int mv_blocks = (n + 3) / 4;
+  if (mv_blocks > kPartRow) mv_blocks = kPartRow;
+  for (int j = 0; j < power_steps; ++j)
+    ns_matvec_kernel<<<mv_blocks, 256, 0, stream>>>(C, n, vec + (j & 1) * n, vec + ((j + 1) & 1) * n, scal, j);
+  ns_scale_planes_kernel<NSP><<<evox::stream_grid(nn, 256), 256, 0, stream>>>(C, n, ldp, Y0, plane, T0, Q0, scal, vec,
+                                                                             power_steps, safe, mv_blocks);
+  int e = evox::last_launch_status();
+  if (e) return e;
+  {
+    // A2 = Y0 Y0 and q = Q0 + c4 A2 from one product
+    auto epi = affine<NSP>(n, ldp);
+    epi.nout = 2;
+    epi.o[0].alpha = 1.f;
+    set_planes<NSP>(epi.o[0], 0, A2, plane);
+    epi.o[1].alpha = kP4c4;
+    epi.o[1].beta = 1.f;
+    epi.o[1].cin[0] = Q0;
+    set_planes<NSP>(epi.o[1], 0, Qp, plane);
+    e = ns_product<NSP, NSP>(Y0, nullptr, Y0, nullptr, 1, plane, ldp, n, epi, stream);
+    if (e) return e;
+  }
+  {
+    // p = T0 + A2 q   (= Z1)
+    auto epi = affine<NSP>(n, ldp);
+    epi.o[0].alpha = 1.f;
+    epi.o[0].beta = 1.f;
+    epi.o[0].cin[0] = T0;
+    set_planes<NSP>(epi.o[0], 0, Pp, plane);
+    e = ns_product<NSP, NSP>(A2, nullptr, Qp, nullptr, 1, plane, ldp, n, epi, stream);
+    if (e) return e;
+  }
+  {
+    // Y1 = Y0 p
+    auto epi = affine<NSP>(n, ldp);
+    epi.o[0].alpha = 1.f;
+    set_planes<NSP>(epi.o[0], 0, Y1, plane);
+    e = ns_product<NSP, NSP>(Y0, nullptr, Pp, nullptr, 1, plane, ldp, n, epi, stream);
+    if (e) return e;
+  }
+  const uint16_t* Y = Y1;
+  const uint16_t* Z = Pp;
+  for (int it = 1; it < iters; ++it) {
+    const bool last = it + 1 == iters;
+    {
+      // T = 1.5 I - 0.5 Z Y (planes for the next products; fp32 for the residual of the last one)
+      auto epi = affine<NSP>(n, ldp);
+      epi.o[0].alpha = -0.5f;
+      epi.o[0].gamma = 1.5f;
+      set_planes<NSP>(epi.o[0], 0, Tp, plane);
+      if (last) epi.o[0].f32[0] = Tf;
+      e = ns_product<NSP, NSP>(Z, nullptr, Y, nullptr, 1, plane, ldp, n, epi, stream);
+      if (e) return e;
+    }
+    if (!last) {
+      auto epi = affine<NSP>(n, ldp);
+      epi.o[0].alpha = 1.f;
+      set_planes<NSP>(epi.o[0], 0, Yb[it & 1], plane);
+      set_planes<NSP>(epi.o[0], 1, Zb[it & 1], plane);
+      e = ns_product<NSP, NSP>(Y, Tp, Tp, Z, 2, plane, ldp, n, epi, stream);      // Y T and T Z
+      if (e) return e;
+      Y = Yb[it & 1];
+      Z = Zb[it & 1];
+    } else {
+      int res_blocks = evox::stream_grid((int64_t)((n + kResStride - 1) / kResStride) * n, 256);
+      if (res_blocks > kPartRow) res_blocks = kPartRow;
+      ns_residual_kernel<<<res_blocks, 256, 0, stream>>>(Tf, n, scal);
+      ns_flags_kernel<<<1, 256, 0, stream>>>(scal, n, res_blocks, prev_sqrt != nullptr && prev_inv != nullptr);
+      // sqrt C = sqrt(s) Y T, C^{-1/2} = Z T / sqrt(s): fp32 images, and the square root once more rounded to bf16
+      auto epi = affine<1>(n, ldp);
+      epi.o[0].alpha = 1.f;
+      epi.o[0].f32[0] = out_sqrt;
+      epi.o[0].f32[1] = out_inv;
+      epi.o[0].scale[0] = scal + 12;
+      epi.o[0].scale[1] = scal + 11;
+      epi.o[0].prev[0] = prev_sqrt;
+      epi.o[0].prev[1] = prev_inv;
+      epi.o[0].pl[0][0] = out_sqrt_bf16;
+      epi.keep = scal + 15;
+      e = ns_product<NSP, 1>(Y, Tp, Tp, Z, 2, plane, ldp, n, epi, stream);        // Y T and T Z
+      if (e) return e;
+    }
+  }
+  return 0;
+}
+
+// cond(C) from both sides after a factorisation: with Z = C^{-1/2}, |Z|_inf^2 >= 1 / lambda_min (a bound) and
+// |Z v|^2 <= 1 / lambda_min for the unit vector v carried between calls (an estimate that improves as v turns
+// towards the smallest eigenvector).  scal[9] = s |Z v|^2, scal[10] = s |Z|_inf^2 with s = scal[13] ~ lambda_max.
+__global__ __launch_bounds__(256) void ns_cond_kernel(float* scal, const float* scal2, int mv_blocks, float* vec2, int n) {
+  __shared__ float red[4];
+  const float inf_norm = block_reduce(part_row(scal2, kRowInf), mv_blocks, true, red);
+  const float sq = block_reduce(part_row(scal2, 0), mv_blocks, false, red);
+  if (threadIdx.x == 0) {
+    scal[9] = scal[13] * sq;
+    scal[10] = scal[13] * inf_norm * inf_norm;
+  }
+  const float inv = rsqrtf(fmaxf(sq, 1e-38f));
+  for (int j = threadIdx.x; j < n; j += blockDim.x) vec2[j] = vec2[n + j] * inv;
+}
+
+}  // namespace
+
+// Condition estimates of the matrix whose inverse square root is `inv` (see ns_cond_kernel).  vec2: 2n floats, the
+// first n a unit vector carried between calls; scal: the block of the factorisation that produced `inv`;
+// scal2: a second block of evox_hip_ns_scal_floats() floats (scratch).
+EVOX_API int evox_hip_ns_cond(const float* inv, int n, float* vec2, float* scal, float* scal2, void* stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  int mv_blocks = (n + 3) / 4;
+  if (mv_blocks > kPartRow) mv_blocks = kPartRow;
+  ns_matvec_kernel<<<mv_blocks, 256, 0, st>>>(inv, n, vec2, vec2 + n, scal2, 0);
+  ns_cond_kernel<<<1, 256, 0, st>>>(scal, scal2, mv_blocks, vec2, n);
+  return evox::last_launch_status();
+}
+
+// Work space of evox_hip_ns_sqrt_bf16: planes = 10 * nsp * n * ldp bf16 elements (zero-filled once by the caller: the
+// pad columns are never written), f32ws = 3 * n * n floats.  ldp: a multiple of 64 elements >= n rounded up to 64.
+// out_sqrt_bf16 (optional): n x ldp, pad columns zero.  iters >= 2 (the first is the fifth-order step).
+EVOX_API int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe,
+                                   void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt,
+                                   const float* prev_inv, float* out_sqrt, float* out_inv, void* out_sqrt_bf16,
+                                   void* stream) {
+  if (n <= 0 || iters < 2 || power_steps < 1 || power_steps > kMaxPow || (nsp != 2 && nsp != 3)) return (int)hipErrorInvalidValue;
+  if (ldp < (int64_t)((n + 63) / 64) * 64 || (ldp & 7) || ((uintptr_t)planes & 15) || ((uintptr_t)out_sqrt_bf16 & 15))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (nsp == 2)
+    return ns_sqrt_planes<2>(C, n, ldp, iters, power_steps, safe, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt, prev_inv,
+                             out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
+  return ns_sqrt_planes<3>(C, n, ldp, iters, power_steps, safe, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt, prev_inv,
+                           out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
 }

@@ -1,0 +1,256 @@
+// CMA-ES hot path on bf16 matrix cores: entry points built on the hand-written NT GEMM of bf16_gemm.h.
+//
+//   evox_hip_normal_bf16_pitched  Z[r][c] = bf16(N(0,1) draw number (row_offset + r) * n + c) into a row-padded buffer
+//   evox_hip_bf16_sample          X = mean + sigma * Z * S^T            (reference: es_variants/cma_es.py:128-135)
+//   evox_hip_cma_gather_t         Yt[c][i] = w_i^(1/2) (x_{order[i]} - mean)[c] / sigma, plus the weighted mean shift
+//   evox_hip_bf16_cov             C' = alpha C + c1 pc pc^T + cmu Yt Yt^T  (reference: cma_es.py:178-184), upper
+//                                 triangle only on the matrix cores, K split over workgroups, mirrored on write
+//
+// Row pitches of every bf16 operand are multiples of 64 elements; pad columns must hold zeros (the callers
+// allocate the buffers zero-filled once and the kernels never write the pad).
+#include "bf16_gemm.h"
+#include "philox.h"
+
+using namespace evox;
+using namespace evox::bg;
+
+namespace {
+
+__global__ __launch_bounds__(256) void normal_bf16_pitched_kernel(const int32_t* __restrict__ key, uint16_t* __restrict__ out,
+                                                                  int64_t rows, int64_t n, int64_t ld, int64_t row_offset) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const uint64_t first_e = (uint64_t)row_offset * (uint64_t)n, last_e = first_e + (uint64_t)rows * (uint64_t)n;   // [first, last)
+  const uint64_t first_b = first_e >> 2;
+  const int64_t nblk = (int64_t)(((last_e - 1) >> 2) - first_b + 1);
+  const bool fast = (n & 3) == 0 && (ld & 3) == 0;     // a counter block never straddles rows, stores are 8-byte aligned
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nblk; t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t blk = first_b + (uint64_t)t;
+    const f32x4 g = normal4(philox_block(k0, k1, blk, kStreamDraw));
+    const uint32_t v[4] = {f32_to_bf16_bits(g.x), f32_to_bf16_bits(g.y), f32_to_bf16_bits(g.z), f32_to_bf16_bits(g.w)};
+    const uint64_t e0 = blk * 4;
+    if (fast) {
+      const uint64_t r = e0 / (uint64_t)n, c = e0 - r * (uint64_t)n;
+      *reinterpret_cast<uint2*>(out + (r - (uint64_t)row_offset) * ld + c) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    } else {
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        const uint64_t e = e0 + l;
+        if (e >= first_e && e < last_e) {
+          const uint64_t r = e / (uint64_t)n, c = e - r * (uint64_t)n;
+          out[(r - (uint64_t)row_offset) * ld + c] = (uint16_t)v[l];
+        }
+      }
+    }
+  }
+}
+
+// Gather + centre + scale + transpose.  Block (ct, rb): columns [64 ct, 64 ct + 64), selected individuals
+// i = 64 (rb + k * RB) ... in tiles of 64.  The tile is read row-wise (256 contiguous bytes per individual) and
+// written column-wise (128 contiguous bytes per column) through LDS.
+__global__ __launch_bounds__(256) void gather_t_kernel(const float* __restrict__ pop, int64_t ldpop,
+                                                       const int64_t* __restrict__ order, const float* __restrict__ mean,
+                                                       const float* __restrict__ rowscale, const float* __restrict__ sigma,
+                                                       uint16_t* __restrict__ yt, int64_t ldy, float* __restrict__ colsum,
+                                                       int mu, int n, int lam) {
+  __shared__ float tile[64][65];
+  __shared__ float part[4][64];
+  const float inv_sigma = 1.0f / sigma[0];
+  const int c0 = blockIdx.x * 64;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = c0 + col;
+  const float m = c < n ? mean[c] : 0.f;
+  float acc = 0.f;
+  const int tiles = (mu + 63) / 64;
+  for (int rt = blockIdx.y; rt < tiles; rt += gridDim.y) {
+    const int i0 = rt * 64;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int il = rr * 4 + grp, i = i0 + il;
+      float v = 0.f;
+      if (i < mu && c < n) {
+        int64_t src = order[i];
+        src = src < 0 ? 0 : (src >= lam ? lam - 1 : src);      // a corrupt index must not leave the population
+        const float w = rowscale[i];
+        const float d = pop[src * ldpop + c] - m;
+        v = d * (w * inv_sigma);
+        acc = fmaf(w * w, d, acc);
+      }
+      tile[il][col] = v;
+    }
+    __syncthreads();
+    {
+      // thread -> column cl = t / 4, individuals 16 (t % 4) ... + 16 of the tile: 32 contiguous bytes
+      const int cl = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+      if (c0 + cl < n) {
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          w[k] = f32_to_bf16_bits(tile[seg + 2 * k][cl]) | (f32_to_bf16_bits(tile[seg + 2 * k + 1][cl]) << 16);
+        uint16_t* dst = yt + (int64_t)(c0 + cl) * ldy + i0 + seg;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+    }
+    __syncthreads();
+  }
+  part[grp][col] = acc;
+  __syncthreads();
+  if (grp == 0 && c < n) colsum[(int64_t)blockIdx.y * n + c] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+}
+
+// step[c] = sum_b colsum[b][c] in a fixed order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ colsum, int rb, int n, float* __restrict__ step) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < rb; ++b) s += colsum[(int64_t)b * n + c];
+  step[c] = s;
+}
+
+// out = alpha C + c1 pc pc^T + cmu * sum_s slab_s on 64 x 64 tiles (i <= j), written to (m, n) and (n, m)
+__global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ C,
+                                                         const float* __restrict__ pc, const float* __restrict__ alpha, float c1,
+                                                         float cmu, float* __restrict__ out, int n, int tiles) {
+  __shared__ float tr[64][65];
+  int i = 0, rem = blockIdx.x;
+  while (rem >= tiles - i) {
+    rem -= tiles - i;
+    ++i;
+  }
+  const int j = i + rem;
+  const int r0 = i * 64, c0 = j * 64;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const float a = alpha[0];
+  const int64_t slab = (int64_t)n * n;
+  const int cc = c0 + col;
+  const float pcc = cc < n ? pc[cc] : 0.f;
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int rl = rr * 4 + grp, r = r0 + rl;
+    float v = 0.f;
+    if (r < n && cc < n) {
+      const int64_t e = (int64_t)r * n + cc;
+      float g = 0.f;
+      for (int s = 0; s < splits; ++s) g += ws[s * slab + e];
+      v = fmaf(a, C[e], fmaf(c1, pc[r] * pcc, cmu * g));
+      if (i != j) out[e] = v;
+    }
+    tr[rl][col] = v;
+  }
+  __syncthreads();
+  if (i == j) {
+    // a diagonal tile takes both halves from its upper triangle: the result is symmetric to the last bit
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int rl = rr * 4 + grp, r = r0 + rl;
+      if (r < n && cc < n) out[(int64_t)r * n + cc] = rl <= col ? tr[rl][col] : tr[col][rl];
+    }
+    return;
+  }
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int rl = rr * 4 + grp;                   // row of the mirrored tile = column of the computed one
+    const int r = c0 + rl, c = r0 + col;
+    if (r < n && c < n) out[(int64_t)r * n + c] = tr[col][rl];
+  }
+}
+
+inline int ksteps_of(int64_t k) { return (int)((k + 63) / 64); }
+
+}  // namespace
+
+EVOX_API int evox_hip_normal_bf16_pitched(const int32_t* key, void* out, int64_t rows, int64_t n, int64_t ld,
+                                          int64_t row_offset, void* stream) {
+  if (rows <= 0 || n <= 0) return 0;
+  if (ld < n) return (int)hipErrorInvalidValue;
+  const uint64_t first_e = (uint64_t)row_offset * (uint64_t)n, last_e = first_e + (uint64_t)rows * (uint64_t)n;
+  const int64_t nblk = (int64_t)(((last_e - 1) >> 2) - (first_e >> 2) + 1);
+  normal_bf16_pitched_kernel<<<stream_grid(nblk, 256), 256, 0, (hipStream_t)stream>>>(key, (uint16_t*)out, rows, n, ld, row_offset);
+  return last_launch_status();
+}
+
+// X[M][N] (fp32, pitch ldx) = mean + sigma * Z[M][K] S[N][K]^T.  ldz, lds: multiples of 64 elements >= K rounded up
+// to 64; pad columns zero.  X and mean 16-byte aligned, ldx a multiple of 4.
+EVOX_API int evox_hip_bf16_sample(const void* Z, int64_t ldz, const void* S, int64_t lds, const float* mean,
+                                  const float* sigma, float* X, int64_t ldx, int M, int N, int K, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+  const int ks = ksteps_of(K);
+  if (ldz < (int64_t)ks * 64 || lds < (int64_t)ks * 64 || (ldz & 7) || (lds & 7) || (ldx & 3) || ldx < N ||
+      ((uintptr_t)X & 15) || ((uintptr_t)mean & 15) || ((uintptr_t)Z & 15) || ((uintptr_t)S & 15))
+    return (int)hipErrorInvalidValue;
+  Args<1> g{};
+  g.a[0][0] = (const uint16_t*)Z;
+  g.b[0][0] = (const uint16_t*)S;
+  g.lda = ldz;
+  g.ldb = lds;
+  g.M = M;
+  g.N = N;
+  g.ksteps = ks;
+  g.ksteps_per_split = ks;
+  EpiSample epi{X, mean, sigma, (long long)ldx, M, N};
+  hipStream_t st = (hipStream_t)stream;
+  // 160 x 256 tiles: at lambda = 10^4, n = 10^3 that is 63 x 4 = 252 workgroups, one round on the 256 CUs
+  const int64_t big = (int64_t)((M + 159) / 160) * ((N + 255) / 256);
+  if (big >= 128) {
+    g.tiles_m = (M + 159) / 160;
+    g.tiles_n = (N + 255) / 256;
+    return launch<160, 256, 2, 4, 1, false, 3, EpiSample>(g, epi, g.tiles_m * g.tiles_n, 1, 1, st);
+  }
+  g.tiles_m = (M + 63) / 64;
+  g.tiles_n = (N + 63) / 64;
+  return launch<64, 64, 2, 2, 1, false, 2, EpiSample>(g, epi, g.tiles_m * g.tiles_n, 1, 1, st);
+}
+
+// rb: number of row blocks of the partial mean shift (colsum is rb x n); step = their sum in a fixed order.
+EVOX_API int evox_hip_cma_gather_t(const float* pop, int64_t ldpop, const int64_t* order, const float* mean,
+                                   const float* rowscale, const float* sigma, void* yt, int64_t ldy, float* colsum, int rb,
+                                   float* step, int mu, int n, int lam, void* stream) {
+  if (mu <= 0 || n <= 0 || rb <= 0 || lam <= 0) return (int)hipErrorInvalidValue;
+  if (ldy < (int64_t)ksteps_of(mu) * 64 || (ldy & 7) || ((uintptr_t)yt & 15)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  gather_t_kernel<<<dim3((n + 63) / 64, rb), 256, 0, st>>>(pop, ldpop, order, mean, rowscale, sigma, (uint16_t*)yt, ldy,
+                                                          colsum, mu, n, lam);
+  int e = last_launch_status();
+  if (e) return e;
+  colsum_reduce_kernel<<<(n + 255) / 256, 256, 0, st>>>(colsum, rb, n, step);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_bf16_cov_splits(int n, int mu) {
+  // enough K splits that (upper 128 x 128 tiles) x splits covers the 256 CUs about once
+  const int T = (n + 127) / 128, tiles = T * (T + 1) / 2, ks = ksteps_of(mu);
+  int want = (kNumCU + tiles - 1) / tiles;
+  if (want > ks) want = ks;
+  if (want < 1) want = 1;
+  const int per = (ks + want - 1) / want;
+  return (ks + per - 1) / per;
+}
+
+// out (n x n fp32, both triangles) = alpha[0] * C + c1 * pc pc^T + cmu * Yt Yt^T, Yt bf16 [n][ldy] with K = mu.
+// ws: evox_hip_bf16_cov_splits(n, mu) * n * n floats.
+EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C, const float* pc,
+                               const float* alpha, float c1, float cmu, float* out, float* ws, int64_t ws_floats,
+                               void* stream) {
+  if (n <= 0 || mu <= 0) return (int)hipErrorInvalidValue;
+  const int ks = ksteps_of(mu);
+  const int splits = evox_hip_bf16_cov_splits(n, mu);
+  const int per = (ks + splits - 1) / splits;
+  if (ldy < (int64_t)ks * 64 || (ldy & 7) || ((uintptr_t)Yt & 15) || (n & 3) || ((uintptr_t)ws & 15) ||
+      ws_floats < (int64_t)splits * n * n)
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const int T = (n + 127) / 128;
+  Args<1> g{};
+  g.a[0][0] = g.b[0][0] = (const uint16_t*)Yt;
+  g.lda = g.ldb = ldy;
+  g.M = g.N = n;
+  g.ksteps = ks;
+  g.ksteps_per_split = per;
+  g.tiles_m = g.tiles_n = T;
+  EpiSlab epi{ws, (long long)n, (long long)n * n, n, n, splits};
+  int e = launch<128, 128, 2, 4, 1, true, 3, EpiSlab>(g, epi, upper_tiles(T), splits, 1, st);
+  if (e) return e;
+  const int T64 = (n + 63) / 64;
+  cov_reduce_kernel<<<upper_tiles(T64), 256, 0, st>>>(ws, splits, C, pc, alpha, c1, cmu, out, n, T64);
+  return last_launch_status();
+}

@@ -11,6 +11,7 @@ mean, sigma, key, population``.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -19,6 +20,7 @@ from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.state import State
 from ....ops import cma as _cma
+from ....ops import cma_bf16 as _b16
 from ....ops import sort as _sort
 
 
@@ -57,7 +59,6 @@ class CMAES(Algorithm):
         if decomposition not in ("eigh", "newton_schulz"):
             raise ValueError("decomposition must be 'eigh' or 'newton_schulz'")
         self.decomposition = decomposition
-        self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16") if decomposition == "newton_schulz" else None
         self.pop_size = 4 + math.floor(3 * math.log(self.dim)) if pop_size is None else int(pop_size)
         dev = self.center_init.device
         if recombination_weights is None:
@@ -89,11 +90,24 @@ class CMAES(Algorithm):
         if decomp_per_iter is None:
             decomp_per_iter = max(int(math.floor(1 / (self.c1 + self.cmu) / n / 10)), 1)
         self.decomp_per_iter = int(decomp_per_iter)
+        # bf16 operands on a GPU: the sampling product, the rank-μ update and the factorisation all run on the
+        # hand-written bf16 matrix-core kernels (``EVOX_AMD_CMA_BF16=library`` keeps the vendor-library products)
+        self._bf16_kernels = (precision == "bf16" and self.center_init.is_cuda and self.dim % 4 == 0
+                              and self._sqrt_w is not None and os.environ.get("EVOX_AMD_CMA_BF16", "kernels") == "kernels"
+                              and os.environ.get("EVOX_AMD_GEMM", "hip") != "torch")
+        self._workspaces = {}
+        self._factor_cache = (None, None)        # (fp32 factor tensor, its padded bf16 image)
+        if decomposition == "newton_schulz":
+            planes = int(os.environ.get("EVOX_AMD_NS_PLANES", "2")) if self._bf16_kernels else 0
+            self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16" and not planes, planes=planes)
+        else:
+            self._ns = None
 
     # ------------------------------------------------------------------------------------
     def setup(self, key):
         dev = self.center_init.device
         eye = torch.eye(self.dim, device=dev)
+        extra = self._ns.init_control(self.dim, dev) if self._ns is not None else {}
         return State(
             pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev), B=eye,
             D=torch.ones(self.dim, device=dev), C=eye.clone(), count_eigen=0, count_iter=0, invsqrtC=eye.clone(),
@@ -101,7 +115,42 @@ class CMAES(Algorithm):
             population=torch.empty((self.pop_size, self.dim), device=dev),
             # device-side copy of count_iter: lets the fused tell kernels (and a recorded graph of
             # the step) read the generation number without a host value
-            count_iter_dev=torch.zeros((), device=dev))
+            count_iter_dev=torch.zeros((), device=dev),
+            # control of the Newton–Schulz factorisation (iteration count, power vector, residual records): part
+            # of the state, so that a resumed or replicated run takes the same decisions as the original
+            **extra)
+
+    # -- bf16 matrix-core path ------------------------------------------------------------------
+    def _workspace(self, rows: int, mu: int) -> "_b16.Workspace":
+        key = (int(rows), int(mu))
+        ws = self._workspaces.get(key)
+        if ws is None:
+            ws = self._workspaces[key] = _b16.Workspace(self.dim, rows, mu, self.center_init.device,
+                                                        ns_planes=max(self._ns.planes, 2) if self._ns is not None else 2)
+        return ws
+
+    def _factor_bf16(self, state, ws):
+        """Zero-padded bf16 image of the sampling factor (``B`` in the Newton–Schulz mode, ``B·diag(D)``
+        otherwise).  The factorisation leaves one next to the fp32 factor it returns; it is looked up by the
+        identity of that tensor, so a restored or older state simply has it rebuilt."""
+        src, img = self._factor_cache
+        if src is state.B and img is not None:
+            return img
+        factor = state.B if self._ns is not None else state.B * state.D
+        img = _b16.padded_bf16(factor, ws.factor_buffer().zero_())
+        self._factor_cache = (state.B, img)
+        return img
+
+    def _factorise(self, state, C, ws=None):
+        """(B, D, invsqrtC, control fields) of the new covariance."""
+        if self._ns is not None:
+            ctrl = {k: getattr(state, k) for k in self._ns.CONTROL_FIELDS}
+            B, invsqrtC, b16, ctrl = self._ns.step(C, ctrl, prev=(state.B, state.invsqrtC), ws=ws)
+            if b16 is not None:
+                self._factor_cache = (B, b16)
+            return B, state.D, invsqrtC, ctrl
+        B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
+        return B, D, invsqrtC, {}
 
     def graph_signature(self, state):
         """Host-side control flow of the next ``tell`` (which HIP graph variant applies)."""
@@ -112,7 +161,7 @@ class CMAES(Algorithm):
         replaying host code).  Valid when every generation takes the same branch, i.e. the
         factorisation runs every generation, and the device work reads ``count_iter_dev``."""
         if self.decomp_per_iter == 1 and self._ns is not None and self._sqrt_w is not None:
-            return ("count_iter", "count_eigen")
+            return ("count_iter", "count_eigen", "ns_calls")
         return ()
 
     def graph_check(self) -> bool:
@@ -124,10 +173,16 @@ class CMAES(Algorithm):
         # the Newton–Schulz mode stores the whole factor C^{1/2} in B and leaves D at ones
         return None if self._ns is not None else state.D
 
+    def _sample(self, state, sample_key, rows: int, row_offset: int = 0, mu: Optional[int] = None):
+        if self._bf16_kernels and state.mean.is_cuda:
+            ws = self._workspace(rows, self.mu if mu is None else mu)
+            return _b16.sample(sample_key, state.mean, state.sigma, self._factor_bf16(state, ws), rows, ws, row_offset)
+        return _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), rows, self.precision,
+                           row_offset=row_offset)
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
-        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), self.pop_size,
-                                 self.precision)
+        population = self._sample(state, sample_key, self.pop_size)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
@@ -153,7 +208,17 @@ class CMAES(Algorithm):
 
     def tell(self, state, fitness):
         order = _sort.argsort(fitness)
-        if state.population.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
+        ws = None
+        if self._bf16_kernels and state.population.is_cuda:
+            # transposed bf16 factor of the selected rows, fused path kernel, upper-triangular rank-μ product
+            from ....ops import gemm as _gemm
+            ws = self._workspace(self.pop_size, self.mu)
+            step = _b16.elite_factor_t(state.population, order, state.mean, state.sigma, self._sqrt_w, ws)
+            mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
+                state.mean, step, self._whiten(state, step), state.ps, state.pc, state.sigma, state.count_iter_dev,
+                (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
+            C = _b16.covariance(state.C, pc, alpha, self.c1, self.cmu, ws)
+        elif state.population.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
             # one pass builds S = sqrt(w)·(X_sel − m)/σ; the mean shift is σ·Sᵀsqrt(w) and the
             # rank-μ term SᵀS
             S, step = _cma.elite_factor(state.population, order, state.mean, state.sigma, self._sqrt_w, self.precision)
@@ -169,17 +234,17 @@ class CMAES(Algorithm):
             alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
             C = _cma.covariance_update(state.C, state.population, order, state.mean, state.sigma, self.weights, pc,
                                        alpha, self.c1, self.cmu, self.precision)
+        return self._finish_tell(state, mean, ps, pc, C, sigma, ws)
+
+    def _finish_tell(self, state, mean, ps, pc, C, sigma, ws=None):
+        extra = {}
         if state.count_iter % self.decomp_per_iter == 0:
-            if self._ns is not None:
-                B, invsqrtC = self._ns(C, prev=(state.B, state.invsqrtC))
-                D = state.D
-            else:
-                B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
+            B, D, invsqrtC, extra = self._factorise(state, C, ws)
             count_eigen = state.count_eigen + 1
         else:
             B, D, invsqrtC, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
         return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=invsqrtC,
-                             count_eigen=count_eigen)
+                             count_eigen=count_eigen, **extra)
 
 
     # -- row-sharded protocol (evox_amd.parallel.ShardedWorkflow) ---------------------------
@@ -194,8 +259,8 @@ class CMAES(Algorithm):
             raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
         local = self.pop_size // world
         key, sample_key = rnd.split(state.key)
-        population = _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), local, self.precision,
-                                 row_offset=rank * local)
+        consts = self._shard_consts(local, state.mean.device)
+        population = self._sample(state, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
@@ -209,7 +274,7 @@ class CMAES(Algorithm):
             expect = local * self.mu / self.pop_size
             keep = int(min(local, -(-(expect + 6.0 * math.sqrt(local) + 1) // 64) * 64))
             cache[key] = {"sqrt_w_padded": torch.sqrt(padded), "ident": torch.arange(local, device=device),
-                          "keep": keep, "overflow": torch.zeros((), dtype=torch.bool, device=device), "calls": 0}
+                          "keep": keep, "calls": 0}
         return cache[key]
 
     def tell_sharded(self, state, fitness, rank: int, world: int):
@@ -219,36 +284,47 @@ class CMAES(Algorithm):
         order, ranking = _sort.argsort_with_rank(fitness)
         my_rank = ranking[rank * local:(rank + 1) * local]
         pop = state.population
-        if pop.is_cuda and self._sqrt_w is not None and _cma.use_factor_form():
+        ws = None
+        if pop.is_cuda and self._sqrt_w is not None and (self._bf16_kernels or _cma.use_factor_form()):
             # local share of the sufficient statistics through the same kernels as the
             # single-process tell: S = sqrt(w_local)(X_local − m)/σ (zero rows for unselected
-            # individuals), Gram matrix by one library GEMM written straight into the message,
-            # then ONE in-place all-reduce of n + n² floats
+            # individuals), Gram matrix written straight into the message,
+            # then ONE in-place all-reduce of n² + n + 4 floats
             from ....ops import gemm as _gemm
             consts = self._shard_consts(local, pop.device)
-            keep = consts["keep"]
+            keep = min(consts["keep"], local)
+            nn = self.dim * self.dim
+            packed = torch.empty(nn + self.dim + 4, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
             if keep < local:
                 # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the
                 # ranks, so that number is hypergeometric with a standard deviation of at most
                 # √local / 2: the local rows are put in rank order and the first `keep` (mean + 12
-                # standard deviations) go through the gather and the Gram GEMM.  A count beyond
-                # `keep` would drop rows, so it is recorded and raised (checked every 64 calls).
+                # standard deviations) go through the gather and the Gram product.  A count beyond
+                # `keep` would drop rows: every rank adds that fact to the message, and any overflow poisons the
+                # update on every rank in the same generation (and raises at the next periodic host check).
                 local_order = _sort.argsort(my_rank.to(torch.float32))[:keep]
-                consts["overflow"] |= (my_rank < self.mu).sum() > keep
-                consts["calls"] += 1
-                if consts["calls"] % 64 == 0 and bool(consts["overflow"]):
-                    raise RuntimeError(f"more than {keep} of the {local} local rows were selected")
+                packed[nn + self.dim:] = ((my_rank < self.mu).sum() > keep).to(torch.float32)
                 sqrt_w_local = consts["sqrt_w_padded"][my_rank[local_order]]
             else:
                 local_order = consts["ident"]
+                packed[nn + self.dim:] = 0.0
                 sqrt_w_local = consts["sqrt_w_padded"][my_rank]      # 0 for rows outside the best μ
-            S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)
-            nn = self.dim * self.dim
-            packed = torch.empty(nn + self.dim, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
-            packed[nn:] = step_sum
-            _gemm.gram(S, out=packed[:nn].view(self.dim, self.dim))
+            gram_out = packed[:nn].view(self.dim, self.dim)
+            if self._bf16_kernels:
+                ws = self._workspace(local, keep)
+                packed[nn:nn + self.dim] = _b16.elite_factor_t(pop, local_order, state.mean, state.sigma, sqrt_w_local, ws)
+                _b16.gram(ws, gram_out)
+            else:
+                S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)
+                packed[nn:nn + self.dim] = step_sum
+                _gemm.gram(S, out=gram_out)
             packed = dist.all_reduce_(packed)
-            step_sum, gram = packed[nn:], packed[:nn].view(self.dim, self.dim)
+            overflow = packed[nn + self.dim]
+            step_sum = torch.where(overflow > 0, torch.full_like(overflow, float("nan")), packed[nn:nn + self.dim])
+            gram = packed[:nn].view(self.dim, self.dim)
+            consts["calls"] += 1
+            if consts["calls"] % 64 == 0 and float(overflow) > 0:
+                raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(overflow)} rank(s)")
             mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
                 state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
                 (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))
@@ -267,17 +343,7 @@ class CMAES(Algorithm):
             ps, pc, hsig, sigma = self._paths(state, mean)
             alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
             C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
-        if state.count_iter % self.decomp_per_iter == 0:
-            if self._ns is not None:
-                B, invsqrtC = self._ns(C, prev=(state.B, state.invsqrtC))
-                D = state.D
-            else:
-                B, D, invsqrtC = _cma.decompose(C, state.B, self.eigh_method)
-            count_eigen = state.count_eigen + 1
-        else:
-            B, D, invsqrtC, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
-        return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=invsqrtC,
-                             count_eigen=count_eigen)
+        return self._finish_tell(state, mean, ps, pc, C, sigma, ws)
 
 
 class SepCMAES(CMAES):

@@ -27,6 +27,7 @@ _native.register_hip_api({
     "evox_hip_gemm_plan_info": (I, [I, I, I, I64, I64, I64, I64, I64, I64, I64, I, P]),
     "evox_hip_ns_scal_floats": (I, []),
     "evox_hip_ns_sqrt": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, I, I, P, P]),
+    "evox_hip_ns_cond": (I, [P, I, P, P, P, P]),
 })
 
 _ready = None
@@ -182,3 +183,12 @@ def ns_sqrt(C: torch.Tensor, ws: NSWorkspace, iters: int, *, power_steps: int = 
     if out_b is not None:
         out_s._evox_bf16 = out_b
     return out_s, out_i
+
+
+def ns_cond(inv: torch.Tensor, vec2: torch.Tensor, scal: torch.Tensor, scal2: torch.Tensor):
+    """Condition estimates of the matrix whose inverse square root is ``inv``, left in ``scal[9]`` (estimate from
+    below: λmax·‖inv·v‖², ``v`` = ``vec2[:n]`` turned one power step further) and ``scal[10]`` (bound from above:
+    λmax·‖inv‖∞²); ``scal[13]`` must hold the λmax scale of the factorisation that produced ``inv``."""
+    n = inv.shape[0]
+    check(hip().evox_hip_ns_cond(inv.data_ptr(), n, vec2.data_ptr(), scal.data_ptr(), scal2.data_ptr(), stream_of(inv)),
+          "ns_cond")

@@ -18,7 +18,7 @@ import torch
 
 from .. import _native
 from ..core import random as rnd
-from ._util import check, hip, on_gpu, stream_of
+from ._util import check, hip, on_gpu, stream_of  # noqa: F401
 
 
 # --------------------------------------------------------------------------------------
@@ -137,100 +137,128 @@ class NewtonSchulzSqrt:
     Newton–Schulz iteration (GEMMs only, quadratically convergent)::
 
         Y₀ = C / s,  Z₀ = I,   T = (3I − Z Y) / 2,   Y ← Y T,   Z ← T Z
-        Y → (C/s)^{1/2},  Z → (C/s)^{-1/2}          (s = ‖C‖∞ ≥ λmax)
+        Y → (C/s)^{1/2},  Z → (C/s)^{-1/2}          (s ≈ λmax)
 
-    The number of iterations adapts to the conditioning of ``C`` without stalling the GPU:
-    every call leaves its final residual ``‖I − Z Y‖_F / √n`` in pinned host memory through an
-    asynchronous copy, and the *next* call reads whatever residual has already arrived and
-    raises or lowers its iteration count.  Since the covariance drifts slowly between
-    generations the controller tracks the need with one generation of lag."""
+    The object holds the policy (tolerance, iteration bounds); everything that changes from call to call —
+    the iteration count, the safe-scaling countdown, the power-iteration vector and the residual records of
+    the last two calls — is an explicit *control* dictionary that the caller carries (CMA-ES keeps it in its
+    ``State``, so checkpoints, replicas on several ranks and resumed runs all see the same values).
 
-    def __init__(self, tol: float = 2e-6, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6,
-                 bf16_copy: bool = False):
-        self.tol, self.min_iters, self.max_iters = tol, min_iters, max_iters
-        self.bf16_copy = bf16_copy        # also emit the square root rounded to bf16 (native driver only)
-        self.iters = start_iters
-        self._pending = None          # (event, host residual record, iters used)
+    The iteration count follows the conditioning of ``C`` without stalling the GPU and without depending on
+    host timing: the call of generation g reads the residual that generation g − 2 left behind (copied to
+    pinned memory when it was produced; by now that copy has long completed, the wait on its event is a
+    formality that makes the decision a pure function of the run's history).
+
+    ``planes``: 0 runs the products in fp32 through the vendor library; 2 or 3 runs them on the bf16 matrix
+    cores from that many split planes per operand (``ops/cma_bf16.py``), the form CMA-ES uses with bf16 sampling.
+    """
+
+    def __init__(self, tol: float | None = None, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6,
+                 bf16_copy: bool = False, planes: int = 0):
+        # two bf16 planes carry 16 significant bits: the residual of such an iteration bottoms out near 1e-5
+        self.tol = (1e-4 if planes == 2 else 2e-6) if tol is None else tol
+        self.min_iters, self.max_iters, self.start_iters = min_iters, max_iters, start_iters
+        self.bf16_copy = bf16_copy        # also emit the square root rounded to bf16 (fp32 library driver)
+        self.planes = int(planes)
         self.last_residual = None
-        self._graph_residual = None
-        self._host = None
-        self._event = None
+        self.fallbacks = 0                # times the guarded outputs passed the previous factors on
         self._eye = None
-        self._ws = None               # native driver scratch (GPU)
-        self.safe_calls = 0           # > 0: scale by the norm bound instead of the λmax estimate
-        self.fallbacks = 0            # times the guarded outputs passed the previous factors on
+        self._ws = None                   # scratch of the fp32 library driver
+        self._pinned = {}                 # id(record tensor) -> (weakref, event, pinned copy)
+        self._ring, self._ring_next = [], 0
+        self._graph_scal = None
+        self._graph_symmetric = False     # which GPU driver the last eager call used (a recording keeps it)
+        self._scratch = None
+        self.symmetric_calls = 0          # calls served by the symmetric bf16 driver
+        self._ctrl = None                 # control of the stand-alone use ``ns(C)``
 
-    def _poll(self):
-        if self._pending is None:
-            return
-        ev, host, used = self._pending
-        if ev is not None and not ev.query():
-            return
-        self._pending = None
-        r = float(host[0])
-        failed = host.numel() > 1 and float(host[1]) != 0.0
+    # -- legacy attribute: tests and tools pin the iteration count through it --------------------------
+    @property
+    def iters(self):
+        return self.start_iters if self._ctrl is None else self._ctrl["ns_iters"]
+
+    @iters.setter
+    def iters(self, v):
+        self.start_iters = int(v)
+        if self._ctrl is not None:
+            self._ctrl["ns_iters"] = int(v)
+
+    # -- control ---------------------------------------------------------------------------------------
+    # record of one call (7 floats, ``scal[9:16]`` of the native drivers):
+    #   0 cond estimate from below, 1 cond bound from above, 2 1/√s, 3 √s, 4 scale s ≈ λmax, 5 residual, 6 failed
+    REC = 7
+    SYM_COND_MAX = 30.0      # the symmetric-half products are used while the cond bound of two calls ago is below
+
+    def init_control(self, n: int, device) -> dict:
+        g = torch.Generator().manual_seed(0x5EED)
+        v = torch.randn(2, n, generator=g)
+        zero = torch.zeros(self.REC, dtype=torch.float32, device=device)
+        return {"ns_iters": int(self.start_iters), "ns_safe": 0, "ns_calls": 0, "ns_used1": 0, "ns_used2": 0,
+                "ns_vec": (v / v.norm(dim=1, keepdim=True)).to(device), "ns_res1": zero, "ns_res2": zero.clone()}
+
+    CONTROL_FIELDS = ("ns_iters", "ns_safe", "ns_calls", "ns_used1", "ns_used2", "ns_vec", "ns_res1", "ns_res2")
+
+    def _policy(self, iters: int, safe: int, r: float, failed: bool, used: int):
         self.last_residual = r
         if failed or not (r == r) or r >= 0.25:
-            # the estimate-scaled iteration did not contract: go back to the provably
-            # convergent scaling for a while (it needs more iterations)
+            # the estimate-scaled iteration did not contract: back to the provably convergent scaling for a while
             self.fallbacks += int(failed)
-            self.safe_calls = 64
-        # convergence is quadratic: one more iteration squares the residual, one fewer takes its
-        # root — raise by as many as the tolerance needs, lower only when the root still passes
+            safe = 64
+        # convergence is quadratic: one more iteration squares the residual, one fewer takes its root — raise by
+        # as many as the tolerance needs, lower only when the root still passes
         if not (r == r) or r > self.tol:
             more = 1 if r * r < self.tol else (2 if r < 0.19 else 4)
-            self.iters = min(self.max_iters, max(self.iters, used) + (more if r == r else 4))
-        elif r ** 0.5 < 0.25 * self.tol and used <= self.iters:
-            self.iters = max(self.min_iters, used - 1)
+            iters = min(self.max_iters, max(iters, used) + (more if r == r else 4))
+        elif r ** 0.5 < 0.25 * self.tol and used <= iters:
+            iters = max(self.min_iters, used - 1)
+        return max(self.min_iters, min(self.max_iters, iters)), safe
+
+    def _record_value(self, rec: torch.Tensor):
+        """The record of a call on the host (list of ``REC`` floats)."""
+        ent = self._pinned.pop(id(rec), None)
+        if ent is not None and ent[0]() is rec:
+            _, ev, host = ent
+            if ev is not None:
+                ev.synchronize()
+            return [float(x) for x in host]
+        return [float(x) for x in rec.detach().cpu()]
+
+    def _publish(self, rec: torch.Tensor):
+        """Start the copy of a fresh record to pinned memory (read two calls later)."""
+        import weakref
+
+        if len(self._pinned) > 8:          # records of abandoned states
+            self._pinned = {k: e for k, e in self._pinned.items() if e[0]() is not None}
+        if rec.is_cuda:
+            if len(self._ring) < 4:
+                self._ring.append((torch.empty(self.REC, dtype=torch.float32, pin_memory=True), torch.cuda.Event()))
+            host, ev = self._ring[self._ring_next]
+            self._ring_next = (self._ring_next + 1) % 4
+            host.copy_(rec, non_blocking=True)
+            ev.record()
+            self._pinned[id(rec)] = (weakref.ref(rec), ev, host)
 
     def needs_more_iterations(self) -> bool:
         """For recorded (graph-replayed) use: read the residual the last replay left on the
         device (one synchronisation) and raise the iteration count if it misses the tolerance."""
-        if self._graph_residual is None:
+        if self._graph_scal is None:
             return False
-        r = float(self._graph_residual)
+        r = float(self._graph_scal[5])
         self.last_residual = r
         if not (r == r) or r > self.tol:
-            self.iters = min(self.max_iters, self.iters + (4 if (r != r or r > 1e-2) else 2))
+            self.start_iters = min(self.max_iters, self.iters + (4 if (r != r or r > 1e-2) else 2))
             return True
         return False
 
-    def _native_ok(self, C) -> bool:
+    # -- drivers ---------------------------------------------------------------------------------------
+    def _library_ok(self, C) -> bool:
         if not (C.is_cuda and C.dtype == torch.float32 and os.environ.get("EVOX_AMD_NS", "native") == "native"):
             return False
         from . import blas as _blas
         return _blas.available()
 
-    def _call_native(self, C, prev, capturing):
-        from . import blas as _blas
+    def _torch_iteration(self, C, iters):
         n = C.shape[0]
-        if self._ws is None or self._ws.n != n or self._ws.work.device != C.device:
-            self._ws = _blas.NSWorkspace(n, C.device)
-        safe = self.safe_calls > 0
-        if safe and not capturing:
-            self.safe_calls -= 1
-        out = _blas.ns_sqrt(C, self._ws, max(1, self.iters), power_steps=1, safe=safe, prev=prev, bf16_copy=self.bf16_copy)
-        if capturing:
-            self._graph_residual = self._ws.scal[14]
-        elif self._pending is None:
-            if self._host is None or self._host.numel() != 2:
-                self._host = torch.empty(2, dtype=torch.float32, pin_memory=True)
-                self._event = torch.cuda.Event()
-            self._host.copy_(self._ws.scal[14:16], non_blocking=True)
-            self._event.record()
-            self._pending = (self._event, self._host, self.iters)
-        return out
-
-    def __call__(self, C: torch.Tensor, prev=None):
-        """``prev``: the previous ``(sqrtC, invsqrtC)``; the GPU driver passes them on when an
-        iteration fails to contract instead of returning garbage."""
-        n = C.shape[0]
-        gpu = C.is_cuda
-        capturing = gpu and torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            self._poll()
-        if self._native_ok(C):
-            return self._call_native(C, prev, capturing)
         eye = self._eye
         if eye is None or eye.shape[0] != n or eye.device != C.device or eye.dtype != C.dtype:
             eye = self._eye = torch.eye(n, device=C.device, dtype=C.dtype)
@@ -239,13 +267,12 @@ class NewtonSchulzSqrt:
         s = torch.maximum(torch.diagonal(C).mean(), C.abs().sum(1).max() / 1.9)
         Y = C / s
         # first iteration with Z₀ = I written out: T = (3I − Y)/2, Z₁ = T (saves two GEMMs)
-        T = torch.add(eye, Y, alpha=-0.5).add_(eye, alpha=0.5) if self.iters > 0 else eye
+        T = torch.add(eye, Y, alpha=-0.5).add_(eye, alpha=0.5) if iters > 0 else eye
         Z = T
-        if self.iters > 0:
+        if iters > 0:
             Y = Y @ T
-        # the multiplication ORDER below is the numerically stable coupled form; products are
-        # plain dense GEMMs and go to the vendor library (rocBLAS/hipBLASLt through torch)
-        for _ in range(self.iters - 1):
+        # the multiplication ORDER below is the numerically stable coupled form
+        for _ in range(iters - 1):
             T = torch.addmm(eye, Z, Y, beta=1.5, alpha=-0.5)
             Y = Y @ T
             Z = T @ Z
@@ -253,23 +280,99 @@ class NewtonSchulzSqrt:
         # residual is its square (quadratic convergence), so this bounds the final error
         res = 2.0 * torch.linalg.matrix_norm(T - eye) / (n ** 0.5)
         res = res * res
-        if capturing:
-            # a recording cannot hand data to the host: keep the residual in a tensor owned by
-            # the graph and let the driver look at it now and then (needs_more_iterations)
-            self._graph_residual = res
-        elif gpu:
-            if self._pending is None:
-                # one residual in flight at a time; pinned buffer and event are allocated once
-                # (a pinned allocation per call costs more host time than the whole iteration)
-                if self._host is None or self._host.numel() != 1:
-                    self._host = torch.empty(1, dtype=torch.float32, pin_memory=True)
-                    self._event = torch.cuda.Event()
-                self._host.copy_(res.reshape(1), non_blocking=True)
-                self._event.record()
-                self._pending = (self._event, self._host, self.iters)
-        else:
-            self._pending = (None, res.reshape(1), self.iters)
         rs = torch.sqrt(s)
-        sqrtC = 0.5 * (Y + Y.T) * rs
-        invsqrtC = 0.5 * (Z + Z.T) / rs
-        return sqrtC, invsqrtC
+        z = torch.zeros((), dtype=torch.float32, device=C.device)
+        rec = torch.stack([z, z, (1 / rs).to(torch.float32), rs.to(torch.float32), s.to(torch.float32),
+                           res.to(torch.float32), z])
+        return 0.5 * (Y + Y.T) * rs, 0.5 * (Z + Z.T) / rs, rec
+
+    def _gpu_scratch(self, n, device, ws):
+        """Scalar blocks and power vectors shared by the two GPU drivers: (scal, scal2, vec4) with vec4 laid out as
+        [v | scratch | v2 | scratch2]."""
+        sc = self._scratch
+        if sc is None or sc[2].numel() != 4 * n or sc[2].device != device:
+            from . import blas as _blas
+            k = int(hip().evox_hip_ns_scal_floats())
+            sc = self._scratch = (torch.zeros(k, dtype=torch.float32, device=device),
+                                  torch.zeros(k, dtype=torch.float32, device=device),
+                                  torch.zeros(4 * n, dtype=torch.float32, device=device))
+        return sc
+
+    def step(self, C: torch.Tensor, ctrl: dict, prev=None, ws=None):
+        """One factorisation.  Returns ``(sqrtC, invsqrtC, sqrtC_bf16 | None, new control)``.
+        ``prev``: the previous ``(sqrtC, invsqrtC)``, passed on by the GPU drivers when an iteration fails to
+        contract.  ``ws``: the ``ops.cma_bf16.Workspace`` of the caller (required when ``planes`` > 0).
+
+        With ``planes`` > 0 two GPU drivers exist.  The symmetric one multiplies only the upper triangle of every
+        product on the bf16 matrix cores and mirrors it; forcing the iterates symmetric changes the first-order
+        error propagation of the coupled iteration, which then amplifies rounding errors by about (√cond − 1)/2 per
+        step, so it is used while the condition bound of the covariance (from the factorisation of two calls ago)
+        is below ``SYM_COND_MAX``.  Beyond that the full fp32 products of the vendor library run."""
+        n = C.shape[0]
+        capturing = C.is_cuda and torch.cuda.is_current_stream_capturing()
+        iters, safe = int(ctrl["ns_iters"]), int(ctrl["ns_safe"])
+        calls = int(ctrl["ns_calls"])
+        lagged = None
+        if not capturing and calls >= 2 and int(ctrl["ns_used2"]) > 0:
+            lagged = self._record_value(ctrl["ns_res2"])
+            iters, safe = self._policy(iters, safe, lagged[5], lagged[6] != 0.0, int(ctrl["ns_used2"]))
+        use_safe = safe > 0
+        if use_safe and not capturing:
+            safe -= 1
+        b16 = None
+        gpu_native = C.is_cuda and C.dtype == torch.float32 and os.environ.get("EVOX_AMD_NS", "native") == "native"
+        if capturing:
+            symmetric = bool(self._graph_symmetric)
+        else:
+            symmetric = bool(self.planes and ws is not None and lagged is not None and 0.0 < lagged[1] <= self.SYM_COND_MAX
+                             and not use_safe)
+            self._graph_symmetric = symmetric
+        self.symmetric_calls += int(symmetric)
+        if gpu_native and (symmetric or self._library_ok(C)):
+            scal, scal2, vec4 = self._gpu_scratch(n, C.device, ws)
+            vec4.view(2, 2 * n)[:, :n].copy_(ctrl["ns_vec"])
+            power = 8 if calls == 0 else 1
+            if symmetric:
+                from . import cma_bf16 as _b
+                used = max(2, iters)
+                sq, inv, b16 = _b.ns_sqrt(C, ws, used, scal, vec4, power_steps=power, safe=use_safe, prev=prev)
+            else:
+                from . import blas as _blas
+                used = max(1, iters)
+                if self._ws is None or self._ws.n != n or self._ws.work.device != C.device:
+                    self._ws = _blas.NSWorkspace(n, C.device)
+                w = self._ws
+                w.fresh, w.vec, w.scal = False, vec4, scal
+                sq, inv = _blas.ns_sqrt(C, w, used, power_steps=power, safe=use_safe, prev=prev, bf16_copy=self.bf16_copy)
+            if self.planes:
+                from . import blas as _blas
+                _blas.ns_cond(inv, vec4[2 * n:], scal, scal2)
+            rec = scal[9:16].clone()
+            new_vec = vec4.view(2, 2 * n)[:, :n].clone()
+            if capturing:
+                self._graph_scal = scal[9:16]
+        else:
+            used = max(1, iters)
+            sq, inv, rec = self._torch_iteration(C, used)
+            new_vec = ctrl["ns_vec"]
+        if not capturing:
+            self._publish(rec)
+        if capturing:
+            # a recording freezes the host values: only the call counter moves (the replay advances it on the host)
+            new = dict(ctrl, ns_calls=calls + 1, ns_vec=new_vec, ns_res1=rec, ns_res2=ctrl["ns_res1"])
+        else:
+            new = {"ns_iters": iters, "ns_safe": safe, "ns_calls": calls + 1, "ns_used1": used,
+                   "ns_used2": int(ctrl["ns_used1"]), "ns_vec": new_vec, "ns_res1": rec, "ns_res2": ctrl["ns_res1"]}
+        return sq, inv, b16, new
+
+    def __call__(self, C: torch.Tensor, prev=None):
+        """Stand-alone use: the control is kept on the object."""
+        if self._ctrl is None or self._ctrl["ns_vec"].shape[1] != C.shape[0] or self._ctrl["ns_vec"].device != C.device:
+            self._ctrl = self.init_control(C.shape[0], C.device)
+        sq, inv, b16, self._ctrl = self.step(C, self._ctrl, prev)
+        if b16 is not None:
+            sq._evox_bf16 = b16
+        if C.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # stand-alone callers read ``last_residual`` right away
+            self.last_residual = self._record_value(self._ctrl["ns_res1"])[5]
+        return sq, inv

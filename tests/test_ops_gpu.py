@@ -989,3 +989,131 @@ def test_cec2022_fused_simple_functions(func, d):
     opt = torch.as_tensor(prob._shift[0, :d], dtype=torch.float32)[None, :].cuda()
     at_opt, _ = prob.evaluate(None, opt)
     assert float(at_opt[0]) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# bf16 matrix-core kernels of the CMA-ES generation (csrc/bf16_gemm.h, csrc/cma_bf16.hip)
+# ---------------------------------------------------------------------------------------------------
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("lam,n", [(10000, 1000), (300, 64), (37, 12), (1000, 256), (640, 260)])
+def test_cma_sample_bf16_kernel_against_fp64_oracle(cuda, lam, n):
+    """X = m + σ Z Sᵀ on the hand-written kernel: the oracle multiplies the SAME bf16-rounded operands in fp64, so
+    only the fp32 accumulation separates the two (asymmetric S: a transposed fragment cannot pass)."""
+    from evox_amd.ops import cma_bf16 as b16
+
+    key = rnd.PRNGKey(5).to(cuda)
+    S = torch.randn(n, n, device=cuda) / n ** 0.5
+    mean = torch.randn(n, device=cuda)
+    sigma = torch.tensor(0.7, device=cuda)
+    ws = b16.Workspace(n, lam, max(lam // 2, 1), cuda)
+    S16 = b16.padded_bf16(S)
+    got = b16.sample(key, mean, sigma, S16, lam, ws)
+    z = rnd.normal(key.cpu(), (lam, n))
+    ref = mean.cpu().double() + 0.7 * (_bf16_round(z) @ _bf16_round(S.cpu()).T)
+    assert torch.allclose(got.cpu().double(), ref, rtol=1e-5, atol=2e-5), (got.cpu() - ref).abs().max()
+    # pad columns of the workspace stay zero, and a window of rows equals the same rows of the full draw
+    assert ws.Z.shape[1] == n or float(ws.Z[:, n:].float().abs().max()) == 0.0
+    part = b16.sample(key, mean, sigma, S16, lam // 2 + 1, ws, row_offset=lam // 4)
+    assert torch.equal(part, got[lam // 4: lam // 4 + lam // 2 + 1])
+
+
+@pytest.mark.parametrize("lam,n", [(10000, 1000), (200, 64), (50, 12), (600, 132), (4096, 320)])
+def test_cma_covariance_bf16_kernel_against_fp64_oracle(cuda, lam, n):
+    from evox_amd.ops import cma_bf16 as b16
+
+    mu = lam // 2
+    pop = torch.randn(lam, n, device=cuda) * 0.5 + 1.0
+    order = torch.argsort(torch.randn(lam, device=cuda))
+    mean = torch.randn(n, device=cuda)
+    w = torch.rand(mu, device=cuda)
+    w = (w / w.sum()).sort(descending=True).values
+    pc = torch.randn(n, device=cuda)
+    a = torch.randn(n, n, device=cuda)
+    C = a @ a.T / n + torch.eye(n, device=cuda)
+    C = 0.5 * (C + C.T)
+    alpha = torch.tensor(0.93, device=cuda)
+    sigma = torch.tensor(0.8, device=cuda)
+    ws = b16.Workspace(n, lam, mu, cuda)
+    step = b16.elite_factor_t(pop, order, mean, sigma, w.sqrt(), ws)
+    got = b16.covariance(C, pc, alpha, 0.01, 0.05, ws)
+    sel = pop.double().cpu()[order.cpu()[:mu]] - mean.double().cpu()
+    ref_step = w.double().cpu() @ sel
+    assert torch.allclose(step.cpu().double(), ref_step, rtol=1e-4, atol=1e-5)
+    # the factor as the kernel stores it: fp32 arithmetic, one rounding to bf16, transposed, zero pad
+    y32 = (pop[order[:mu]] - mean) * (w.sqrt() * (1.0 / sigma))[:, None]
+    assert torch.equal(ws.Yt[:, :mu].float(), y32.to(torch.bfloat16).float().T.contiguous())
+    assert ws.Yt.shape[1] == mu or float(ws.Yt[:, mu:].float().abs().max()) == 0.0
+    y = _bf16_round(y32.cpu())
+    ref = 0.93 * C.double().cpu() + 0.01 * torch.outer(pc.double().cpu(), pc.double().cpu()) + 0.05 * (y.T @ y)
+    assert torch.allclose(got.cpu().double(), ref, rtol=1e-5, atol=1e-5), (got.cpu() - ref).abs().max()
+    assert torch.equal(got, got.T)
+    # against the unrounded fp64 update: bf16 operand rounding only
+    exact = cma.covariance_update_reference(C.double().cpu(), pop.double().cpu(), order.cpu(), mean.double().cpu(), 0.8,
+                                            w.double().cpu(), pc.double().cpu(), 0.93, 0.01, 0.05)
+    assert torch.allclose(got.cpu().double(), exact, rtol=2e-2, atol=2e-3)
+    # the Gram matrix alone (message of the row-sharded tell)
+    g = torch.empty(n, n, device=cuda)
+    b16.gram(ws, g)
+    assert torch.allclose(g.cpu().double(), y.T @ y, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("n,cond", [(1000, 30.0), (256, 4.0), (64, 10.0), (132, 20.0)])
+def test_newton_schulz_on_bf16_planes(cuda, n, cond, planes):
+    """The symmetric-half driver in the regime it is used in (condition bound <= 30)."""
+    from evox_amd.ops import cma_bf16 as b16
+
+    q, _ = torch.linalg.qr(torch.randn(n, n, device=cuda, dtype=torch.float64))
+    ev = torch.logspace(0, math.log10(cond), n, device=cuda, dtype=torch.float64)
+    C64 = (q * ev) @ q.T
+    C64 = 0.5 * (C64 + C64.T)
+    C = C64.float()
+    ws = b16.Workspace(n, 8, 4, cuda, ns_planes=planes)
+    iters = 4 + int(math.log2(cond))
+    for safe in (True, False):
+        s, zi, s16 = b16.ns_sqrt(C, ws, iters, power_steps=8, safe=safe)
+        scal = ws.ns()["scal"]
+        tol = 3e-4 if planes == 2 else 3e-5
+        rel = float((s.double() @ s.double() - C64).norm() / C64.norm())
+        assert rel < tol, (rel, safe)
+        eye = torch.eye(n, device=cuda, dtype=torch.float64)
+        res = float((zi.double() @ C64 @ zi.double() - eye).norm() / n ** 0.5)
+        assert res < 10 * tol, (res, safe)
+        assert torch.equal(s, s.T) and torch.equal(zi, zi.T)
+        assert float(scal[15]) == 0.0 and float(scal[14]) < 1e-3
+        assert torch.equal(s16[:, :n], s.to(torch.bfloat16))
+        assert s16.shape[1] == n or float(s16[:, n:].float().abs().max()) == 0.0
+    # a non-finite input makes the guarded outputs pass the previous factors on
+    bad = C.clone()
+    bad[0, 0] = float("nan")
+    prev = (torch.full_like(C, 3.0), torch.full_like(C, 4.0))
+    s, zi, s16 = b16.ns_sqrt(bad, ws, 3, prev=prev)
+    assert float(ws.ns()["scal"][15]) == 1.0
+    assert torch.equal(s, prev[0]) and torch.equal(zi, prev[1])
+
+
+def test_cmaes_bf16_kernels_track_fp32_run(cuda):
+    """The whole generation on the bf16 kernels (sampling, transposed factor, upper-triangular rank-μ product,
+    plane Newton–Schulz) against the fp32 run of the same seed: same optimisation trajectory within bf16 noise."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    out = {}
+    for prec in ("fp32", "bf16"):
+        algo = algorithms.CMAES(torch.full((128,), 3.0, device=cuda), 1.0, pop_size=512, decomposition="newton_schulz",
+                                precision=prec)
+        assert algo._bf16_kernels == (prec == "bf16")
+        wf = workflows.StdWorkflow(algo, problems.numerical.Sphere())
+        s = wf.init(ex.PRNGKey(3))
+        for _ in range(120):
+            s = wf.step(s)
+        a = s.get_child_state("algorithm")
+        out[prec] = (float((a.mean ** 2).sum()), float(a.sigma), a)
+    assert out["fp32"][0] < 0.3 and out["bf16"][0] < 0.3, out
+    assert abs(math.log(out["bf16"][0] / out["fp32"][0])) < 0.5 and abs(math.log(out["bf16"][1] / out["fp32"][1])) < 0.5
+    a = out["bf16"][2]
+    assert torch.equal(a.C, a.C.T) and a.ns_calls == 120 and 2 <= a.ns_iters <= 8
+    assert algo._ns.symmetric_calls >= 100, algo._ns.symmetric_calls        # a Sphere keeps C well conditioned
