@@ -23,6 +23,37 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_launch(n: int) -> int:
+    """Run this script as ``n`` ranks on this node (one child process per rank, rendezvous on 127.0.0.1)."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        worst = worst or p.returncode
+    if out:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +82,12 @@ def main():
                          "rehearses the multi-rank path on a single GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start one fresh process per GPU (nothing in this process has touched
+        # a GPU yet, and the children are started, never exec'ed into), relay rank 0's JSON line and return the
+        # worst exit code
+        raise SystemExit(_self_launch(args.gpus))
+
     import torch
 
     import evox_amd as ex
@@ -59,8 +96,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     on_gpu = args.device == "cuda"
     if world > 1:
         dist.init_process_group(args.backend or ("nccl" if on_gpu else "gloo"))

@@ -85,9 +85,9 @@ struct Geometry {
   static constexpr int NI = ROWS / 8;
   static constexpr int NJ = (NI + NW - 1) / NW;
   static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
-  static_assert(STAGES == 2 || STAGES == 3, "two or three LDS stages");
+  static_assert(STAGES >= 2 && STAGES <= 5, "two to five LDS stages");
   static_assert(LDS_BYTES <= 160 * 1024, "the stages must fit the 160 KiB of LDS");
-  static_assert(2 * NJ <= 63, "vmcnt holds six bits");
+  static_assert((STAGES - 2) * NJ <= 63, "vmcnt holds six bits");
   static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "wave tiles are multiples of 16");
   static_assert(BM % 8 == 0 && BN % 8 == 0, "planes start on 8-row boundaries");
 };
@@ -223,26 +223,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(Args<NP> g, Epi ep
       __syncthreads();
     }
   } else {
-    // Three stages, two of them in flight.  Per step: wait until this wave's loads of step kt have landed (the
-    // loads of step kt + 1 may stay outstanding: a counted vmcnt), one barrier (every wave's share of step kt is
-    // in LDS, and every wave has finished reading step kt - 1), refill the buffer of step kt - 1 with step
-    // kt + 2, multiply step kt.  The barrier is the bare instruction: a fenced one would drain the loads in flight.
+    // STAGES buffers, STAGES - 1 steps in flight.  Per step: wait until this wave's loads of step kt have landed
+    // (the loads of the following steps may stay outstanding: a counted vmcnt), one barrier (every wave's share of
+    // step kt is in LDS, and every wave has finished reading step kt - 1), refill the buffer of step kt - 1 with
+    // step kt + STAGES - 1, multiply step kt.  The barrier is the bare instruction: a fenced one would drain the
+    // loads in flight.
     constexpr int FULL = (NI % NW == 0) ? NJ : NJ - 1;       // loads per stage of the waves with one fewer
     const bool extra = (NI % NW != 0) && wave < NI % NW;     // this wave issues NJ per stage
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+    auto wait_behind = [&](int later) {                      // `later` younger stages may stay in flight
+      if (extra) {
+        if (later <= 0) wait_vmcnt<0>();
+        else if (later == 1) wait_vmcnt<NJ>();
+        else if (later == 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * NJ>();
+        else wait_vmcnt<(STAGES > 4 ? 3 : 1) * NJ>();
+      } else {
+        if (later <= 0) wait_vmcnt<0>();
+        else if (later == 1) wait_vmcnt<FULL>();
+        else if (later == 2) wait_vmcnt<(STAGES > 3 ? 2 : 1) * FULL>();
+        else wait_vmcnt<(STAGES > 4 ? 3 : 1) * FULL>();
+      }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+      if (s0 < nk) stage(s0, s0);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        if (extra) wait_vmcnt<NJ>(); else wait_vmcnt<FULL>();
-      } else {
-        wait_vmcnt<0>();
-      }
+      wait_behind(min(STAGES - 2, nk - 1 - kt));
       __builtin_amdgcn_s_barrier();
-      if (kt + 2 < nk && !(g.probe & 1)) stage(buf == 0 ? 2 : buf - 1, kt + 2);
+      if (kt + STAGES - 1 < nk && !(g.probe & 1)) stage(buf == 0 ? STAGES - 1 : buf - 1, kt + STAGES - 1);
       if (!(g.probe & 2)) compute(buf);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      buf = buf == 2 ? 0 : buf + 1;
+      buf = buf == STAGES - 1 ? 0 : buf + 1;
     }
   }
 

@@ -568,10 +568,78 @@ __global__ __launch_bounds__(256) void ns_scale_planes_kernel(const float* __res
     Q0[i] = (r == c ? kP4c2 : 0.f) + kP4c3 * y;
   }
   if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) scal[13] = s;
+    if (threadIdx.x == 0) {
+      scal[13] = s;
+      scal[12] = sqrtf(s);
+      scal[11] = 1.f / sqrtf(s);
+    }
     const float* w = vec + (steps & 1) * n;
     const float inv = rsqrtf(fmaxf(last, 1e-38f));
     for (int j = threadIdx.x; j < n; j += blockDim.x) vec[j] = w[j] * inv;
+  }
+}
+
+// Residual of a finished factorisation without forming Z Y: |(Z (S v) - v)| / |v| for a fixed pseudo-random probe v.
+// For E = Z S - I and a random direction, E|E v|^2 = |E|_F^2 / n, the quantity the T-based bound measures.
+__device__ __forceinline__ float probe_v(int i) {
+  const uint32_t h = (uint32_t)i * 2654435761u + 0x9E3779B9u;
+  return (float)((h >> 9) & 0xFFFFu) * (1.f / 32768.f) - 1.f;
+}
+
+// one wave per row: y = A x, or with x == nullptr y = A probe
+__global__ __launch_bounds__(256) void ns_probe_mv_kernel(const float* __restrict__ A, int n, const float* __restrict__ x,
+                                                          float* __restrict__ y, float* scal, int residual) {
+  __shared__ float sd[4], sv[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float d2 = 0.f, v2 = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+    const float* r = A + (size_t)row * n;
+    float acc = 0.f;
+    for (int j = lane; j < n; j += 64) acc = fmaf(r[j], x != nullptr ? x[j] : probe_v(j), acc);
+    acc = evox::wave_sum(acc);
+    if (residual) {
+      const float v = probe_v(row), d = acc - v;
+      d2 = fmaf(d, d, d2);
+      v2 = fmaf(v, v, v2);
+    } else if (lane == 0) {
+      y[row] = acc;
+    }
+  }
+  if (residual) {
+    if (lane == 0) { sd[wave] = d2; sv[wave] = v2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      part_row(scal, kRowRes)[blockIdx.x] = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+      part_row(scal, kMaxPow - 1)[blockIdx.x] = (sv[0] + sv[1]) + (sv[2] + sv[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ns_probe_flags_kernel(float* scal, int blocks, int have_prev) {
+  __shared__ float red[4];
+  const float d2 = block_reduce(part_row(scal, kRowRes), blocks, false, red);
+  const float v2 = block_reduce(part_row(scal, kMaxPow - 1), blocks, false, red);
+  if (threadIdx.x == 0) {
+    const float res = sqrtf(d2 / fmaxf(v2, 1e-38f));
+    const bool good = res < 0.25f;                        // false for NaN
+    scal[14] = res;
+    scal[15] = (!good && have_prev) ? 1.f : 0.f;
+  }
+}
+
+// a failed factorisation passes the previous factors on: copies only when scal[15] is set
+template <int NSP_UNUSED = 0>
+__global__ __launch_bounds__(256) void ns_guard_kernel(const float* scal, const float* __restrict__ prev_sqrt,
+                                                       const float* __restrict__ prev_inv, float* __restrict__ out_sqrt,
+                                                       float* __restrict__ out_inv, uint16_t* __restrict__ out_b16, int n,
+                                                       int64_t ldp) {
+  if (scal[15] == 0.f) return;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float sv = prev_sqrt[i];
+    out_sqrt[i] = sv;
+    out_inv[i] = prev_inv[i];
+    if (out_b16 != nullptr) out_b16[(i / n) * ldp + (i % n)] = (uint16_t)f32_to_bf16_bits(sv);
   }
 }
 
@@ -605,7 +673,10 @@ int ns_product(const uint16_t* a0, const uint16_t* a1, const uint16_t* b0, const
   g.ksteps_per_split = g.ksteps;
   const int T = (n + 63) / 64;
   g.tiles_m = g.tiles_n = T;
-  return launch<64, 64, 2, 4, NSP, true, 2, EpiAffine<NPO>>(g, epi, upper_tiles(T), 1, batch, st);
+  // two products in one launch are more workgroups than CUs: two stages (64 KiB at two planes) let two of them
+  // share a CU; a single product runs one workgroup per CU and keeps a third stage in flight
+  if (batch > 1) return launch<64, 64, 2, 4, NSP, true, 2, EpiAffine<NPO>>(g, epi, upper_tiles(T), 1, batch, st);
+  return launch<64, 64, 2, 4, NSP, true, 3, EpiAffine<NPO>>(g, epi, upper_tiles(T), 1, batch, st);
 }
 
 template <int NPO>
@@ -665,14 +736,41 @@ int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_step
     if (e) return e;
   }
   {
-    // p = T0 + A2 q   (= Z1)
+    // p = T0 + A2 q   (= Z1); when the fifth-order step is the whole factorisation, C^{-1/2} = p / sqrt(s) leaves here
     auto epi = affine<NSP>(n, ldp);
     epi.o[0].alpha = 1.f;
     epi.o[0].beta = 1.f;
     epi.o[0].cin[0] = T0;
     set_planes<NSP>(epi.o[0], 0, Pp, plane);
+    if (iters == 1) {
+      epi.nout = 2;
+      epi.o[1].alpha = 1.f;
+      epi.o[1].beta = 1.f;
+      epi.o[1].cin[0] = T0;
+      epi.o[1].f32[0] = out_inv;
+      epi.o[1].scale[0] = scal + 11;
+    }
     e = ns_product<NSP, NSP>(A2, nullptr, Qp, nullptr, 1, plane, ldp, n, epi, stream);
     if (e) return e;
+  }
+  if (iters == 1) {
+    // sqrt C = sqrt(s) Y0 p, then the probe residual and the guard
+    auto epi = affine<1>(n, ldp);
+    epi.o[0].alpha = 1.f;
+    epi.o[0].f32[0] = out_sqrt;
+    epi.o[0].scale[0] = scal + 12;
+    epi.o[0].pl[0][0] = out_sqrt_bf16;
+    e = ns_product<NSP, 1>(Y0, nullptr, Pp, nullptr, 1, plane, ldp, n, epi, stream);
+    if (e) return e;
+    float* w = Tf;                                        // n floats of scratch
+    ns_probe_mv_kernel<<<mv_blocks, 256, 0, stream>>>(out_sqrt, n, nullptr, w, scal, 0);
+    ns_probe_mv_kernel<<<mv_blocks, 256, 0, stream>>>(out_inv, n, w, nullptr, scal, 1);
+    const int have_prev = prev_sqrt != nullptr && prev_inv != nullptr;
+    ns_probe_flags_kernel<<<1, 256, 0, stream>>>(scal, mv_blocks, have_prev);
+    if (have_prev)
+      ns_guard_kernel<><<<evox::stream_grid(nn, 256), 256, 0, stream>>>(scal, prev_sqrt, prev_inv, out_sqrt, out_inv,
+                                                                       out_sqrt_bf16, n, ldp);
+    return evox::last_launch_status();
   }
   {
     // Y1 = Y0 p
@@ -760,12 +858,13 @@ EVOX_API int evox_hip_ns_cond(const float* inv, int n, float* vec2, float* scal,
 
 // Work space of evox_hip_ns_sqrt_bf16: planes = 10 * nsp * n * ldp bf16 elements (zero-filled once by the caller: the
 // pad columns are never written), f32ws = 3 * n * n floats.  ldp: a multiple of 64 elements >= n rounded up to 64.
-// out_sqrt_bf16 (optional): n x ldp, pad columns zero.  iters >= 2 (the first is the fifth-order step).
+// out_sqrt_bf16 (optional): n x ldp, pad columns zero.  iters >= 1 (the first is the fifth-order step; with
+// iters == 1 it is the whole factorisation and the residual is estimated with a probe vector).
 EVOX_API int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe,
                                    void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt,
                                    const float* prev_inv, float* out_sqrt, float* out_inv, void* out_sqrt_bf16,
                                    void* stream) {
-  if (n <= 0 || iters < 2 || power_steps < 1 || power_steps > kMaxPow || (nsp != 2 && nsp != 3)) return (int)hipErrorInvalidValue;
+  if (n <= 0 || iters < 1 || power_steps < 1 || power_steps > kMaxPow || (nsp != 2 && nsp != 3)) return (int)hipErrorInvalidValue;
   if (ldp < (int64_t)((n + 63) / 64) * 64 || (ldp & 7) || ((uintptr_t)planes & 15) || ((uintptr_t)out_sqrt_bf16 & 15))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;

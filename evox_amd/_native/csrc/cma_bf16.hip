@@ -44,70 +44,104 @@ __global__ __launch_bounds__(256) void normal_bf16_pitched_kernel(const int32_t*
   }
 }
 
-// Gather + centre + scale + transpose.  Block (ct, rb): columns [64 ct, 64 ct + 64), selected individuals
-// i = 64 (rb + k * RB) ... in tiles of 64.  The tile is read row-wise (256 contiguous bytes per individual) and
-// written column-wise (128 contiguous bytes per column) through LDS.
+// Gather + centre + scale + transpose.  Block (ct, rb): columns [64 ct, 64 ct + 64), selected individuals in tiles of
+// 64 (tile rb, rb + gridDim.y, ...).  A tile is read row-wise with 16-byte loads (every lane has its four loads of a
+// tile in flight together) and written column-wise (128 contiguous bytes per column) through LDS.
 __global__ __launch_bounds__(256) void gather_t_kernel(const float* __restrict__ pop, int64_t ldpop,
                                                        const int64_t* __restrict__ order, const float* __restrict__ mean,
                                                        const float* __restrict__ rowscale, const float* __restrict__ sigma,
                                                        uint16_t* __restrict__ yt, int64_t ldy, float* __restrict__ colsum,
                                                        int mu, int n, int lam) {
   __shared__ float tile[64][65];
-  __shared__ float part[4][64];
+  __shared__ float part[16][64];
   const float inv_sigma = 1.0f / sigma[0];
   const int c0 = blockIdx.x * 64;
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = c0 + col;
-  const float m = c < n ? mean[c] : 0.f;
-  float acc = 0.f;
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;      // column quad, row group (16 rows per pass)
+  const int c = c0 + 4 * q;
+  const bool vec = (ldpop & 3) == 0 && (((uintptr_t)pop | (uintptr_t)mean) & 15) == 0 && c + 3 < n;
+  float m[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = c + k < n ? mean[c + k] : 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   const int tiles = (mu + 63) / 64;
   for (int rt = blockIdx.y; rt < tiles; rt += gridDim.y) {
     const int i0 = rt * 64;
-#pragma unroll 4
-    for (int rr = 0; rr < 16; ++rr) {
-      const int il = rr * 4 + grp, i = i0 + il;
-      float v = 0.f;
-      if (i < mu && c < n) {
-        int64_t src = order[i];
-        src = src < 0 ? 0 : (src >= lam ? lam - 1 : src);      // a corrupt index must not leave the population
-        const float w = rowscale[i];
-        const float d = pop[src * ldpop + c] - m;
-        v = d * (w * inv_sigma);
-        acc = fmaf(w * w, d, acc);
+    int64_t src[4];
+    float w[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int i = i0 + rg + 16 * p;
+      int64_t sidx = i < mu ? order[i] : 0;
+      src[p] = sidx < 0 ? 0 : (sidx >= lam ? lam - 1 : sidx);      // a corrupt index must not leave the population
+      w[p] = i < mu ? rowscale[i] : 0.f;
+    }
+    float4 x[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float* rp = pop + src[p] * ldpop + c;
+      if (vec) {
+        x[p] = *reinterpret_cast<const float4*>(rp);
+      } else {
+        x[p] = make_float4(c < n ? rp[0] : 0.f, c + 1 < n ? rp[1] : 0.f, c + 2 < n ? rp[2] : 0.f, c + 3 < n ? rp[3] : 0.f);
       }
-      tile[il][col] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int il = rg + 16 * p;
+      const float xs[4] = {x[p].x, x[p].y, x[p].z, x[p].w};
+      const float sc = w[p] * inv_sigma, w2 = w[p] * w[p];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float d = (c + k < n) ? xs[k] - m[k] : 0.f;
+        tile[il][4 * q + k] = d * sc;            // zero beyond mu: w = 0
+        acc[k] = fmaf(w2, d, acc[k]);
+      }
     }
     __syncthreads();
     {
       // thread -> column cl = t / 4, individuals 16 (t % 4) ... + 16 of the tile: 32 contiguous bytes
       const int cl = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
       if (c0 + cl < n) {
-        uint32_t w[8];
+        uint32_t wv[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-          w[k] = f32_to_bf16_bits(tile[seg + 2 * k][cl]) | (f32_to_bf16_bits(tile[seg + 2 * k + 1][cl]) << 16);
+          wv[k] = f32_to_bf16_bits(tile[seg + 2 * k][cl]) | (f32_to_bf16_bits(tile[seg + 2 * k + 1][cl]) << 16);
         uint16_t* dst = yt + (int64_t)(c0 + cl) * ldy + i0 + seg;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+        *reinterpret_cast<uint4*>(dst) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        *reinterpret_cast<uint4*>(dst + 8) = make_uint4(wv[4], wv[5], wv[6], wv[7]);
       }
     }
     __syncthreads();
   }
-  part[grp][col] = acc;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part[rg][4 * q + k] = acc[k];
   __syncthreads();
-  if (grp == 0 && c < n) colsum[(int64_t)blockIdx.y * n + c] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+  if (threadIdx.x < 64 && c0 + (int)threadIdx.x < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += part[g][threadIdx.x];
+    colsum[(int64_t)blockIdx.y * n + c0 + threadIdx.x] = s;
+  }
 }
 
-// step[c] = sum_b colsum[b][c] in a fixed order
+// step[c] = sum_b colsum[b][c] in a fixed order: 64 columns per block, four row groups, then LDS
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ colsum, int rb, int n, float* __restrict__ step) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int b = 0; b < rb; ++b) s += colsum[(int64_t)b * n + c];
-  step[c] = s;
+  if (c < n) {
+#pragma unroll 8
+    for (int b = grp; b < rb; b += 4) s += colsum[(int64_t)b * n + c];
+  }
+  part[grp][col] = s;
+  __syncthreads();
+  if (grp == 0 && c < n) step[c] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
-// out = alpha C + c1 pc pc^T + cmu * sum_s slab_s on 64 x 64 tiles (i <= j), written to (m, n) and (n, m)
+// out = alpha C + c1 pc pc^T + cmu * sum_s slab_s on 64 x 64 tiles (i <= j), written to (m, n) and (n, m).
+// 16-byte loads, every slab of an element group in flight together (the pass is bound by memory latency otherwise).
+template <int MAXS>
 __global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict__ ws, int splits, const float* __restrict__ C,
                                                          const float* __restrict__ pc, const float* __restrict__ alpha, float c1,
                                                          float cmu, float* __restrict__ out, int n, int tiles) {
@@ -119,31 +153,49 @@ __global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict
   }
   const int j = i + rem;
   const int r0 = i * 64, c0 = j * 64;
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const float a = alpha[0];
   const int64_t slab = (int64_t)n * n;
-  const int cc = c0 + col;
-  const float pcc = cc < n ? pc[cc] : 0.f;
-#pragma unroll 4
-  for (int rr = 0; rr < 16; ++rr) {
-    const int rl = rr * 4 + grp, r = r0 + rl;
-    float v = 0.f;
-    if (r < n && cc < n) {
+  const int cc = c0 + 4 * q;
+  float pcc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pcc[k] = cc + k < n ? pc[cc + k] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = rg + 16 * p, r = r0 + rl;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < n && cc < n) {                          // n is a multiple of 4: the quad is inside or outside as a whole
       const int64_t e = (int64_t)r * n + cc;
-      float g = 0.f;
-      for (int s = 0; s < splits; ++s) g += ws[s * slab + e];
-      v = fmaf(a, C[e], fmaf(c1, pc[r] * pcc, cmu * g));
-      if (i != j) out[e] = v;
+      float4 g[MAXS];
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s)
+        g[s] = s < splits ? *reinterpret_cast<const float4*>(ws + s * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = MAXS; s < splits; ++s) {          // more slabs than the unrolled batch
+        const float4 t = *reinterpret_cast<const float4*>(ws + s * slab + e);
+        g[0].x += t.x; g[0].y += t.y; g[0].z += t.z; g[0].w += t.w;
+      }
+      const float4 cv = *reinterpret_cast<const float4*>(C + e);
+      float4 sum = g[0];
+#pragma unroll
+      for (int s = 1; s < MAXS; ++s) { sum.x += g[s].x; sum.y += g[s].y; sum.z += g[s].z; sum.w += g[s].w; }
+      const float pr = pc[r];
+      v[0] = fmaf(a, cv.x, fmaf(c1, pr * pcc[0], cmu * sum.x));
+      v[1] = fmaf(a, cv.y, fmaf(c1, pr * pcc[1], cmu * sum.y));
+      v[2] = fmaf(a, cv.z, fmaf(c1, pr * pcc[2], cmu * sum.z));
+      v[3] = fmaf(a, cv.w, fmaf(c1, pr * pcc[3], cmu * sum.w));
+      if (i != j) *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    tr[rl][col] = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tr[rl][4 * q + k] = v[k];
   }
   __syncthreads();
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
   if (i == j) {
     // a diagonal tile takes both halves from its upper triangle: the result is symmetric to the last bit
 #pragma unroll 4
     for (int rr = 0; rr < 16; ++rr) {
       const int rl = rr * 4 + grp, r = r0 + rl;
-      if (r < n && cc < n) out[(int64_t)r * n + cc] = rl <= col ? tr[rl][col] : tr[col][rl];
+      if (r < n && c0 + col < n) out[(int64_t)r * n + c0 + col] = rl <= col ? tr[rl][col] : tr[col][rl];
     }
     return;
   }
@@ -212,7 +264,7 @@ EVOX_API int evox_hip_cma_gather_t(const float* pop, int64_t ldpop, const int64_
                                                           colsum, mu, n, lam);
   int e = last_launch_status();
   if (e) return e;
-  colsum_reduce_kernel<<<(n + 255) / 256, 256, 0, st>>>(colsum, rb, n, step);
+  colsum_reduce_kernel<<<(n + 63) / 64, 256, 0, st>>>(colsum, rb, n, step);
   return last_launch_status();
 }
 
@@ -251,6 +303,6 @@ EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const
   int e = launch<128, 128, 2, 4, 1, true, 3, EpiSlab>(g, epi, upper_tiles(T), splits, 1, st);
   if (e) return e;
   const int T64 = (n + 63) / 64;
-  cov_reduce_kernel<<<upper_tiles(T64), 256, 0, st>>>(ws, splits, C, pc, alpha, c1, cmu, out, n, T64);
+  cov_reduce_kernel<8><<<upper_tiles(T64), 256, 0, st>>>(ws, splits, C, pc, alpha, c1, cmu, out, n, T64);
   return last_launch_status();
 }

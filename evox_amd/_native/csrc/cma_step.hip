@@ -1,0 +1,225 @@
+// One native call per half of a CMA-ES generation.
+//
+// A generation at lambda = 10^4, n = 10^3 is ~25 kernels of 3-35 us.  Issued one by one from the interpreter, each
+// costs 5-10 us of host time (argument marshalling, allocator, stream lookup), which is more than the kernels take:
+// the step was bound by the host.  The two entry points below issue the whole kernel sequence of `ask` and of `tell`
+// from C++ on the caller's stream; the interpreter allocates the output tensors and keeps the policy decisions
+// (which factorisation driver, how many iterations) that need values from earlier generations.
+//
+//   ask   (reference: es_variants/cma_es.py:128-135)  key split, Gaussian draws (unless drawn ahead), X = m + s Z S^T
+//   tell  (reference: es_variants/cma_es.py:137-196)  rank sort, transposed factor of the selected rows + mean shift,
+//         whitening matvec, path / step-size update, rank-mu covariance update, factorisation C^{1/2}, C^{-1/2}
+#include "hip_common.h"
+
+extern "C" {
+int evox_hip_split(const int32_t* keys, int32_t* out, int64_t nkeys, int64_t n, void* stream);
+int evox_hip_normal_bf16_pitched(const int32_t* key, void* out, int64_t rows, int64_t n, int64_t ld, int64_t row_offset,
+                                 void* stream);
+int evox_hip_bf16_sample(const void* Z, int64_t ldz, const void* S, int64_t lds, const float* mean, const float* sigma,
+                         float* X, int64_t ldx, int M, int N, int K, void* stream);
+int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order, int64_t* rank_out, int* scratch, void* stream);
+int evox_hip_cma_gather_t(const float* pop, int64_t ldpop, const int64_t* order, const float* mean, const float* rowscale,
+                          const float* sigma, void* yt, int64_t ldy, float* colsum, int rb, float* step, int mu, int n,
+                          int lam, void* stream);
+int evox_hip_cma_paths(const float* mean, const float* step, const float* whitened, const float* ps, const float* pc,
+                       const float* sigma, const float* iter, const float* consts, int n, float* mean_out, float* ps_out,
+                       float* pc_out, float* scalars, void* stream);
+int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C, const float* pc, const float* alpha,
+                      float c1, float cmu, float* out, float* ws, int64_t ws_floats, void* stream);
+int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe, void* planes,
+                          float* f32ws, float* vec, float* scal, const float* prev_sqrt, const float* prev_inv,
+                          float* out_sqrt, float* out_inv, void* out_sqrt_bf16, void* stream);
+int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps, int safe, float* work, const float* eye, float* vec,
+                     float* scal, const float* prev_sqrt, const float* prev_inv, float* out_sqrt, float* out_inv, int tune,
+                     int first_step, void* out_sqrt_bf16, void* stream);
+int evox_hip_ns_cond(const float* inv, int n, float* vec2, float* scal, float* scal2, void* stream);
+}
+
+namespace {
+
+using namespace evox;
+
+// y = A x for a row-major n x n matrix: one wavefront per row, 16-byte loads
+__global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ A, int n, const float* __restrict__ x,
+                                                     float* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
+    const float* r = A + (size_t)row * n;
+    float acc = 0.f;
+    if ((n & 3) == 0) {
+      const float4* r4 = reinterpret_cast<const float4*>(r);
+      const float4* x4 = reinterpret_cast<const float4*>(x);
+      for (int j = lane; j < (n >> 2); j += 64) {
+        const float4 a = r4[j], v = x4[j];
+        acc += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
+      }
+    } else {
+      for (int j = lane; j < n; j += 64) acc += r[j] * x[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+  }
+}
+
+// small device-to-device moves of the control block (fill kernels, not memcpy nodes: the sequence may be recorded)
+__global__ void copy_floats_kernel(const float* __restrict__ src, float* __restrict__ dst, int count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = src[i];
+}
+// vec4 = [v | scratch | v2 | scratch2] <- ctrl (2 x n); and back
+__global__ void vec_in_kernel(const float* __restrict__ ctrl, float* __restrict__ vec4, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n) vec4[(i / n) * 2 * n + (i % n)] = ctrl[i];
+}
+// the control vectors and the 7-float record of the call leave together
+__global__ void ctrl_out_kernel(const float* __restrict__ vec4, const float* __restrict__ scal, float* __restrict__ ctrl,
+                                float* __restrict__ rec, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 2 * n) ctrl[i] = vec4[(i / n) * 2 * n + (i % n)];
+  if (i < 7) rec[i] = scal[9 + i];
+}
+
+}  // namespace
+
+// y = A x (A: n x n row-major fp32): the whitening product of the path update
+EVOX_API int evox_hip_matvec(const float* A, int n, const float* x, float* y, void* stream) {
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  int mv_blocks = (n + 3) / 4;
+  if (mv_blocks > kNumCU * 4) mv_blocks = kNumCU * 4;
+  matvec_kernel<<<mv_blocks, 256, 0, (hipStream_t)stream>>>(A, n, x, y);
+  return last_launch_status();
+}
+
+struct CmaAsk {
+  const int32_t* key;        // [2]
+  int32_t* keys_out;         // [2][2]: next key, sampling key
+  void* z;                   // rows x ldn bf16 draws
+  const void* s16;           // n x ldn bf16 sampling factor
+  const float* mean;
+  const float* sigma;
+  float* x;                  // rows x n fp32 out
+  int64_t ldn, row_offset;
+  int rows, n;
+  int draw;                  // 0: z already holds this generation's draws
+  int split;                 // 0: keys_out already holds the split of key
+  // draws of the NEXT generation on a side stream (they depend on the key alone), all optional
+  int wait_side;             // this generation's split and draws were made ahead: wait for them first
+  int prefetch;              // make the next generation's now
+  void* side;                // hipStream_t (default priority)
+  void* ev_main;             // hipEvent_t pair created by evox_hip_event_create
+  void* ev_side;
+  int32_t* keys_next;        // [2][2]
+  void* z_next;              // the draw buffer that is not `z`
+};
+
+EVOX_API void* evox_hip_event_create() {
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return (void*)e;
+}
+EVOX_API void evox_hip_event_destroy(void* e) {
+  if (e) (void)hipEventDestroy((hipEvent_t)e);
+}
+
+EVOX_API int evox_hip_cma_ask(const CmaAsk* a, void* stream) {
+  int e = 0;
+  hipStream_t main_st = (hipStream_t)stream;
+  if (a->wait_side) {
+    if (hipStreamWaitEvent(main_st, (hipEvent_t)a->ev_side, 0) != hipSuccess) return (int)hipErrorUnknown;
+  }
+  if (a->split) {
+    e = evox_hip_split(a->key, a->keys_out, 1, 2, stream);
+    if (e) return e;
+  }
+  if (a->draw) {
+    e = evox_hip_normal_bf16_pitched(a->keys_out + 2, a->z, a->rows, a->n, a->ldn, a->row_offset, stream);
+    if (e) return e;
+  }
+  e = evox_hip_bf16_sample(a->z, a->ldn, a->s16, a->ldn, a->mean, a->sigma, a->x, a->n, a->rows, a->n, a->n, stream);
+  if (e || !a->prefetch) return e;
+  // The side stream starts after the product above has been issued: the other draw buffer was last read by the
+  // previous generation's product (earlier on this stream), and the key it splits is in keys_out.
+  hipStream_t side = (hipStream_t)a->side;
+  if (hipEventRecord((hipEvent_t)a->ev_main, main_st) != hipSuccess) return (int)hipErrorUnknown;
+  if (hipStreamWaitEvent(side, (hipEvent_t)a->ev_main, 0) != hipSuccess) return (int)hipErrorUnknown;
+  e = evox_hip_split(a->keys_out, a->keys_next, 1, 2, a->side);
+  if (e) return e;
+  e = evox_hip_normal_bf16_pitched(a->keys_next + 2, a->z_next, a->rows, a->n, a->ldn, a->row_offset, a->side);
+  if (e) return e;
+  if (hipEventRecord((hipEvent_t)a->ev_side, side) != hipSuccess) return (int)hipErrorUnknown;
+  return 0;
+}
+
+struct CmaTell {
+  // problem and workspace (constant for a given instance)
+  int n, lam, mu, rb, ns_planes;
+  int64_t ldn, ldmu, cov_ws_floats;
+  float consts[8];           // cs, cc, mueff, cm, damps, chiN, c1, cmu
+  const float* rowscale;     // sqrt of the recombination weights (mu)
+  void* yt;                  // n x ldmu bf16
+  float* colsum;             // rb x n
+  float* cov_ws;
+  int64_t* order;            // lam
+  int* sort_scratch;         // evox_hip_rank_sort_scratch(lam) ints
+  float* step;               // n
+  float* whitened;           // n
+  void* planes;              // Newton-Schulz planes
+  float* ns_f32;             // 3 n^2
+  float* vec4;               // 4 n
+  float* scal;
+  float* scal2;
+  float* lib_work;           // 6 n^2 (fp32 library driver), or null
+  const float* lib_eye;      // n^2 identity, or null
+  // inputs of the call
+  const float* fitness;
+  const float* pop;
+  int64_t ldpop;
+  const float *mean, *ps, *pc, *sigma, *C, *B, *invsqrtC, *iter_dev;
+  const float* ctrl_vec;     // 2 x n power vectors of the factorisation control
+  const float* prev_rec;     // record of the previous call (7 floats): its condition estimates are carried over
+  // outputs
+  float *mean_o, *ps_o, *pc_o, *scalars_o;   // scalars: sigma', alpha, hsig, |ps|, then n floats of scratch
+  float *C_o, *B_o, *inv_o;
+  void* b16_o;               // n x ldn bf16 image of B_o (symmetric driver), or null
+  float* ctrl_vec_o;         // 2 x n
+  float* rec_o;              // 7
+  // factorisation control
+  int factor;                // 0: skip the factorisation (decomp_per_iter > 1)
+  int ns_iters, ns_power, ns_safe, ns_symmetric, ns_cond, ns_first_poly4, ns_tune;
+};
+
+EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int n = t->n;
+  int e = evox_hip_rank_sort_sliced(t->fitness, t->lam, t->order, nullptr, t->sort_scratch, stream);
+  if (e) return e;
+  e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
+                            t->step, t->mu, n, t->lam, stream);
+  if (e) return e;
+  e = evox_hip_matvec(t->invsqrtC, n, t->step, t->whitened, stream);
+  if (e) return e;
+  e = evox_hip_cma_paths(t->mean, t->step, t->whitened, t->ps, t->pc, t->sigma, t->iter_dev, t->consts, n, t->mean_o, t->ps_o,
+                         t->pc_o, t->scalars_o, stream);
+  if (e) return e;
+  e = evox_hip_bf16_cov(t->yt, t->ldmu, n, t->mu, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->C_o,
+                        t->cov_ws, t->cov_ws_floats, stream);
+  if (e || !t->factor) return e;
+  vec_in_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->ctrl_vec, t->vec4, n);
+  if (t->ns_symmetric) {
+    e = evox_hip_ns_sqrt_bf16(t->C_o, n, t->ldn, t->ns_planes, t->ns_iters, t->ns_power, t->ns_safe, t->planes, t->ns_f32,
+                              t->vec4, t->scal, t->B, t->invsqrtC, t->B_o, t->inv_o, t->b16_o, stream);
+  } else {
+    if (t->lib_work == nullptr || t->lib_eye == nullptr) return (int)hipErrorInvalidValue;
+    e = evox_hip_ns_sqrt(t->C_o, n, t->ns_iters, t->ns_power, t->ns_safe, t->lib_work, t->lib_eye, t->vec4, t->scal, t->B,
+                         t->invsqrtC, t->B_o, t->inv_o, t->ns_tune, t->ns_first_poly4, nullptr, stream);
+  }
+  if (e) return e;
+  if (t->ns_cond) {
+    e = evox_hip_ns_cond(t->inv_o, n, t->vec4 + 2 * n, t->scal, t->scal2, stream);
+    if (e) return e;
+  } else {
+    copy_floats_kernel<<<1, 64, 0, st>>>(t->prev_rec, t->scal + 9, 2);
+  }
+  ctrl_out_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->vec4, t->scal, t->ctrl_vec_o, t->rec_o, n);
+  return last_launch_status();
+}

@@ -70,7 +70,21 @@ __global__ __launch_bounds__(256) void so_fitness_kernel(const T* __restrict__ x
     a.s0 = 0.0f;
     a.s1 = (FUNC == kGriewank) ? 1.0f : 0.0f;
     if (live) {
-      if constexpr (FUNC == kAckley) {
+      // rows on 16-byte boundaries: four elements per lane and load (1 KiB per wavefront instruction)
+      const bool vec4 = sizeof(T) == 4 && FUNC != kRosenbrock && LPR == 64 && (dim & 3) == 0 && (pitch & 3) == 0 &&
+                        ((uintptr_t)x & 15) == 0 && !(FUNC == kAckley && p2 != 6.283185307179586f);
+      if (vec4) {
+        if constexpr (sizeof(T) == 4 && FUNC != kRosenbrock) {
+          const float4* rp4 = reinterpret_cast<const float4*>(rp);
+          for (int j = sub; j < (dim >> 2); j += LPR) {
+            const float4 v = rp4[j];
+            accumulate<FUNC>(a, v.x, 0.f, 4 * j, false);
+            accumulate<FUNC>(a, v.y, 0.f, 4 * j + 1, false);
+            accumulate<FUNC>(a, v.z, 0.f, 4 * j + 2, false);
+            accumulate<FUNC>(a, v.w, 0.f, 4 * j + 3, false);
+          }
+        }
+      } else if constexpr (FUNC == kAckley) {
         // general c: cos(c*x); the default c = 2*pi takes the exact cospi path
         if (p2 == 6.283185307179586f) {
           for (int j = sub; j < dim; j += LPR) accumulate<FUNC>(a, load1(rp + j), 0.f, j, false);

@@ -85,12 +85,84 @@ __global__ __launch_bounds__(kThreads) void rank_sort_kernel(const float* __rest
   }
 }
 
+// The same count spread over more workgroups for key vectors that would otherwise leave most of the chip idle
+// (10^4 keys are 157 blocks of 64 rows): the j range is cut into kSlices slices, block (rows, slice) writes the
+// partial count of its rows, and the second kernel adds the slices of a row (integers: any order gives the same sum)
+// and scatters the order.
+constexpr int kSlices = 4;
+
+__global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __restrict__ keys, int n, int* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) uint32_t sk[kChunk];
+  __shared__ int part[kWaves][kRows];
+  const int il = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = blockIdx.x * kRows;
+  const int i = i0 + il;
+  const uint32_t ki = i < n ? sortable(keys[i]) : 0xFFFFFFFEu;
+  // this block's slice of the keys, in whole groups of four
+  const int per = ((n + kSlices - 1) / kSlices + 3) / 4 * 4;
+  const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
+  int cnt = 0;
+  for (int base = j0; base < j1; base += kChunk) {
+    const int len = min(kChunk, j1 - base);
+    const int padded = (len + 4 * kWaves - 1) / (4 * kWaves) * (4 * kWaves);
+    for (int t = threadIdx.x; t < padded; t += kThreads) sk[t] = t < len ? sortable(keys[base + t]) : 0xFFFFFFFFu;
+    __syncthreads();
+    const int q = padded / kWaves;
+    const int lo = s * q, hi = lo + q;
+    const int m0 = min(max(i0 - base, lo), hi), m1 = min(max(i0 + kRows - base, lo), hi);
+    cnt += count_below(sk, lo, m0, ki + 1u);
+    {
+      const uint4* p4 = reinterpret_cast<const uint4*>(sk);
+#pragma unroll 16
+      for (int g = m0 >> 2; g < (m1 >> 2); ++g) {
+        const uint4 k = p4[g];
+        const int gj = base + 4 * g;
+        cnt += (int)(k.x < ki + (uint32_t)(gj + 0 < i)) + (int)(k.y < ki + (uint32_t)(gj + 1 < i)) +
+               (int)(k.z < ki + (uint32_t)(gj + 2 < i)) + (int)(k.w < ki + (uint32_t)(gj + 3 < i));
+      }
+    }
+    cnt += count_below(sk, m1, hi, ki);
+    __syncthreads();
+  }
+  part[s][il] = cnt;
+  __syncthreads();
+  if (s == 0 && i < n) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) r += part[w][il];
+    partial[(size_t)blockIdx.y * n + i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const int* __restrict__ partial, int n, int64_t* __restrict__ order,
+                                                           int64_t* __restrict__ rank_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int r = 0;
+#pragma unroll
+  for (int sl = 0; sl < kSlices; ++sl) r += partial[(size_t)sl * n + i];
+  order[r] = i;
+  if (rank_out) rank_out[i] = r;
+}
+
 }  // namespace
 
 // order[r] = index of the r-th smallest key (stable); rank_out (optional) = inverse permutation
 EVOX_API int evox_hip_rank_sort(const float* keys, int n, int64_t* order, int64_t* rank_out, void* stream) {
   if (n <= 0) return 0;
   rank_sort_kernel<<<(n + kRows - 1) / kRows, kThreads, 0, (hipStream_t)stream>>>(keys, n, order, rank_out);
+  return evox::last_launch_status();
+}
+
+// The sliced form: `scratch` holds evox_hip_rank_sort_scratch(n) ints.
+EVOX_API int64_t evox_hip_rank_sort_scratch(int n) { return (int64_t)kSlices * (n > 0 ? n : 0); }
+
+EVOX_API int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order, int64_t* rank_out, int* scratch, void* stream) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  rank_count_kernel<<<dim3((n + kRows - 1) / kRows, kSlices), kThreads, 0, st>>>(keys, n, scratch);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out);
   return evox::last_launch_status();
 }
 

@@ -97,6 +97,11 @@ class CMAES(Algorithm):
                               and os.environ.get("EVOX_AMD_GEMM", "hip") != "torch")
         self._workspaces = {}
         self._factor_cache = (None, None)        # (fp32 factor tensor, its padded bf16 image)
+        self._split_ahead = None                 # (key tensor, next key, sampling key) made one generation ahead
+        # the whole kernel sequence of ask / tell from one native call each (``EVOX_AMD_CMA_NATIVE=0``: one call per op)
+        self._native_calls = self._bf16_kernels and os.environ.get("EVOX_AMD_CMA_NATIVE", "1") != "0"
+        self._prefetch_draws = os.environ.get("EVOX_AMD_CMA_PREFETCH", "0") == "1"   # measured slower: the draw kernel competes with the factorisation for CUs
+        self._generations = {}
         if decomposition == "newton_schulz":
             planes = int(os.environ.get("EVOX_AMD_NS_PLANES", "2")) if self._bf16_kernels else 0
             self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16" and not planes, planes=planes)
@@ -128,6 +133,14 @@ class CMAES(Algorithm):
             ws = self._workspaces[key] = _b16.Workspace(self.dim, rows, mu, self.center_init.device,
                                                         ns_planes=max(self._ns.planes, 2) if self._ns is not None else 2)
         return ws
+
+    def _generation(self, ws):
+        from ....ops import cma_native as _nat
+        g = self._generations.get(id(ws))
+        if g is None:
+            g = self._generations[id(ws)] = _nat.Generation(
+                ws, self._sqrt_w, (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu), self._ns)
+        return g
 
     def _factor_bf16(self, state, ws):
         """Zero-padded bf16 image of the sampling factor (``B`` in the Newton–Schulz mode, ``B·diag(D)``
@@ -173,16 +186,36 @@ class CMAES(Algorithm):
         # the Newton–Schulz mode stores the whole factor C^{1/2} in B and leaves D at ones
         return None if self._ns is not None else state.D
 
-    def _sample(self, state, sample_key, rows: int, row_offset: int = 0, mu: Optional[int] = None):
+    def _keys(self, state):
+        """``(next key, sampling key)`` of this generation: the split made ahead by the previous ``ask`` when it
+        was made for this very key tensor (see ``_sample``), a fresh split otherwise — the same values either way."""
+        ahead, self._split_ahead = self._split_ahead, None
+        if ahead is not None and ahead[0] is state.key:
+            return ahead[1], ahead[2]
+        return rnd.split(state.key)
+
+    def _sample(self, state, key, sample_key, rows: int, row_offset: int = 0, mu: Optional[int] = None):
         if self._bf16_kernels and state.mean.is_cuda:
             ws = self._workspace(rows, self.mu if mu is None else mu)
-            return _b16.sample(sample_key, state.mean, state.sigma, self._factor_bf16(state, ws), rows, ws, row_offset)
+            pop = _b16.sample(sample_key, state.mean, state.sigma, self._factor_bf16(state, ws), rows, ws, row_offset)
+            if not torch.cuda.is_current_stream_capturing() and os.environ.get("EVOX_AMD_CMA_PREFETCH", "0") == "1":
+                # the Gaussian draws of the next generation depend on the key alone: they are produced on a side
+                # stream while this generation is evaluated and told
+                k2, s2 = rnd.split(key)
+                self._split_ahead = (key, k2, s2)
+                ws.prefetch_normal(s2, rows, self.dim, row_offset)
+            return pop
         return _cma.sample(sample_key, state.mean, state.sigma, state.B, self._sample_scale(state), rows, self.precision,
                            row_offset=row_offset)
 
     def ask(self, state):
-        key, sample_key = rnd.split(state.key)
-        population = self._sample(state, sample_key, self.pop_size)
+        if self._native_calls and state.mean.is_cuda:
+            ws = self._workspace(self.pop_size, self.mu)
+            population, key = self._generation(ws).ask(state.key, self._factor_bf16(state, ws), state.mean, state.sigma,
+                                                       self.pop_size, 0, self._prefetch_draws)
+        else:
+            key, sample_key = self._keys(state)
+            population = self._sample(state, key, sample_key, self.pop_size)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
@@ -204,9 +237,43 @@ class CMAES(Algorithm):
         return ps, pc, hsig, sigma
 
     def _whiten(self, state, delta):
+        if self._bf16_kernels and delta.is_cuda and state.invsqrtC.dim() == 2:
+            return _b16.matvec(state.invsqrtC, delta)
         return state.invsqrtC @ delta
 
+    def _tell_native(self, state, fitness):
+        """``tell`` as one native call (same kernels and arithmetic as the op-by-op path below)."""
+        ws = self._workspace(self.pop_size, self.mu)
+        gen = self._generation(ws)
+        factor = state.count_iter % self.decomp_per_iter == 0
+        ns = self._ns
+        plan = None
+        if factor and ns is not None:
+            capturing = torch.cuda.is_current_stream_capturing()
+            ctrl = {k: getattr(state, k) for k in ns.CONTROL_FIELDS}
+            plan = ns.plan(ctrl, capturing, True, True)
+        fitness = fitness.contiguous()
+        mean, ps, pc, sigma, C, B, inv, b16, vec_o, rec = gen.tell(state, fitness, factor and ns is not None, plan)
+        extra = {}
+        if not factor:
+            B, D, inv, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
+        elif ns is not None:
+            D, count_eigen = state.D, state.count_eigen + 1
+            if b16 is not None:
+                self._factor_cache = (B, b16)
+            if capturing:
+                ns._graph_scal = gen.scal[9:16]
+            extra = ns.commit(ctrl, plan, rec, vec_o, capturing)
+        else:
+            B, D, inv, extra = self._factorise(state, C, ws)
+            count_eigen = state.count_eigen + 1
+        return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=inv, count_eigen=count_eigen,
+                             **extra)
+
     def tell(self, state, fitness):
+        if (self._native_calls and state.population.is_cuda and fitness.dtype == torch.float32
+                and fitness.shape[0] == self.pop_size <= 16384):
+            return self._tell_native(state, fitness)
         order = _sort.argsort(fitness)
         ws = None
         if self._bf16_kernels and state.population.is_cuda:
@@ -258,9 +325,9 @@ class CMAES(Algorithm):
         if self.pop_size % world:
             raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
         local = self.pop_size // world
-        key, sample_key = rnd.split(state.key)
+        key, sample_key = self._keys(state)
         consts = self._shard_consts(local, state.mean.device)
-        population = self._sample(state, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
+        population = self._sample(state, key, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 

@@ -29,6 +29,7 @@ _native.register_hip_api({
     "evox_hip_bf16_cov": (I, [P, I64, I, I, P, P, P, F, F, P, P, I64, P]),
     "evox_hip_ns_scal_floats": (I, []),
     "evox_hip_ns_sqrt_bf16": (I, [P, I, I64, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "evox_hip_matvec": (I, [P, I, P, P, P]),
 })
 
 
@@ -58,9 +59,14 @@ class Workspace:
     def __init__(self, n: int, lam: int, mu: int, device, ns_planes: int = 2):
         self.n, self.lam, self.mu, self.device = int(n), int(lam), int(mu), device
         self.ldn, self.ldmu = pitch(n), pitch(mu)
-        self.Z = torch.zeros((lam, self.ldn), dtype=torch.bfloat16, device=device)
+        # Gaussian draws of a generation: two buffers, so that the draws of the next generation can be produced on
+        # a side stream while the current one is still being consumed (``prefetch_normal``)
+        self._Z = [torch.zeros((lam, self.ldn), dtype=torch.bfloat16, device=device) for _ in range(2)]
+        self._z_next = 0
+        self._prefetch = None            # (key tensor, rows, row_offset, buffer, event)
+        self._side = None
         self.Yt = torch.zeros((n, self.ldmu), dtype=torch.bfloat16, device=device)
-        self.rb = max(1, min(32, (mu + 63) // 64))
+        self.rb = max(1, min(96, (mu + 63) // 64))          # row tiles of the gather that run as separate workgroups
         self.colsum = torch.empty((self.rb, n), dtype=torch.float32, device=device)
         self.cov_splits = int(hip().evox_hip_bf16_cov_splits(n, mu)) if (n % 4 == 0) else 0
         self.cov_ws = torch.empty((max(self.cov_splits, 1), n, n), dtype=torch.float32, device=device) if self.cov_splits else None
@@ -70,6 +76,39 @@ class Workspace:
         # bf16 images of the sampling factor: a ring of two, handed out alternately (see ``factor_buffer``)
         self._factor = [torch.zeros((n, self.ldn), dtype=torch.bfloat16, device=device) for _ in range(2)]
         self._factor_next = 0
+
+    @property
+    def Z(self) -> torch.Tensor:
+        return self._Z[self._z_next]
+
+    def draws(self, key: torch.Tensor, rows: int, n: int, row_offset: int) -> torch.Tensor:
+        """The (rows, pitch) bf16 draws ``normal(key, (·, n))[row_offset:row_offset + rows]``: taken from the
+        prefetch when it was made for this very key tensor, drawn on the current stream otherwise."""
+        pf, self._prefetch = self._prefetch, None
+        if pf is not None and pf[0] is key and pf[1] == rows and pf[2] == row_offset:
+            torch.cuda.current_stream(self.device).wait_event(pf[4])
+            self._z_next = 0 if pf[3] is self._Z[0] else 1
+            return pf[3][:rows]
+        z = self._Z[self._z_next][:rows]
+        normal_pitched(key, z, n, row_offset)
+        return z
+
+    def prefetch_normal(self, key: torch.Tensor, rows: int, n: int, row_offset: int):
+        """Start the draws of the NEXT generation (its sampling key is already known) on a side stream into the
+        buffer that is not in use; ``draws`` hands them out when asked for the same key tensor."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        buf = self._Z[self._z_next ^ 1]
+        self._side.wait_stream(main)             # the key exists, and the last reader of `buf` has been issued
+        with torch.cuda.stream(self._side):
+            normal_pitched(key, buf[:rows], n, row_offset)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        key.record_stream(self._side)
+        self._prefetch = (key, rows, row_offset, buf, ev)
 
     def factor_buffer(self) -> torch.Tensor:
         """A zero-padded (n, pitch(n)) bf16 buffer for the next sampling factor.  Two buffers alternate, so the
@@ -110,8 +149,7 @@ def sample(key, mean, sigma, S_bf16, pop_size: int, ws: Workspace, row_offset: i
     n = mean.shape[0]
     if pop_size > ws.lam or n != ws.n or S_bf16.shape != (n, ws.ldn) or S_bf16.dtype != torch.bfloat16:
         raise ValueError("sample: operands do not match the workspace")
-    z = ws.Z[:pop_size]
-    normal_pitched(key, z, n, row_offset)
+    z = ws.draws(key, pop_size, n, row_offset)
     if out is None:
         out = torch.empty((pop_size, n), dtype=torch.float32, device=mean.device)
     sig = sigma.reshape(1) if isinstance(sigma, torch.Tensor) else torch.tensor([float(sigma)], device=mean.device)
@@ -168,7 +206,7 @@ def gram(ws: Workspace, out: torch.Tensor):
 
 def ns_sqrt(C, ws: Workspace, iters: int, scal: torch.Tensor | None = None, vec: torch.Tensor | None = None, *,
             power_steps: int = 1, safe: bool = False, prev=None):
-    """``(sqrtC, invsqrtC, sqrtC_bf16)`` after ``iters`` (≥ 2) coupled Newton–Schulz steps whose products are
+    """``(sqrtC, invsqrtC, sqrtC_bf16)`` after ``iters`` (≥ 1) coupled Newton–Schulz steps whose products are
     symmetric-half products of bf16 split planes (well-conditioned ``C`` only: see ``NewtonSchulzSqrt.step``).
     ``sqrtC_bf16`` is the (n, pitch(n)) zero-padded bf16 copy the sampling product reads.  ``scal`` (the driver's
     scalar block) and ``vec`` (2n floats, the first n a unit vector carried between calls) default to the
@@ -184,9 +222,18 @@ def ns_sqrt(C, ws: Workspace, iters: int, scal: torch.Tensor | None = None, vec:
     out_s, out_i = torch.empty_like(C), torch.empty_like(C)
     out_b = ws.factor_buffer()
     ps, pi = (prev[0].contiguous(), prev[1].contiguous()) if prev is not None else (None, None)
-    check(hip().evox_hip_ns_sqrt_bf16(C.data_ptr(), n, ws.ldn, ws.ns_planes, max(2, int(iters)), int(power_steps),
+    check(hip().evox_hip_ns_sqrt_bf16(C.data_ptr(), n, ws.ldn, ws.ns_planes, max(1, int(iters)), int(power_steps),
                                       int(bool(safe)), st["planes"].data_ptr(), st["f32"].data_ptr(), vec.data_ptr(),
                                       scal.data_ptr(), ps.data_ptr() if ps is not None else None,
                                       pi.data_ptr() if pi is not None else None, out_s.data_ptr(), out_i.data_ptr(),
                                       out_b.data_ptr(), stream_of(C)), "ns_sqrt_bf16")
     return out_s, out_i, out_b
+
+
+def matvec(A: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``A @ x`` for a contiguous fp32 (n, n) matrix: one wavefront per row, a fixed summation order (the whitening
+    product of the path update; the native generation driver runs the same kernel)."""
+    n = A.shape[0]
+    y = torch.empty(n, dtype=torch.float32, device=A.device)
+    check(hip().evox_hip_matvec(A.contiguous().data_ptr(), n, x.contiguous().data_ptr(), y.data_ptr(), stream_of(A)), "matvec")
+    return y

@@ -10,11 +10,14 @@ from .. import _native
 from ._util import check, hip, stream_of
 
 P, I = _native.P, _native.I
-_native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
+_native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]),
+                          "evox_hip_rank_sort_scratch": (_native.I64, [I]),
+                          "evox_hip_rank_sort_sliced": (I, [P, I, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
                           "evox_hip_select_wide_ws": (_native.I64, [I]),
                           "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
 _RANK_SORT_MAX = 16384
+_SLICED_MIN = 2048          # from here on the two-launch sliced count beats the one-launch form
 
 
 def _rank_sortable(keys: torch.Tensor) -> bool:
@@ -26,6 +29,12 @@ def _rank_sort(keys: torch.Tensor, want_rank: bool):
     keys = keys.contiguous()
     order = torch.empty(n, dtype=torch.int64, device=keys.device)
     rank = torch.empty(n, dtype=torch.int64, device=keys.device) if want_rank else None
+    if n >= _SLICED_MIN:
+        # too few 64-row blocks to fill the chip: the count is spread over four times as many workgroups
+        scratch = torch.empty(int(hip().evox_hip_rank_sort_scratch(n)), dtype=torch.int32, device=keys.device)
+        check(hip().evox_hip_rank_sort_sliced(keys.data_ptr(), n, order.data_ptr(), rank.data_ptr() if want_rank else None,
+                                              scratch.data_ptr(), stream_of(keys)), "rank_sort_sliced")
+        return order, rank
     check(hip().evox_hip_rank_sort(keys.data_ptr(), n, order.data_ptr(), rank.data_ptr() if want_rank else None,
                                    stream_of(keys)), "rank_sort")
     return order, rank

@@ -1117,3 +1117,58 @@ def test_cmaes_bf16_kernels_track_fp32_run(cuda):
     a = out["bf16"][2]
     assert torch.equal(a.C, a.C.T) and a.ns_calls == 120 and 2 <= a.ns_iters <= 8
     assert algo._ns.symmetric_calls >= 100, algo._ns.symmetric_calls        # a Sphere keeps C well conditioned
+
+
+@pytest.mark.parametrize("decomposition", ["newton_schulz", "eigh"])
+def test_cmaes_native_generation_equals_op_by_op(cuda, decomposition, monkeypatch):
+    """ask / tell issued as one native call each run the same kernels on the same operands as the op-by-op path:
+    the two runs agree to the last bit, state field by state field."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    def run(native):
+        monkeypatch.setenv("EVOX_AMD_CMA_NATIVE", "1" if native else "0")
+        algo = algorithms.CMAES(torch.full((96,), 2.0, device=cuda), 1.0, pop_size=320, decomposition=decomposition,
+                                precision="bf16")
+        assert algo._native_calls == native
+        wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin())
+        s = wf.init(ex.PRNGKey(11))
+        for _ in range(25):
+            s = wf.step(s)
+        return s.get_child_state("algorithm"), algo
+
+    a, algo_a = run(True)
+    b, algo_b = run(False)
+    for k in ("mean", "sigma", "ps", "pc", "C", "B", "invsqrtC", "population", "key"):
+        assert torch.equal(getattr(a, k), getattr(b, k)), k
+    if decomposition == "newton_schulz":
+        assert a.ns_iters == b.ns_iters and a.ns_calls == b.ns_calls == 25
+        assert torch.equal(a.ns_vec, b.ns_vec) and torch.equal(a.ns_res1, b.ns_res1)
+        assert algo_a._ns.symmetric_calls == algo_b._ns.symmetric_calls > 0
+
+
+def test_newton_schulz_fifth_order_step_alone(cuda):
+    """iters = 1: the fifth-order first step is the whole factorisation (covariances close to a multiple of the
+    identity); the residual then comes from a probe vector and the guard still passes previous factors on."""
+    from evox_amd.ops import cma_bf16 as b16
+
+    n = 1000
+    a = torch.randn(n, 4 * n, device=cuda, dtype=torch.float64)
+    C64 = 2.5 * (a @ a.T / (4 * n)) * 0.2 + 2.0 * torch.eye(n, device=cuda, dtype=torch.float64)   # eigenvalues in about [2.0, 3.2]
+    C64 = 0.5 * (C64 + C64.T)
+    C = C64.float()
+    ws = b16.Workspace(n, 8, 4, cuda)
+    s, zi, s16 = b16.ns_sqrt(C, ws, 1, power_steps=8)
+    scal = ws.ns()["scal"]
+    eye = torch.eye(n, device=cuda, dtype=torch.float64)
+    true_res = float((zi.double() @ s.double() - eye).norm() / n ** 0.5)
+    assert float((s.double() @ s.double() - C64).norm() / C64.norm()) < 5e-4
+    assert true_res < 5e-4 and float(scal[15]) == 0.0
+    assert 0.3 * true_res < float(scal[14]) < 3.0 * true_res + 1e-6          # the probe estimate tracks the true residual
+    assert torch.equal(s, s.T) and torch.equal(zi, zi.T) and torch.equal(s16[:, :n], s.to(torch.bfloat16))
+    bad = C.clone()
+    bad[3, 3] = float("inf")
+    prev = (torch.full_like(C, 3.0), torch.full_like(C, 4.0))
+    s, zi, s16 = b16.ns_sqrt(bad, ws, 1, prev=prev)
+    assert float(scal[15]) == 1.0 and torch.equal(s, prev[0]) and torch.equal(zi, prev[1])
+    assert torch.equal(s16[:, :n], prev[0].to(torch.bfloat16))
