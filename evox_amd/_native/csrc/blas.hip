@@ -595,7 +595,18 @@ __global__ __launch_bounds__(256) void ns_probe_mv_kernel(const float* __restric
   for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
     const float* r = A + (size_t)row * n;
     float acc = 0.f;
-    for (int j = lane; j < n; j += 64) acc = fmaf(r[j], x != nullptr ? x[j] : probe_v(j), acc);
+    if ((n & 3) == 0) {
+      const float4* r4 = reinterpret_cast<const float4*>(r);
+      for (int j = lane; j < (n >> 2); j += 64) {
+        const float4 a = r4[j];
+        float4 v;
+        if (x != nullptr) v = reinterpret_cast<const float4*>(x)[j];
+        else v = make_float4(probe_v(4 * j), probe_v(4 * j + 1), probe_v(4 * j + 2), probe_v(4 * j + 3));
+        acc += (a.x * v.x + a.y * v.y) + (a.z * v.z + a.w * v.w);
+      }
+    } else {
+      for (int j = lane; j < n; j += 64) acc = fmaf(r[j], x != nullptr ? x[j] : probe_v(j), acc);
+    }
     acc = evox::wave_sum(acc);
     if (residual) {
       const float v = probe_v(row), d = acc - v;
@@ -615,25 +626,22 @@ __global__ __launch_bounds__(256) void ns_probe_mv_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void ns_probe_flags_kernel(float* scal, int blocks, int have_prev) {
+// The probe residual from its partials and the guard in one launch: every block derives the verdict itself (250
+// partials), block 0 records it, and only a failed factorisation copies the previous factors over the outputs.
+__global__ __launch_bounds__(256) void ns_probe_guard_kernel(float* scal, int blocks, const float* __restrict__ prev_sqrt,
+                                                             const float* __restrict__ prev_inv, float* __restrict__ out_sqrt,
+                                                             float* __restrict__ out_inv, uint16_t* __restrict__ out_b16, int n,
+                                                             int64_t ldp) {
   __shared__ float red[4];
   const float d2 = block_reduce(part_row(scal, kRowRes), blocks, false, red);
   const float v2 = block_reduce(part_row(scal, kMaxPow - 1), blocks, false, red);
-  if (threadIdx.x == 0) {
-    const float res = sqrtf(d2 / fmaxf(v2, 1e-38f));
-    const bool good = res < 0.25f;                        // false for NaN
+  const float res = sqrtf(d2 / fmaxf(v2, 1e-38f));
+  const bool failed = !(res < 0.25f) && prev_sqrt != nullptr && prev_inv != nullptr;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     scal[14] = res;
-    scal[15] = (!good && have_prev) ? 1.f : 0.f;
+    scal[15] = failed ? 1.f : 0.f;
   }
-}
-
-// a failed factorisation passes the previous factors on: copies only when scal[15] is set
-template <int NSP_UNUSED = 0>
-__global__ __launch_bounds__(256) void ns_guard_kernel(const float* scal, const float* __restrict__ prev_sqrt,
-                                                       const float* __restrict__ prev_inv, float* __restrict__ out_sqrt,
-                                                       float* __restrict__ out_inv, uint16_t* __restrict__ out_b16, int n,
-                                                       int64_t ldp) {
-  if (scal[15] == 0.f) return;
+  if (!failed) return;
   const int64_t total = (int64_t)n * n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const float sv = prev_sqrt[i];
@@ -765,11 +773,8 @@ int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_step
     float* w = Tf;                                        // n floats of scratch
     ns_probe_mv_kernel<<<mv_blocks, 256, 0, stream>>>(out_sqrt, n, nullptr, w, scal, 0);
     ns_probe_mv_kernel<<<mv_blocks, 256, 0, stream>>>(out_inv, n, w, nullptr, scal, 1);
-    const int have_prev = prev_sqrt != nullptr && prev_inv != nullptr;
-    ns_probe_flags_kernel<<<1, 256, 0, stream>>>(scal, mv_blocks, have_prev);
-    if (have_prev)
-      ns_guard_kernel<><<<evox::stream_grid(nn, 256), 256, 0, stream>>>(scal, prev_sqrt, prev_inv, out_sqrt, out_inv,
-                                                                       out_sqrt_bf16, n, ldp);
+    ns_probe_guard_kernel<<<evox::stream_grid(nn, 256), 256, 0, stream>>>(scal, mv_blocks, prev_sqrt, prev_inv, out_sqrt,
+                                                                         out_inv, out_sqrt_bf16, n, ldp);
     return evox::last_launch_status();
   }
   {

@@ -44,6 +44,27 @@ __global__ __launch_bounds__(256) void normal_bf16_pitched_kernel(const int32_t*
   }
 }
 
+// The same draws for rows whose length is a multiple of 4 (a counter block never straddles rows): one wavefront per
+// row, lanes over the row's counter blocks — no 64-bit division per block, one 8-byte store per lane and block.
+__global__ __launch_bounds__(256) void normal_bf16_rows_kernel(const int32_t* __restrict__ key, uint16_t* __restrict__ out,
+                                                               int64_t rows, int n, int64_t ld, int64_t row_offset) {
+  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  const int lane = threadIdx.x & 63;
+  const int bpr = n >> 2;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const uint64_t b0 = (uint64_t)(row_offset + r) * (uint64_t)bpr;
+    uint16_t* orow = out + r * ld;
+    for (int cb = lane; cb < bpr; cb += 64) {
+      const f32x4 g = normal4(philox_block(k0, k1, b0 + (uint64_t)cb, kStreamDraw));
+      const uint32_t lo = f32_to_bf16_bits(g.x) | (f32_to_bf16_bits(g.y) << 16);
+      const uint32_t hi = f32_to_bf16_bits(g.z) | (f32_to_bf16_bits(g.w) << 16);
+      *reinterpret_cast<uint2*>(orow + 4 * cb) = make_uint2(lo, hi);
+    }
+  }
+}
+
 // Gather + centre + scale + transpose.  Block (ct, rb): columns [64 ct, 64 ct + 64), selected individuals in tiles of
 // 64 (tile rb, rb + gridDim.y, ...).  A tile is read row-wise with 16-byte loads (every lane has its four loads of a
 // tile in flight together) and written column-wise (128 contiguous bytes per column) through LDS.
@@ -215,6 +236,12 @@ EVOX_API int evox_hip_normal_bf16_pitched(const int32_t* key, void* out, int64_t
                                           int64_t row_offset, void* stream) {
   if (rows <= 0 || n <= 0) return 0;
   if (ld < n) return (int)hipErrorInvalidValue;
+  if ((n & 3) == 0 && (ld & 3) == 0 && n < (1ll << 31) && ((uintptr_t)out & 7) == 0) {
+    int64_t blocks = (rows + 3) / 4;                       // four rows (wavefronts) per workgroup
+    if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+    normal_bf16_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(key, (uint16_t*)out, rows, (int)n, ld, row_offset);
+    return last_launch_status();
+  }
   const uint64_t first_e = (uint64_t)row_offset * (uint64_t)n, last_e = first_e + (uint64_t)rows * (uint64_t)n;
   const int64_t nblk = (int64_t)(((last_e - 1) >> 2) - (first_e >> 2) + 1);
   normal_bf16_pitched_kernel<<<stream_grid(nblk, 256), 256, 0, (hipStream_t)stream>>>(key, (uint16_t*)out, rows, n, ld, row_offset);

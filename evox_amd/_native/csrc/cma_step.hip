@@ -71,12 +71,13 @@ __global__ void vec_in_kernel(const float* __restrict__ ctrl, float* __restrict_
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n) vec4[(i / n) * 2 * n + (i % n)] = ctrl[i];
 }
-// the control vectors and the 7-float record of the call leave together
-__global__ void ctrl_out_kernel(const float* __restrict__ vec4, const float* __restrict__ scal, float* __restrict__ ctrl,
-                                float* __restrict__ rec, int n) {
+// The control vectors and the 7-float record of the call leave together.  Without a refresh of the condition
+// estimates (`carry` set) the two estimates of the previous record are carried over.
+__global__ void ctrl_out_kernel(const float* __restrict__ vec4, const float* __restrict__ scal, const float* __restrict__ carry,
+                                float* __restrict__ ctrl, float* __restrict__ rec, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n) ctrl[i] = vec4[(i / n) * 2 * n + (i % n)];
-  if (i < 7) rec[i] = scal[9 + i];
+  if (i < 7) rec[i] = (carry != nullptr && i < 2) ? carry[i] : scal[9 + i];
 }
 
 }  // namespace
@@ -217,9 +218,8 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   if (t->ns_cond) {
     e = evox_hip_ns_cond(t->inv_o, n, t->vec4 + 2 * n, t->scal, t->scal2, stream);
     if (e) return e;
-  } else {
-    copy_floats_kernel<<<1, 64, 0, st>>>(t->prev_rec, t->scal + 9, 2);
   }
-  ctrl_out_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->vec4, t->scal, t->ctrl_vec_o, t->rec_o, n);
+  ctrl_out_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->vec4, t->scal, t->ns_cond ? nullptr : t->prev_rec, t->ctrl_vec_o,
+                                                      t->rec_o, n);
   return last_launch_status();
 }

@@ -89,9 +89,10 @@ __global__ __launch_bounds__(kThreads) void rank_sort_kernel(const float* __rest
 // (10^4 keys are 157 blocks of 64 rows): the j range is cut into kSlices slices, block (rows, slice) writes the
 // partial count of its rows, and the second kernel adds the slices of a row (integers: any order gives the same sum)
 // and scatters the order.
-constexpr int kSlices = 4;
+constexpr int kSlices = 4;      // upper bound; a launch uses as many as keep rows x slices within one round of blocks
 
-__global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __restrict__ keys, int n, int* __restrict__ partial) {
+__global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __restrict__ keys, int n, int* __restrict__ partial,
+                                                              int slices) {
   __shared__ __attribute__((aligned(16))) uint32_t sk[kChunk];
   __shared__ int part[kWaves][kRows];
   const int il = threadIdx.x & 63;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __res
   const int i = i0 + il;
   const uint32_t ki = i < n ? sortable(keys[i]) : 0xFFFFFFFEu;
   // this block's slice of the keys, in whole groups of four
-  const int per = ((n + kSlices - 1) / kSlices + 3) / 4 * 4;
+  const int per = ((n + slices - 1) / slices + 3) / 4 * 4;
   const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
   int cnt = 0;
   for (int base = j0; base < j1; base += kChunk) {
@@ -136,12 +137,11 @@ __global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __res
 }
 
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const int* __restrict__ partial, int n, int64_t* __restrict__ order,
-                                                           int64_t* __restrict__ rank_out) {
+                                                           int64_t* __restrict__ rank_out, int slices) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int r = 0;
-#pragma unroll
-  for (int sl = 0; sl < kSlices; ++sl) r += partial[(size_t)sl * n + i];
+  for (int sl = 0; sl < slices; ++sl) r += partial[(size_t)sl * n + i];
   order[r] = i;
   if (rank_out) rank_out[i] = r;
 }
@@ -161,8 +161,12 @@ EVOX_API int64_t evox_hip_rank_sort_scratch(int n) { return (int64_t)kSlices * (
 EVOX_API int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order, int64_t* rank_out, int* scratch, void* stream) {
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  rank_count_kernel<<<dim3((n + kRows - 1) / kRows, kSlices), kThreads, 0, st>>>(keys, n, scratch);
-  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out);
+  // two 1024-thread blocks fit a CU: stay within one round of 512 blocks
+  const int rows = (n + kRows - 1) / kRows;
+  int slices = 2 * evox::kNumCU / rows;
+  slices = slices < 1 ? 1 : (slices > kSlices ? kSlices : slices);
+  rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices);
   return evox::last_launch_status();
 }
 
