@@ -23,35 +23,16 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port() -> int:
-    import socket
-
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
 def _self_launch(n: int) -> int:
-    """Run this script as ``n`` ranks on this node (one child process per rank, rendezvous on 127.0.0.1)."""
-    import subprocess
+    """Run this script as ``n`` ranks on this node (``evox_amd/utils/launch.py``, loaded by path so that this
+    parent process imports neither torch nor the package)."""
+    import importlib.util
 
-    port = os.environ.get("MASTER_PORT") or str(_free_port())
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        worst = worst or p.returncode
-    if out:
-        sys.stdout.write(out)
-        sys.stdout.flush()
-    return worst
+    spec = importlib.util.spec_from_file_location(
+        "_evox_launch", os.path.join(os.path.dirname(os.path.abspath(__file__)), "evox_amd", "utils", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.launch_ranks(__file__, sys.argv[1:], n)
 
 
 def main():
@@ -61,7 +42,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--pop", type=int, default=10000, help="population per GPU (weak) or total (strong)")
     ap.add_argument("--dim", type=int, default=1000)
-    ap.add_argument("--problem", default="ackley", choices=["ackley", "sphere"])
+    ap.add_argument("--problem", default="ackley", choices=["ackley", "sphere", "rosenbrock", "ellipsoid"])
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"],
                     help="operands of the sampling and covariance GEMMs (accumulation, state and factorisation are fp32)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -114,7 +95,8 @@ def main():
     center = ex.random.uniform(ex.random.fold_in(key, 1), (args.dim,), minval=-5.0, maxval=5.0).to(dev)
     algo = algorithms.CMAES(center_init=center, init_stdev=1.0, pop_size=total_pop, precision=args.precision,
                             eigh_method=args.eigh, decomposition=args.decomp)
-    problem = problems.numerical.Ackley() if args.problem == "ackley" else problems.numerical.Sphere()
+    problem = {"ackley": problems.numerical.Ackley, "sphere": problems.numerical.Sphere,
+               "rosenbrock": problems.numerical.Rosenbrock, "ellipsoid": problems.numerical.Ellipsoid}[args.problem]()
     if world > 1:
         from evox_amd.workflows import ShardedWorkflow
 
@@ -150,11 +132,19 @@ def main():
 
     alg_state = state.get_child_state("algorithm")
     sigma = float(alg_state.sigma)
+    best = float(problem.evaluate(None, alg_state.mean.reshape(1, -1).float())[0][0])
+    ns = getattr(algo, "_ns", None)
+    ns_report = None
+    if ns is not None and "ns_iters" in alg_state:
+        # which driver factorised, with how many iterations, and the condition bound it acted on
+        ns_report = {"iterations": int(alg_state.ns_iters), "calls": int(alg_state.ns_calls),
+                     "symmetric_bf16_calls": int(ns.symmetric_calls), "guard_fallbacks": int(ns.fallbacks),
+                     "cond_estimate_below": float(alg_state.ns_res1[0]), "cond_bound_above": float(alg_state.ns_res1[1])}
     if rank == 0:
         ms = dt / args.steps * 1e3
         evals = total_pop * args.steps / dt
         out = {
-            "metric": "evaluations/sec, CMA-ES pop=10k dim=1k Ackley",
+            "metric": f"evaluations/sec, CMA-ES pop=10k dim=1k {args.problem.capitalize()}",
             "value": evals,
             "unit": "evaluations/s",
             "n_gpus": world,
@@ -166,7 +156,7 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
-            "data": "synthetic (Ackley objective, random initial mean; no data set)",
+            "data": f"synthetic ({args.problem.capitalize()} objective, random initial mean; no data set)",
             "config": {"model": f"CMA-ES dim={args.dim} on {args.problem}", "global_batch": total_pop,
                        "pop_per_gpu": total_pop // world, "seq_len": args.dim,
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated factorisation)",
@@ -175,6 +165,8 @@ def main():
                        "precision": ("bf16 operands in the sampling and covariance GEMMs; fp32 accumulation, state, "
                                      "fitness and factorisation" if args.precision == "bf16" else "fp32 throughout")},
             "sigma_end": sigma,
+            "best_fitness_end": best,
+            "factorisation": ns_report,
             "factorisation_residual": getattr(getattr(algo, "_ns", None), "last_residual", None),
         }
         print(json.dumps(out), flush=True)

@@ -6,8 +6,8 @@
     python benchmarks/run.py openes_mlp                # OpenES, ~1M-parameter MLP policy, pop=4096
     python benchmarks/run.py island_shade              # island-model SHADE on CEC'22 F1, pop=50k per island
 
-Multi-GPU configurations are launched with ``python -m torch.distributed.run --nproc-per-node N
-benchmarks/run.py <name>``.  Each run prints one JSON line.  Timed regions are bracketed by a
+Multi-GPU configurations: ``python benchmarks/run.py <name> --gpus N`` starts one process per GPU itself
+(``python -m torch.distributed.run --nproc-per-node N benchmarks/run.py <name> --gpus N`` works too).  Each run prints one JSON line.  Timed regions are bracketed by a
 barrier and a device synchronisation; synthetic data and random initial weights throughout."""
 from __future__ import annotations
 
@@ -17,9 +17,29 @@ import os
 import sys
 import time
 
-import torch
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+def _gpus_requested(argv) -> int:
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _gpus_requested(sys.argv[1:]) > 1:
+    # one fresh process per GPU, started before this process imports torch (evox_amd/utils/launch.py by path)
+    import importlib.util
+
+    _spec = importlib.util.spec_from_file_location("_evox_launch", os.path.join(_ROOT, "evox_amd", "utils", "launch.py"))
+    _mod = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(_mod)
+    raise SystemExit(_mod.launch_ranks(__file__, sys.argv[1:], _gpus_requested(sys.argv[1:])))
+
+import torch                                                    # noqa: E402
 
 import evox_amd as ex                                           # noqa: E402
 from evox_amd import algorithms, problems, workflows          # noqa: E402
@@ -48,8 +68,10 @@ def _timed(wf, state, steps, warmup, device):
 
 def _setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if world > 1:
-        dist.init_process_group()
+        dist.init_process_group("nccl" if args.device == "cuda" and torch.cuda.is_available() else "gloo")
     if args.device == "cuda" and torch.cuda.is_available():
         device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(device)
@@ -168,6 +190,7 @@ if __name__ == "__main__":
     ap.add_argument("--pop", type=int, default=0)
     ap.add_argument("--dim", type=int, default=0)
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks on this node (one per GPU); >1 self-launches")
     ap.add_argument("--decomp", default="newton_schulz")
     ap.add_argument("--algo", default="openes")
     ap.add_argument("--param-dtype", default="fp32", choices=["fp32", "bf16"])

@@ -162,22 +162,3 @@ EVOX_API int evox_hip_fold_in(const int32_t* keys, int32_t* out, int64_t nkeys, 
   fold_kernel<<<(int)((nkeys + 63) / 64), 64, 0, (hipStream_t)stream>>>(keys, out, nkeys, data);
   return last_launch_status();
 }
-
-namespace {
-__global__ void debug_parts_kernel(const int32_t* key, float* out, int64_t nblk) {
-  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nblk) return;
-  u32x4 b = philox_block(k0, k1, (uint64_t)t, kStreamDraw);
-  float lg = det_logf(bits_to_unit_open0(b.x));
-  float s, c;
-  det_sincos2pi(bits_to_unit(b.y), &s, &c);
-  out[4 * t] = lg; out[4 * t + 1] = det_sqrtf(-2.0f * lg); out[4 * t + 2] = s; out[4 * t + 3] = c;
-}
-}  // namespace
-
-// diagnostic twin of evox_cpu_debug_parts
-EVOX_API int evox_hip_debug_parts(const int32_t* key, float* out, int64_t nblk, void* stream) {
-  debug_parts_kernel<<<(int)((nblk + 255) / 256), 256, 0, (hipStream_t)stream>>>(key, out, nblk);
-  return last_launch_status();
-}

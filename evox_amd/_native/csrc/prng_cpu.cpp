@@ -85,15 +85,3 @@ void evox_cpu_fold_in(const int32_t* keys, int32_t* out, int64_t nkeys, int64_t 
 }
 
 }  // extern "C"
-
-// diagnostic: the four intermediate quantities of the first Box-Muller pair of every block
-extern "C" void evox_cpu_debug_parts(const int32_t* key, float* out, int64_t nblk) {
-  const uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
-  for (int64_t t = 0; t < nblk; ++t) {
-    u32x4 b = philox_block(k0, k1, (uint64_t)t, kStreamDraw);
-    float lg = det_logf(bits_to_unit_open0(b.x));
-    float s, c;
-    det_sincos2pi(bits_to_unit(b.y), &s, &c);
-    out[4 * t] = lg; out[4 * t + 1] = det_sqrtf(-2.0f * lg); out[4 * t + 2] = s; out[4 * t + 3] = c;
-  }
-}

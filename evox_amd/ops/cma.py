@@ -107,23 +107,13 @@ def small_svd_vt(X: torch.Tensor) -> torch.Tensor:
 
 
 def decompose(C, B_prev: Optional[torch.Tensor] = None, method: Optional[str] = None):
-    """``(B, D, invsqrtC)`` with ``C = B diag(D²) Bᵀ`` and ``invsqrtC = B diag(1/D) Bᵀ``.
+    """``(B, D, invsqrtC)`` with ``C = B diag(D²) Bᵀ`` and ``invsqrtC = B diag(1/D) Bᵀ`` from the vendor dense
+    symmetric solver behind ``torch.linalg.eigh`` (small problems on a GPU go through the host, see ``_host_max``).
 
-    method: "jacobi"  – warm-started block-Jacobi solver written for gfx950 (GPU default),
-            "solver"  – the vendor dense solver behind ``torch.linalg.eigh``.
-    ``B_prev`` (the previous generation's eigenvectors) warm-starts the Jacobi solver."""
-    method = method or os.environ.get("EVOX_AMD_EIGH", "auto")
-    if on_gpu(C) and method in ("auto", "jacobi"):
-        from . import eigh as _eigh
-
-        if _eigh.available():
-            B, evals = _eigh.jacobi_eigh(C, B_prev)
-        elif method == "jacobi":
-            raise RuntimeError("the Jacobi eigensolver is not built")
-        else:
-            B, evals = eigh_reference(C)
-    else:
-        B, evals = eigh_reference(C)
+    This is the exact-semantics path of the reference (``algorithms/so/es_variants/cma_es.py:143-166``); it costs
+    tens of milliseconds at n = 1000 on the GPU, which is why CMA-ES defaults to :class:`NewtonSchulzSqrt` there.
+    ``B_prev`` and ``method`` are accepted for call compatibility and ignored."""
+    B, evals = eigh_reference(C)
     D = torch.sqrt(evals.clamp_min(1e-30))
     invsqrtC = (B / D) @ B.T
     return B, D, invsqrtC

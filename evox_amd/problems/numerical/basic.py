@@ -5,6 +5,8 @@ from __future__ import annotations
 
 import math
 
+import torch
+
 from ...core.problem import Problem
 from ...ops import fitness as _f
 
@@ -67,3 +69,22 @@ class Griewank(Problem):
 class Schwefel(Problem):
     def evaluate(self, state, X):
         return _f.schwefel(X), state
+
+
+class Ellipsoid(Problem):
+    """``Σ_i cond^{i/(d-1)} x_i²`` — the axis-parallel ill-conditioned quadratic (condition number ``cond``, 10⁶ by
+    default) that covariance-adapting strategies are tuned on.  Not part of the reference's numerical suite; it is the
+    stress case for the factorisation of an ill-conditioned covariance in ``bench.py --problem ellipsoid``."""
+
+    def __init__(self, cond: float = 1e6):
+        super().__init__()
+        self.cond = float(cond)
+        self._w = None
+
+    def evaluate(self, state, X):
+        d = X.shape[-1]
+        if self._w is None or self._w.shape[0] != d or self._w.device != X.device:
+            e = torch.arange(d, dtype=torch.float64) / max(d - 1, 1)
+            self._w = torch.pow(torch.tensor(self.cond, dtype=torch.float64), e).to(torch.float32).to(X.device)
+        Xf = X.float()
+        return (Xf * Xf) @ self._w, state

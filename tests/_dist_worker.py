@@ -17,12 +17,18 @@ from evox_amd.parallel import IslandWorkflow, ShardedWorkflow
 
 def main():
     case, out_path = sys.argv[1], sys.argv[2]
-    dist.init_process_group("gloo")
+    backend = os.environ.get("EVOX_TEST_BACKEND", "gloo")
+    if backend == "nccl":
+        # RCCL: one GPU per rank
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    dist.init_process_group(backend)
     rank, world = dist.get_process_id(), dist.get_world_size()
     dim = 8
     # EVOX_TEST_DEVICE=cuda: every rank computes on the one visible GPU while the collectives stay
     # on gloo (device data is staged through host memory by evox_amd.core.distributed)
     dev = torch.device(os.environ.get("EVOX_TEST_DEVICE", "cpu"))
+    if backend == "nccl":
+        dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
     c = torch.full((dim,), 3.0, device=dev)
     lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}

@@ -61,6 +61,19 @@ def test_row_sharded_matches_single_process(case, tmp_path):
             assert res[0]["local_rows"] == 16 // world
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_newton_schulz_replicas_stay_identical(world, tmp_path):
+    """The factorisation's iteration control lives in the algorithm state and is a function of the run's history
+    only: every rank takes the same decisions, so the replicated state stays bit-identical without any resync —
+    also at the world size of a full node."""
+    env = {"EVOX_TEST_DECOMP": "newton_schulz"}
+    base = launch("cmaes", 1, tmp_path, env)[0]
+    res = launch("cmaes", world, tmp_path, env)
+    assert all(r["vec"] == res[0]["vec"] for r in res), "replicas diverged"
+    assert res[0]["row_sharded"] and res[0]["local_rows"] == 16 // world
+    assert torch.allclose(torch.tensor(res[0]["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
+
+
 def test_resync_brings_a_drifted_replica_back(tmp_path):
     """``resync_every``: rank 1's covariance and step size are nudged at generation 12; after the broadcast at
     generation 15 the replicas are bit-identical again and stay so."""
@@ -158,3 +171,17 @@ def test_one_shot_p2p_wait_is_bounded(tmp_path):
     res = launch("p2p_timeout", 2, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
     assert res[0]["timed_out"] is True
     assert res[1]["timed_out"] is False and res[1]["sum"] == [3.0] * 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cmaes", "openes"])
+def test_row_sharded_over_rccl(case, tmp_path):
+    """One rank per GPU over RCCL — the production path.  Needs at least two GPUs; the one-GPU test box skips it."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    env = {"EVOX_TEST_DEVICE": "cuda", "EVOX_TEST_DECOMP": "newton_schulz"}
+    base = launch(case, 1, tmp_path, env)[0]
+    res = launch(case, 2, tmp_path, dict(env, EVOX_TEST_BACKEND="nccl"))
+    for r in res:
+        assert r["row_sharded"] and r["world"] == 2
+        assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
