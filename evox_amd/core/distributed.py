@@ -90,7 +90,19 @@ def _p2p_group(x: torch.Tensor):
     if not p2p.enabled():
         return None
     g = p2p.default_group()
+    # a wait of an earlier collective that ran out (a late or dead peer) surfaces here, before more work is
+    # queued on NaN-filled results: P2PTimeout
+    g.poll()
     return g if x.numel() * 4 <= g.max_bytes else None
+
+
+def check_p2p() -> None:
+    """Synchronise and raise ``P2PTimeout`` if a peer-to-peer collective of this process has timed out (workflows
+    call it where they synchronise anyway: monitors' host reads, checkpoints)."""
+    from ..parallel import p2p
+
+    if p2p.enabled() and p2p._default is not None:
+        p2p._default.check()
 
 
 def _via_host(x: torch.Tensor) -> bool:

@@ -5,6 +5,13 @@ rank writes its contribution directly into every peer's receive buffer (all xGMI
 then waits — for a bounded time — for the peers' flags.  It needs a ``torch.distributed`` process
 group only to exchange the IPC handles at construction.
 
+Sums of at least ``two_shot_min_bytes`` go in two shots (reduce-scatter, then all-gather, both direct), so each
+link carries 2/W of the message instead of all of it.
+
+A wait that runs out of polls fills its output with NaNs and sets an error word that the host can read without
+synchronising (a pinned copy): every later call of the group — and ``check()`` — raises :class:`P2PTimeout`.
+After a time-out the group is out of step with its peers and must not be used again.
+
 Opt-in: ``core.distributed`` routes device tensors of at most ``max_bytes`` through a group when
 ``EVOX_AMD_P2P=1``; RCCL stays the default.  The path has been exercised with several processes
 sharing one GPU (the only multi-process GPU configuration available to its tests), not yet across
@@ -32,8 +39,11 @@ _native.register_hip_api({
     "evox_hip_p2p_export": (I, [P, P, I]),
     "evox_hip_p2p_import": (I, [P, P]),
     "evox_hip_p2p_close": (I, [P]),
-    "evox_hip_p2p_put": (I, [P, I64, P, I, I, I, I64, I64, ctypes.c_uint32, P, P]),
-    "evox_hip_p2p_collect": (I, [P, I, I, I64, I64, I64, ctypes.c_uint32, P, I, ctypes.c_longlong, P, P]),
+    "evox_hip_p2p_put": (I, [P, I64, P, I, I, I, I64, I64, ctypes.c_uint32, P, I64, P]),
+    "evox_hip_p2p_collect": (I, [P, I, I, I64, I64, I64, ctypes.c_uint32, P, I, ctypes.c_longlong, P, P, P]),
+    "evox_hip_p2p_two_shot_finish": (I, [P, P, I, I, I, I64, I64, I64, I64, I64, I64, ctypes.c_uint32, P, ctypes.c_longlong,
+                                         P, P, P, P]),
+    "evox_hip_host_device_ptr": (I, [P, P]),
 })
 
 
@@ -43,7 +53,7 @@ class P2PTimeout(RuntimeError):
 
 class P2PGroup:
     def __init__(self, max_bytes: int = 8 << 20, group=None, device: Optional[torch.device] = None,
-                 timeout_s: float = 20.0):
+                 timeout_s: float = 20.0, two_shot_min_bytes: Optional[int] = None):
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized()):
@@ -58,7 +68,12 @@ class P2PGroup:
         self.max_bytes = (int(max_bytes) + 63) // 64 * 64
         self.slot_stride = self.world * self.max_bytes
         self._header = lib.evox_hip_p2p_header_bytes()
-        total = self._header + 2 * self.slot_stride
+        # reduced chunks of the two-shot sum: one chunk per rank and slot
+        self.chunk_stride = ((self.max_bytes + self.world - 1) // self.world + 63) // 64 * 64
+        self._red_offset = self._header + 2 * self.slot_stride
+        total = self._red_offset + 2 * self.world * self.chunk_stride
+        self.two_shot_min_bytes = int(os.environ.get("EVOX_AMD_P2P_TWO_SHOT_MIN", str(256 << 10))) \
+            if two_shot_min_bytes is None else int(two_shot_min_bytes)
         with torch.cuda.device(self.device):
             own = ctypes.c_void_p()
             check(lib.evox_hip_p2p_alloc(ctypes.byref(own), total), "p2p_alloc")
@@ -81,11 +96,17 @@ class P2PGroup:
                 self._opened.append(ptr.value)
         self._peer_table = torch.tensor(self._peers, dtype=torch.int64, device=self.device)
         self._done = torch.zeros(self.world, dtype=torch.int32, device=self.device)
+        self._done2 = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # the same word in pinned host memory, written by the wait kernels: readable without a synchronisation
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        dev_ptr = ctypes.c_void_p()
+        check(lib.evox_hip_host_device_ptr(self._err_host.data_ptr(), ctypes.byref(dev_ptr)), "hipHostGetDevicePointer")
+        self._err_host_dev = dev_ptr.value
+        self._broken = False
         self._seq = 0
         # ≈ 1 µs per poll (a sleep of 32·64 cycles plus the load): the budget bounds the wait kernel
         self._max_polls = max(1000, int(timeout_s * 1e6))
-        self._checked = 0
         dist.barrier(group=group)                     # every buffer is mapped before anyone writes
 
     # ------------------------------------------------------------------------------------
@@ -102,16 +123,33 @@ class P2PGroup:
             return src.clone() if reduce else src.new_empty((0,))
         if n * 4 > self.max_bytes:
             raise ValueError(f"message of {n * 4} bytes exceeds the group's max_bytes={self.max_bytes}")
+        self._raise_if_timed_out()
         self._seq = (self._seq + 1) & 0xFFFFFFFF or 1
         slot = self._seq & 1
         out = torch.empty(n if reduce else n * self.world, dtype=src.dtype, device=self.device)
         lib, s = hip(), stream_of(src)
+        two_shot = reduce and self.world > 1 and n * 4 >= self.two_shot_min_bytes
+        # words of a chunk: a multiple of 4 (16-byte stores) that covers the message with W chunks
+        chunk = ((n + self.world - 1) // self.world + 3) // 4 * 4 if two_shot else 0
         check(lib.evox_hip_p2p_put(src.data_ptr(), n, self._peer_table.data_ptr(), self.world, self.rank, slot,
-                                   self.slot_stride, self.max_bytes, self._seq, self._done.data_ptr(), s), "p2p_put")
-        check(lib.evox_hip_p2p_collect(self._own, self.world, slot, self.slot_stride, self.max_bytes, n, self._seq,
-                                       out.data_ptr(), int(reduce), self._max_polls, self._err.data_ptr(), s),
-              "p2p_collect")
+                                   self.slot_stride, self.max_bytes, self._seq, self._done.data_ptr(), chunk, s), "p2p_put")
+        if two_shot:
+            check(lib.evox_hip_p2p_two_shot_finish(self._own, self._peer_table.data_ptr(), self.world, self.rank, slot,
+                                                   self.slot_stride, self.max_bytes, self._red_offset, self.chunk_stride,
+                                                   chunk, n, self._seq, out.data_ptr(), self._max_polls,
+                                                   self._done2.data_ptr(), self._err.data_ptr(), self._err_host_dev, s),
+                  "p2p_two_shot_finish")
+        else:
+            check(lib.evox_hip_p2p_collect(self._own, self.world, slot, self.slot_stride, self.max_bytes, n, self._seq,
+                                           out.data_ptr(), int(reduce), self._max_polls, self._err.data_ptr(),
+                                           self._err_host_dev, s), "p2p_collect")
         return out
+
+    def _raise_if_timed_out(self) -> None:
+        if self._broken or int(self._err_host[0]):
+            self._broken = True
+            raise P2PTimeout("a peer's message did not arrive in time; the outputs of that collective are NaN-filled "
+                             "and this group is out of step with its peers")
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
         """Concatenation of every rank's ``x`` along dim 0 (all ranks pass the same shape)."""
@@ -123,10 +161,14 @@ class P2PGroup:
         return self._run(x, True).reshape(x.shape)
 
     def check(self) -> None:
-        """Synchronise and raise ``P2PTimeout`` if any wait since the last check ran out of polls."""
+        """Synchronise and raise ``P2PTimeout`` if any wait of this group ran out of polls."""
         if int(self._err.item()):
-            self._err.zero_()
-            raise P2PTimeout("a peer's message did not arrive in time")
+            self._broken = True
+        self._raise_if_timed_out()
+
+    def poll(self) -> None:
+        """The same without synchronising: sees the time-outs of the collectives that have finished by now."""
+        self._raise_if_timed_out()
 
     def close(self) -> None:
         lib = hip()

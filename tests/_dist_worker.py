@@ -89,7 +89,8 @@ def main():
         g = P2PGroup(max_bytes=1 << 20, timeout_s=10.0)
         ok = True
         gen = torch.Generator().manual_seed(1234)
-        for it, n in enumerate([3, 1000, 4096, 65536, 7, 262144, 12, 1001]):
+        g.two_shot_min_bytes = 4096 * 4
+        for it, n in enumerate([3, 1000, 4096, 65536, 7, 262144, 12, 1001, 4100, 65537]):
             full = torch.randn(world, n, generator=gen)              # same on every rank
             mine = full[rank].to(dev)
             got = g.all_gather(mine)
@@ -127,7 +128,22 @@ def main():
             g.check()
         except P2PTimeout:
             timed_out = True
-        result = {"timed_out": timed_out, "sum": out.cpu().tolist() if not timed_out else None}
+        poisoned = bool(torch.isnan(out).all()) if timed_out else False
+        # the framework's own collectives on the same situation: the next routed call raises
+        from evox_amd.parallel import p2p as p2p_mod
+
+        p2p_mod._default = g
+        os.environ["EVOX_AMD_P2P"] = "1"
+        routed_raises = False
+        if rank == 0:                      # rank 1 saw no time-out; a further collective would wait for rank 0 in vain
+            try:
+                dist.all_reduce(x)
+            except P2PTimeout:
+                routed_raises = True
+        os.environ["EVOX_AMD_P2P"] = "0"
+        p2p_mod._default = None
+        result = {"timed_out": timed_out, "sum": out.cpu().tolist() if not timed_out else None, "poisoned": poisoned,
+                  "routed_raises": routed_raises}
         dist.barrier()
         g.close()
     with open(f"{out_path}.{rank}", "w") as f:

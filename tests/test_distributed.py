@@ -169,7 +169,7 @@ def test_one_shot_p2p_collectives(world, tmp_path):
 @pytest.mark.gpu
 def test_one_shot_p2p_wait_is_bounded(tmp_path):
     res = launch("p2p_timeout", 2, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
-    assert res[0]["timed_out"] is True
+    assert res[0]["timed_out"] is True and res[0]["poisoned"] is True and res[0]["routed_raises"] is True
     assert res[1]["timed_out"] is False and res[1]["sum"] == [3.0] * 8
 
 
