@@ -9,7 +9,17 @@ problem from a ``cloudpickle`` payload with the same seed, joins one ``torch.dis
 :class:`~evox_amd.parallel.workflows.ShardedWorkflow`: each evaluates its slice of the
 population and the fitness is all-gathered *between the workers* – nothing flows through the
 driver except the step command and, for the driver-side monitors, rank 0's copy of the hook
-arguments.  ``async_dispatch`` steps may be in flight before the driver waits."""
+arguments (with the full candidate set, row-aligned with the fitness — the reference passes ``None`` there,
+``distributed.py:110-113``).  ``async_dispatch`` steps may be in flight before the driver waits.
+
+``metrics`` (name → ``f(fitness)``) are evaluated on rank 0 on every generation's whole-population fitness and
+delivered with the step's result: ``latest_metrics`` / ``metric_history``.  ``global_fit_transform`` is applied on
+every worker to the gathered fitness before ``fit_transforms``.  (The reference declares both parameters and never
+reads them, ``distributed.py:262-266``.)
+
+A worker that raises or dies does not leave the job hanging: the driver waits on all pipes at once, and on the
+first error — or a worker process found dead — kills the remaining workers (exact processes it started) and
+raises ``RuntimeError`` with the worker's traceback."""
 from __future__ import annotations
 
 import multiprocessing as mp
@@ -17,6 +27,7 @@ import os
 import socket
 import warnings
 from collections import deque
+from multiprocessing.connection import wait as _wait_pipes
 from typing import Callable, Dict, List, Optional, Union
 
 import torch
@@ -72,12 +83,33 @@ def _worker_main(rank, world, port, conn, payload, options):
     else:
         device = torch.device("cpu")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ..core.module import use_state
     from .workflows import ShardedWorkflow
     spec = cloudpickle.loads(payload)
     recorder = _HookRecorder(spec["hooks"] if rank == 0 else [])
-    wf = ShardedWorkflow(spec["algorithm"], spec["problem"], monitors=[recorder] if rank == 0 else [],
+    metrics = spec.get("metrics") or {}
+    metric_values = {}
+    if rank == 0 and metrics:
+        def _metrics_hook(state, cands, tcands, fitness):
+            for name, fn in metrics.items():
+                v = fn(fitness)
+                metric_values[name] = v.detach().cpu() if isinstance(v, torch.Tensor) else v
+
+        class _MetricMonitor:
+            def hooks(self):
+                return ["post_eval"]
+
+            def set_opt_direction(self, _):
+                pass
+
+            post_eval = staticmethod(_metrics_hook)
+        extra_monitors = [_MetricMonitor()]
+    else:
+        extra_monitors = []
+    wf = ShardedWorkflow(spec["algorithm"], spec["problem"], monitors=([recorder] if rank == 0 else []) + extra_monitors,
                          opt_direction=spec["opt_direction"], candidate_transforms=spec["sol_transforms"],
-                         fitness_transforms=spec["fit_transforms"])
+                         fitness_transforms=spec["fit_transforms"], global_fitness_transforms=spec.get("global_fit_transforms", ()),
+                         monitor_candidates=spec.get("monitor_candidates", "local"))
     state = None
     try:
         while True:
@@ -88,7 +120,24 @@ def _worker_main(rank, world, port, conn, payload, options):
                 conn.send(("ok", None))
             elif cmd == "step":
                 state = wf.step(state)
-                conn.send(("ok", recorder.drain() if rank == 0 else None))
+                conn.send(("ok", (recorder.drain(), dict(metric_values)) if rank == 0 else None))
+            elif cmd == "valid":
+                # the problem switched to its validation split on a throw-away state; every worker evaluates its rows
+                # of the current candidates, the fitness is gathered between the workers
+                vstate = use_state(wf.problem.valid)(state, metric=arg)
+                pop, vstate = use_state(wf.algorithm.ask)(vstate)
+                n = pop.shape[0]
+                lo, hi = wf.slice_bounds(n, rank, world)
+                part = pop[lo:hi]
+                for t in wf.candidate_transforms:
+                    part = t(part)
+                fit, _ = use_state(wf.problem.evaluate)(vstate, part)
+                full = wf._gather_fitness(fit, n, world)
+                conn.send(("ok", full.detach().cpu() if rank == 0 else None))
+            elif cmd == "fail":                                  # test hook: a worker that raises mid-run
+                if rank == arg:
+                    raise RuntimeError("injected worker failure")
+                conn.send(("ok", None))
             elif cmd == "sample":
                 cands, _ = wf.algorithm.ask(state.get_child_state("algorithm"))
                 conn.send(("ok", cands.detach().cpu() if rank == 0 else None))
@@ -125,9 +174,15 @@ class ProcessDistributedWorkflow(Workflow):
         for m in self.monitors:
             m.set_opt_direction(self.opt_direction)
         remote_hooks = [h for h in HOOK_NAMES if self.registered_hooks[h] and h not in ("pre_step", "post_step")]
+        needs_cands = any(h in remote_hooks for h in ("post_eval", "pre_tell"))
+        self._problem_has_valid = callable(getattr(problem, "valid", None))
+        self.metrics = dict(metrics or {})
+        self.latest_metrics: Dict[str, object] = {}
+        self.metric_history: Dict[str, list] = {k: [] for k in self.metrics}
         payload = cloudpickle.dumps(dict(algorithm=algorithm, problem=problem, opt_direction=opt_direction,
                                          sol_transforms=list(sol_transforms), fit_transforms=list(fit_transforms),
-                                         hooks=remote_hooks))
+                                         global_fit_transforms=list(global_fit_transform), metrics=self.metrics,
+                                         hooks=remote_hooks, monitor_candidates="full" if needs_cands else "local"))
         self.num_workers = num_workers
         self.async_dispatch = max(1, async_dispatch)
         self._inflight = deque()
@@ -147,13 +202,44 @@ class ProcessDistributedWorkflow(Workflow):
         for c in self._conns:
             c.send((cmd, arg))
 
-    def _recv_all(self):
-        out = []
+    def _abort(self, why: str):
+        """Kill every worker this driver started and raise."""
+        for p in self._procs:
+            if p.is_alive():
+                p.kill()
+        for p in self._procs:
+            p.join(timeout=5)
         for c in self._conns:
-            status, value = c.recv()
-            if status == "err":
-                raise RuntimeError(f"distributed worker failed: {value}")
-            out.append(value)
+            try:
+                c.close()
+            except OSError:
+                pass
+        self._conns, self._procs = [], []
+        self._inflight.clear()
+        raise RuntimeError(f"distributed worker failed: {why}")
+
+    def _recv_all(self, poll_s: float = 0.5):
+        """One reply from every worker.  Waits on all pipes at once: the first error, closed pipe or dead process
+        aborts the job instead of blocking on a peer that waits in a collective for the failed one."""
+        out = [None] * len(self._conns)
+        pending = {c: i for i, c in enumerate(self._conns)}
+        while pending:
+            ready = _wait_pipes(list(pending), timeout=poll_s)
+            for c in ready:
+                i = pending[c]
+                try:
+                    status, value = c.recv()
+                except (EOFError, OSError):
+                    self._abort(f"worker {i} closed its pipe (exit code {self._procs[i].exitcode})")
+                if status == "err":
+                    self._abort(f"worker {i}: {value}")
+                out[i] = value
+                del pending[c]
+            if not ready:
+                for c, i in pending.items():
+                    p = self._procs[i]
+                    if not p.is_alive() and not c.poll():
+                        self._abort(f"worker {i} died (exit code {p.exitcode})")
         return out
 
     def _replay(self, state, calls):
@@ -163,7 +249,12 @@ class ProcessDistributedWorkflow(Workflow):
 
     def _collect_one(self, state):
         self._inflight.popleft()
-        self._replay(state, self._recv_all()[0])
+        calls, metric_values = self._recv_all()[0]
+        self._replay(state, calls)
+        if metric_values:
+            self.latest_metrics = metric_values
+            for k, v in metric_values.items():
+                self.metric_history.setdefault(k, []).append(v)
 
     def setup(self, key):
         self._send_all("init", key.cpu())
@@ -191,6 +282,15 @@ class ProcessDistributedWorkflow(Workflow):
         self._send_all("sample")
         return self._recv_all()[0], state
 
+    def valid(self, state: State, metric: str = "loss"):
+        """Fitness of the current candidates on the problem's validation split (``problem.valid(state, metric)``);
+        the workers' states are left untouched.  Reference: ``workflows/distributed.py:145-153, 381-383``."""
+        if not self._problem_has_valid:
+            raise NotImplementedError("the problem has no valid(state, metric) method")
+        self.flush(state)
+        self._send_all("valid", metric)
+        return self._recv_all()[0], state
+
     def get_full_state(self):
         self.flush()
         self._send_all("state")
@@ -205,6 +305,8 @@ class ProcessDistributedWorkflow(Workflow):
             self._recv_all()
         except (RuntimeError, EOFError, BrokenPipeError, OSError):
             pass
+        if not self._procs:
+            return
         for p in self._procs:
             p.join(timeout=10)
             if p.is_alive():

@@ -35,19 +35,65 @@ class ShardedWorkflow(StdWorkflow):
     ``("population",)``) is broadcast to the other ranks.  The replicas are computed from identical all-reduced
     statistics, but by library GEMMs whose algorithm each rank picks by its own timing, so they may differ in the
     last bits; the differences stay at rounding level (the covariance update contracts them), and the broadcast,
-    a few MB every k generations, removes them altogether."""
+    a few MB every k generations, removes them altogether.
+
+    ``monitor_candidates`` (row-sharded mode; in replicated mode every rank holds all candidates anyway):
+    ``"local"`` – the ``post_eval`` / ``pre_tell`` hooks get this rank's rows next to the full fitness
+    (:class:`~evox_amd.monitors.EvalMonitor` then tracks the best among the rows it sees); ``"full"`` – the candidate
+    rows are all-gathered each generation (pop × dim elements) and the hooks get the full set, row-aligned with the
+    fitness.  The option must be the same on every rank: the gather is a collective whether or not a rank has monitors.
+
+    State fields declared with ``pytree_field(sharding=ShardingType.SHARED_FIRST_DIM)`` in the algorithm's state
+    dataclass (or listed in ``algorithm.sharded_fields``) are row-local: ``resync`` leaves them alone and
+    ``shard_state`` cuts them to this rank's rows."""
 
     def __init__(self, algorithm, problem, monitors=(), opt_direction="min", candidate_transforms=(),
-                 fitness_transforms=(), resync_every: int = 0, **kwargs):
+                 fitness_transforms=(), resync_every: int = 0, monitor_candidates: str = "local",
+                 global_fitness_transforms=(), **kwargs):
         super().__init__(algorithm, problem, monitors, opt_direction, candidate_transforms, fitness_transforms, **kwargs)
         self.row_sharded = supports_sharding(algorithm)
         self.pmap_axis_name = dist.POP_AXIS_NAME
         self.resync_every = int(resync_every)
+        if monitor_candidates not in ("local", "full"):
+            raise ValueError("monitor_candidates must be 'local' or 'full'")
+        self.monitor_candidates = monitor_candidates
+        # applied to the gathered (whole-population) fitness on every rank, before ``fitness_transforms``
+        self.global_fitness_transforms = list(global_fitness_transforms)
+        if self.global_fitness_transforms:
+            self.fitness_transforms = self.global_fitness_transforms + self.fitness_transforms
+
+    def _local_fields(self, alg_state) -> set:
+        """Names of the row-local fields of the algorithm state: ``algorithm.sharded_fields`` plus every field whose
+        declaration carries ``sharding=ShardingType.SHARED_FIRST_DIM``."""
+        import dataclasses
+
+        local = set(getattr(self.algorithm, "sharded_fields", ("population",)))
+        fields = getattr(alg_state, "_state_dict", None)
+        if fields is not None and dataclasses.is_dataclass(fields):
+            for f in dataclasses.fields(fields):
+                if f.metadata.get("sharding") is dist.ShardingType.SHARED_FIRST_DIM:
+                    local.add(f.name)
+        return local
+
+    def shard_state(self, state):
+        """Cut every row-local field of the algorithm state that still has its full first dimension to this rank's
+        rows (a replicated state, e.g. a single-process checkpoint, becomes this rank's share)."""
+        alg = state.get_child_state("algorithm")
+        rank, world = state.rank, state.world_size
+        if world == 1:
+            return state
+        fresh = {}
+        for name in self._local_fields(alg):
+            if name in alg:
+                v = getattr(alg, name)
+                if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] % world == 0:
+                    fresh[name] = dist.ShardingType.SHARED_FIRST_DIM.shard(v, rank, world)
+        return state.replace_child("algorithm", alg.replace(**fresh)) if fresh else state
 
     def resync(self, state):
         """Rank 0's replicated algorithm state on every rank (collective: all ranks call it)."""
         alg = state.get_child_state("algorithm")
-        local = set(getattr(self.algorithm, "sharded_fields", ("population",)))
+        local = self._local_fields(alg)
         fresh = {}
         for name in alg.keys():
             v = getattr(alg, name)
@@ -79,13 +125,16 @@ class ShardedWorkflow(StdWorkflow):
         for m in hooks["pre_eval"]:
             m.pre_eval(state, cands, tcands)
         fitness, state = self._evaluate(state, tcands)          # includes the fitness all-gather
+        seen = cands
+        if self.monitor_candidates == "full" and world > 1:
+            seen = _tree.tree_map(lambda t: dist.all_gather(t, dist.POP_AXIS_NAME, axis=0, tiled=True), cands)
         for m in hooks["post_eval"]:
-            m.post_eval(state, cands, tcands, fitness)
+            m.post_eval(state, seen, tcands, fitness)
         tfitness = fitness
         for t in self.fitness_transforms:
             tfitness = t(tfitness)
         for m in hooks["pre_tell"]:
-            m.pre_tell(state, cands, tcands, fitness, tfitness)
+            m.pre_tell(state, seen, tcands, fitness, tfitness)
         state = use_state(self.algorithm.tell_sharded)(state, tfitness, rank, world)
         if aux is not None:
             aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)

@@ -8,9 +8,12 @@ fused kernels; ``graph_step=True`` records the steady-state step into a HIP grap
 it (``evox_amd.utils.graph``).
 
 Multi-GPU: one process per GPU.  After ``enable_multi_devices`` every rank runs the same
-algorithm on replicated state (identical keys ⇒ identical populations), evaluates rows
-``[rank·n/W, (rank+1)·n/W)`` and all-gathers the fitness over RCCL — the data-parallel mode
-of the reference (``src/evox/workflows/std_workflow.py:33-313``).
+algorithm on replicated state (identical keys ⇒ identical populations), evaluates its slice of the
+rows and all-gathers the fitness over RCCL — the data-parallel mode of the reference
+(``src/evox/workflows/std_workflow.py:33-313``).  The slices are remainder-aware (the first
+``n mod W`` ranks take one row more, as the reference's actor workers do, ``workflows/distributed.py:49-54``;
+its pmap mode refuses such sizes).  The ``post_eval`` / ``pre_tell`` hooks receive the full candidate
+set, row-aligned with the full fitness they come with, and this rank's transformed slice.
 """
 from __future__ import annotations
 
@@ -108,7 +111,29 @@ class StdWorkflow(Workflow):
         ask = self.algorithm.init_ask if first else self.algorithm.ask
         return use_state(ask)(state)
 
-    def _evaluate(self, state, cands):
+    @staticmethod
+    def slice_bounds(n: int, rank: int, world: int):
+        """Rows ``[lo, hi)`` of rank ``rank`` when ``n`` rows are spread over ``world`` ranks."""
+        per, rem = divmod(n, world)
+        lo = per * rank + min(rank, rem)
+        return lo, lo + per + (1 if rank < rem else 0)
+
+    def _gather_fitness(self, fitness, n_total=None, world=1):
+        if n_total is None or world == 1 or n_total % world == 0:
+            return all_gather(fitness, self.pmap_axis_name, axis=0, tiled=True)
+        # uneven slices: pad to the largest, gather, drop the padding rows
+        per = n_total // world + 1
+        pad = per - fitness.shape[0]
+        if pad:
+            fitness = torch.cat([fitness, fitness.new_zeros((pad,) + tuple(fitness.shape[1:]))], dim=0)
+        full = all_gather(fitness, self.pmap_axis_name, axis=0, tiled=True)
+        parts = []
+        for r in range(world):
+            lo, hi = self.slice_bounds(n_total, r, world)
+            parts.append(full[r * per:r * per + (hi - lo)])
+        return torch.cat(parts, dim=0)
+
+    def _evaluate(self, state, cands, n_total=None):
         if not self.external_problem:
             fitness, state = use_state(self.problem.evaluate)(state, cands)
         else:
@@ -122,7 +147,7 @@ class StdWorkflow(Workflow):
             if tuple(fitness.shape) != want:
                 raise ValueError(f"external problem returned fitness of shape {tuple(fitness.shape)}, expected {want}")
             fitness = fitness.to(dev)
-        fitness = all_gather(fitness, self.pmap_axis_name, axis=0, tiled=True)
+        fitness = self._gather_fitness(fitness, n_total, getattr(state, "world_size", 1))
         d = self.opt_direction
         if isinstance(d, torch.Tensor):
             fitness = fitness * d.to(fitness.device)
@@ -151,13 +176,11 @@ class StdWorkflow(Workflow):
             m.post_ask(state, cands)
 
         world = state.world_size
+        all_cands, n_total = cands, None
         if world > 1:
-            n = _tree.tree_leaves(cands)[0].shape[0]
-            if n % world:
-                raise ValueError(f"#Candidates ({n}) should be divisible by the number of devices ({world})")
-            s = n // world
-            lo = state.rank * s
-            cands = _tree.tree_map(lambda x: x[lo:lo + s], cands)
+            n_total = _tree.tree_leaves(cands)[0].shape[0]
+            lo, hi = self.slice_bounds(n_total, state.rank, world)
+            cands = _tree.tree_map(lambda x: x[lo:hi], cands)
 
         tcands = cands
         for t in self.candidate_transforms:
@@ -167,22 +190,22 @@ class StdWorkflow(Workflow):
             m.pre_eval(state, cands, tcands)
 
         with _prof.scope("evaluate"):
-            fitness, state = self._evaluate(state, tcands)
+            fitness, state = self._evaluate(state, tcands, n_total)
 
         for m in hooks["post_eval"]:
-            m.post_eval(state, cands, tcands, fitness)
+            m.post_eval(state, all_cands, tcands, fitness)
 
         tfitness = fitness
         for t in self.fitness_transforms:
             tfitness = t(tfitness)
 
         for m in hooks["pre_tell"]:
-            m.pre_tell(state, cands, tcands, fitness, tfitness)
+            m.pre_tell(state, all_cands, tcands, fitness, tfitness)
 
         with _prof.scope("tell"):
             state = self._tell(state, tfitness)
         if aux is not None:
-            aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
+            aux.update(cands=all_cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
 
         for m in hooks["post_tell"]:
             m.post_tell(state)

@@ -134,6 +134,86 @@ def test_process_distributed_workflow_cso():
         wf.close()
 
 
+class _SplitSphere:
+    """Sphere on the training split, shifted sphere on the validation split (the ``valid`` protocol of the
+    reference's distributed workflow, ``workflows/distributed.py:145-153``)."""
+
+    def __new__(cls):
+        from evox_amd.core.problem import Problem
+        from evox_amd.core.state import State
+
+        class SplitSphere(Problem):
+            def setup(self, key):
+                return State(shift=torch.tensor(0.0))
+
+            def valid(self, state, metric="loss"):
+                return state.replace(shift=torch.tensor(1.0 if metric == "loss" else 2.0))
+
+            def evaluate(self, state, X):
+                return ((X - state.shift) ** 2).sum(dim=1), state
+
+        return SplitSphere()
+
+
+def test_process_distributed_workflow_metrics_valid_and_uneven_slices():
+    """21 candidates over 2 workers (slices of 11 and 10), a driver-side monitor that receives the full candidate
+    set, per-generation metrics, a global fitness transform, and ``valid`` on the validation split."""
+    import evox_amd as ex
+    from evox_amd import algorithms, workflows
+    from evox_amd.monitors import EvalMonitor
+
+    seen = {}
+
+    class Probe(EvalMonitor):
+        def post_eval(self, state, cands, tcands, fitness):
+            seen["cands"], seen["fit"] = tuple(cands.shape), tuple(fitness.shape)
+            seen["aligned"] = bool(torch.allclose((cands ** 2).sum(dim=1), fitness, atol=1e-4))
+            super().post_eval(state, cands, tcands, fitness)
+
+    mon = Probe()
+    wf = workflows.RayDistributedWorkflow(
+        algorithm=algorithms.PSO(lb=torch.full((3,), -5.0), ub=torch.full((3,), 5.0), pop_size=21),
+        problem=_SplitSphere(), num_workers=2, monitors=[mon],
+        metrics={"best": lambda f: f.min(), "mean": lambda f: f.mean()},
+        global_fit_transform=[lambda f: f * 0.5], options={"num_cpus": 1})
+    try:
+        state = wf.init(ex.PRNGKey(7))
+        for _ in range(12):
+            state = wf.step(state, block=True)
+        # hooks see the fitness before any transform, row-aligned with the full candidate set
+        assert seen["cands"] == (21, 3) and seen["fit"] == (21,) and seen["aligned"]
+        assert len(wf.metric_history["best"]) == 12 and float(wf.latest_metrics["best"]) <= float(wf.metric_history["best"][0])
+        vfit, state = wf.valid(state, metric="loss")
+        cands, state = wf.sample(state)
+        assert vfit.shape == (21,)
+        assert torch.allclose(vfit, ((cands - 1.0) ** 2).sum(dim=1), atol=1e-5)
+    finally:
+        wf.close()
+
+
+def test_process_distributed_workflow_worker_failure_is_reported():
+    """A worker that raises does not leave the driver blocked on the other workers' pipes."""
+    import time
+
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    wf = workflows.RayDistributedWorkflow(
+        algorithm=algorithms.PSO(lb=torch.full((3,), -5.0), ub=torch.full((3,), 5.0), pop_size=20),
+        problem=problems.numerical.Sphere(), num_workers=2, options={"num_cpus": 1})
+    try:
+        state = wf.init(ex.PRNGKey(7))
+        state = wf.step(state, block=True)
+        t0 = time.time()
+        wf._send_all("fail", 1)
+        with pytest.raises(RuntimeError, match="injected worker failure"):
+            wf._recv_all()
+        assert time.time() - t0 < 30
+        assert wf._procs == []                      # everything it started is gone
+    finally:
+        wf.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["cmaes", "cmaes_wide", "openes"])
 def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
