@@ -10,6 +10,12 @@ The PRNG keys live inside the state, so a resumed run continues the same random 
 Writes go to a temporary sibling first and are renamed into place, so a crash never leaves a
 half-written checkpoint under the final name.  Loading executes nothing from the file
 (safetensors + JSON).  Reference behaviour: ``src/evox/core/state.py:264-301``.
+
+Several ranks (``save_state_sharded`` / ``load_state_sharded``): rank 0 writes the manifest and the replicated
+tensors once; every rank writes the row-local tensors it owns (the fields a workflow declares as sharded along
+dim 0) to ``rank00000.safetensors``, ``rank00001.safetensors``, ….  All ranks write into one temporary directory,
+meet at a barrier, and rank 0 renames it into place.  A checkpoint written by W ranks loads on W' ranks: the
+row-local tensors are concatenated in rank order and cut again for the loading job.
 """
 from __future__ import annotations
 
@@ -178,4 +184,82 @@ def load_state(path, template=None, directory: bool = True, device=None):
             out.append(r.to(device=device if device is not None else t.device, dtype=t.dtype))
         else:
             out.append(r)
+    return _tree.tree_unflatten(t_def, out)
+
+
+def _rank_file(rank: int) -> str:
+    return f"rank{rank:05d}.safetensors"
+
+
+def save_state_sharded(state, path, local_keys, rank: int, world: int, barrier=None, extra: Optional[dict] = None) -> None:
+    """Collective: every rank calls it with the same ``path`` (a directory on a file system all ranks see).
+
+    ``local_keys``: '/'-separated tree paths (as in the manifest, e.g. ``children/algorithm/fields/population``) of
+    the tensors that hold only this rank's rows; everything else is taken to be replicated and written by rank 0."""
+    from safetensors.torch import save_file
+
+    path = Path(path).resolve()
+    local_keys = set(local_keys)
+    tensors: dict = {}
+    manifest = {"format": FORMAT_VERSION, "tree": _encode(state, tensors, ""), "extra": extra or {},
+                "sharded": {"world": int(world), "local_keys": sorted(local_keys)}}
+    missing = local_keys - set(tensors)
+    if missing:
+        raise KeyError(f"row-local keys not found in the state tree: {sorted(missing)}")
+    tmp = path.with_name(path.name + ".tmp-sharded")
+    if rank == 0:
+        if tmp.exists():
+            shutil.rmtree(tmp)
+        tmp.mkdir(parents=True)
+    if barrier is not None:
+        barrier()
+    save_file({k: tensors[k].clone() for k in sorted(local_keys)} or {"__empty__": torch.zeros(1)}, str(tmp / _rank_file(rank)))
+    if rank == 0:
+        save_file({k: v.clone() for k, v in tensors.items() if k not in local_keys}, str(tmp / "tensors.safetensors"))
+        (tmp / "manifest.json").write_text(json.dumps(manifest))
+    if barrier is not None:
+        barrier()
+    if rank == 0:
+        if path.exists():
+            shutil.rmtree(path)
+        os.replace(tmp, path)
+    if barrier is not None:
+        barrier()
+
+
+def load_state_sharded(path, rank: int, world: int, template=None, device=None):
+    """This rank's view of a checkpoint written by ``save_state_sharded`` (any writer world size)."""
+    from safetensors.torch import load_file
+
+    path = Path(path).resolve()
+    manifest = json.loads((path / "manifest.json").read_text())
+    if manifest.get("format") != FORMAT_VERSION:
+        raise ValueError(f"unsupported checkpoint format {manifest.get('format')}")
+    info = manifest.get("sharded")
+    if info is None:
+        raise ValueError("not a sharded checkpoint; use load_state")
+    tensors = load_file(str(path / "tensors.safetensors"))
+    saved_world, keys = int(info["world"]), list(info["local_keys"])
+    if saved_world == world:
+        mine = load_file(str(path / _rank_file(rank)))
+        for k in keys:
+            tensors[k] = mine[k]
+    elif keys:
+        parts = [load_file(str(path / _rank_file(r))) for r in range(saved_world)]
+        for k in keys:
+            full = torch.cat([p[k] for p in parts], dim=0)
+            n = full.shape[0]
+            if n % world:
+                raise ValueError(f"{k}: {n} rows cannot be spread evenly over {world} ranks")
+            per = n // world
+            tensors[k] = full[rank * per:(rank + 1) * per].clone()
+    restored = _decode(manifest["tree"], tensors, device)
+    if template is None:
+        return restored
+    t_leaves, t_def = _tree.tree_flatten(template)
+    r_leaves, _ = _tree.tree_flatten(restored)
+    if len(t_leaves) != len(r_leaves):
+        raise ValueError(f"checkpoint has {len(r_leaves)} leaves but the template has {len(t_leaves)}")
+    out = [r.to(device=device if device is not None else t.device, dtype=t.dtype)
+           if isinstance(t, torch.Tensor) and isinstance(r, torch.Tensor) else r for t, r in zip(t_leaves, r_leaves)]
     return _tree.tree_unflatten(t_def, out)

@@ -107,6 +107,32 @@ class ShardedWorkflow(StdWorkflow):
             return None
         return state.replace(rank=dist.get_process_id(), world_size=dist.get_world_size())
 
+    # -- checkpoints -----------------------------------------------------------------------
+    def _local_keys(self, state):
+        own = state.find_path_to(self._node_id, None)
+        prefix = "/".join(f"children/{p}" for p in own[0]) if own and own[0] else ""
+        alg = state.get_child_state("algorithm")
+        base = (prefix + "/" if prefix else "") + "children/algorithm/fields/"
+        return {base + name for name in self._local_fields(alg)
+                if name in alg and isinstance(getattr(alg, name), torch.Tensor)}
+
+    def save_checkpoint(self, state, path) -> None:
+        """Collective.  The replicated state once (rank 0), each rank's row-local fields in a file of its own
+        (``core/checkpoint.py``); a single-process job writes the same layout with one rank file."""
+        from ..core.checkpoint import save_state_sharded
+
+        local = self._local_keys(state) if (self.row_sharded and state.world_size > 1) else set()
+        save_state_sharded(state, path, local, state.rank, state.world_size, dist.barrier)
+
+    def load_checkpoint(self, path, template=None, device=None):
+        """This rank's state from ``save_checkpoint`` — also when the job now has a different number of ranks (the
+        row-local fields are re-cut; rank and world size are those of the loading job)."""
+        from ..core.checkpoint import load_state_sharded
+
+        rank, world = dist.get_process_id(), dist.get_world_size()
+        state = load_state_sharded(path, rank, world, template, device)
+        return state.replace(rank=rank, world_size=world)
+
     def _step(self, state, hooks=None, aux=None):
         if not self.row_sharded or state.world_size == 1 and not self.row_sharded:
             return super()._step(state, hooks, aux)

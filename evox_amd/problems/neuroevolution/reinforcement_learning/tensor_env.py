@@ -141,6 +141,103 @@ class TensorEnvProblem(Problem):
             total = total[0]
         return total, state.replace(key=key)
 
+    # ------------------------------------------------------------------------------------
+    def rollout(self, key, weights, respect_done: bool = False):
+        """One episode of ONE individual (``weights`` without the population axis): the observations
+        ``(T+1, obs_dim)``, rewards ``(T,)`` and done flags ``(T,)`` on the host."""
+        from ....core.tree import tree_leaves, tree_map
+        device = tree_leaves(weights)[0].device
+        batched = tree_map(lambda w: w.unsqueeze(0), weights)
+        env_state, obs = self.env.reset(key.to(device), 1, device)
+        frames, rewards, dones = [obs[0].detach().cpu()], [], []
+        for _ in range(self.max_episode_length):
+            action = self.policy(batched, obs.reshape(1, 1, -1)).reshape(1, -1)
+            env_state, obs, reward, done = self.env.step(env_state, action)
+            frames.append(obs[0].detach().cpu())
+            rewards.append(float(reward[0]))
+            dones.append(bool(done[0]))
+            if respect_done and dones[-1]:
+                break
+        return torch.stack(frames), torch.tensor(rewards), torch.tensor(dones)
+
+    def visualize(self, key, weights, output_type: str = "HTML", respect_done: bool = False, width: int = 320,
+                  height: int = 240, **kwargs):
+        """Roll one individual out and render the episode (reference: ``brax.py:99-133``, which renders the physics
+        scene through ``brax.io``; a tensor environment has no scene, so what is drawn is its observation vector).
+
+        ``output_type="HTML"``: a self-contained page — an animated bar display of the observation with a slider, and the
+        cumulative reward curve.  ``"rgb_array"``: one ``(height, width, 3)`` uint8 array per time step.  An environment
+        may supply its own ``render(obs_row, width, height) -> uint8 array`` for the frames."""
+        assert output_type in ("HTML", "rgb_array"), "output_type must be either HTML or rgb_array"
+        obs, rewards, dones = self.rollout(key, weights, respect_done)
+        if output_type == "rgb_array":
+            draw = getattr(self.env, "render", None) or _bars_frame
+            return [draw(row, width, height) for row in obs]
+        import json
+        lim = float(obs.abs().max().clamp_min(1e-6))
+        payload = json.dumps({"obs": [[round(float(v), 5) for v in row] for row in obs],
+                              "ret": [round(float(v), 5) for v in torch.cumsum(rewards, 0)],
+                              "done": [int(d) for d in dones], "lim": lim})
+        return _HTML_TEMPLATE.replace("__DATA__", payload).replace("__W__", str(width)).replace("__H__", str(height))
+
+
+def _bars_frame(row, width: int, height: int):
+    """Observation vector as a bar display: one column per coordinate, zero line in the middle."""
+    import numpy as np
+
+    img = np.full((height, width, 3), 255, dtype=np.uint8)
+    v = np.asarray(row, dtype=np.float64)
+    n = max(len(v), 1)
+    lim = max(float(np.abs(v).max()), 1.0)
+    mid = height // 2
+    img[mid, :, :] = 160
+    bw = max(width // n, 1)
+    for i, x in enumerate(v[: width // bw]):
+        h = int(round((height // 2 - 2) * min(abs(x) / lim, 1.0)))
+        lo, hi = (mid - h, mid) if x >= 0 else (mid, mid + h)
+        img[lo:hi + 1, i * bw:(i + 1) * bw - (1 if bw > 2 else 0)] = (38, 110, 200) if x >= 0 else (200, 80, 50)
+    return img
+
+
+_HTML_TEMPLATE = """<!DOCTYPE html>
+<html><head><meta charset="utf-8"><title>episode</title></head>
+<body style="font-family:sans-serif">
+<canvas id="c" width="__W__" height="__H__" style="border:1px solid #999"></canvas>
+<canvas id="r" width="__W__" height="__H__" style="border:1px solid #999"></canvas><br>
+<input id="t" type="range" min="0" value="0" style="width:640px"> <span id="lab"></span>
+<script>
+const D = __DATA__;
+const c = document.getElementById('c').getContext('2d'), r = document.getElementById('r').getContext('2d');
+const W = __W__, H = __H__, T = D.obs.length, sl = document.getElementById('t');
+sl.max = T - 1;
+function draw(t) {
+  c.clearRect(0, 0, W, H); c.strokeStyle = '#999'; c.beginPath(); c.moveTo(0, H / 2); c.lineTo(W, H / 2); c.stroke();
+  const o = D.obs[t], bw = W / o.length;
+  for (let i = 0; i < o.length; i++) {
+    const h = (H / 2 - 2) * Math.min(Math.abs(o[i]) / D.lim, 1);
+    c.fillStyle = o[i] >= 0 ? '#266ec8' : '#c85032';
+    c.fillRect(i * bw, o[i] >= 0 ? H / 2 - h : H / 2, Math.max(bw - 1, 1), h);
+  }
+  r.clearRect(0, 0, W, H);
+  if (D.ret.length) {
+    const lo = Math.min(0, ...D.ret), hi = Math.max(1e-9, ...D.ret);
+    r.strokeStyle = '#2a2'; r.beginPath();
+    D.ret.forEach((v, i) => { const x = i / Math.max(D.ret.length - 1, 1) * W, y = H - (v - lo) / (hi - lo) * (H - 4) - 2;
+      i ? r.lineTo(x, y) : r.moveTo(x, y); });
+    r.stroke();
+    const x = Math.max(t - 1, 0) / Math.max(D.ret.length - 1, 1) * W;
+    r.strokeStyle = '#000'; r.beginPath(); r.moveTo(x, 0); r.lineTo(x, H); r.stroke();
+  }
+  document.getElementById('lab').textContent = 'step ' + t + '/' + (T - 1) + (t > 0 ? '  return ' + D.ret[t - 1] : '') +
+    (t > 0 && D.done[t - 1] ? '  (done)' : '');
+}
+sl.oninput = () => draw(+sl.value);
+let t = 0; draw(0);
+const timer = setInterval(() => { t = (t + 1) % T; sl.value = t; draw(t); }, 50);
+sl.onmousedown = () => clearInterval(timer);
+</script></body></html>
+"""
+
 
 class Brax(TensorEnvProblem):
     """Name-based constructor with the reference's signature (``brax.py:16-24``).  ``env_name``

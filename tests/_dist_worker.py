@@ -55,6 +55,36 @@ def main():
                   "row_sharded": wf.row_sharded, "best": float(mon.get_best_fitness()),
                   "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_resync", "cmaes_wide") else None,
                   "cov": alg.C.reshape(-1).tolist() if case == "cmaes_resync" else None}
+    elif case == "sharded_ckpt":
+        path = os.environ["EVOX_TEST_CKPT"]
+
+        def make():
+            return ShardedWorkflow(A.CMAES(c, 1.0, pop_size=16, decomposition="newton_schulz"), problems.numerical.Rosenbrock())
+
+        wf = make()
+        state = wf.init(ex.PRNGKey(3))
+        for _ in range(6):
+            state = wf.step(state)
+        wf.save_checkpoint(state, path)
+        for _ in range(6):
+            state = wf.step(state)
+        wf2 = make()
+        resumed = wf2.load_checkpoint(path, template=wf2.init(ex.PRNGKey(77)))
+        rows = int(resumed.get_child_state("algorithm").population.shape[0])
+        for _ in range(6):
+            resumed = wf2.step(resumed)
+        a, b = state.get_child_state("algorithm"), resumed.get_child_state("algorithm")
+        result = {"same": bool(torch.equal(a.mean, b.mean) and torch.equal(a.C, b.C) and torch.equal(a.sigma, b.sigma)),
+                  "rows": rows, "files": sorted(os.listdir(path)), "vec": a.mean.tolist()}
+    elif case == "sharded_ckpt_load":
+        # a job of another size picks the checkpoint up
+        path = os.environ["EVOX_TEST_CKPT"]
+        wf = ShardedWorkflow(A.CMAES(c, 1.0, pop_size=16, decomposition="newton_schulz"), problems.numerical.Rosenbrock())
+        state = wf.load_checkpoint(path, template=wf.init(ex.PRNGKey(5)))
+        rows = int(state.get_child_state("algorithm").population.shape[0])
+        for _ in range(6):
+            state = wf.step(state)
+        result = {"rows": rows, "vec": state.get_child_state("algorithm").mean.tolist(), "world": state.world_size}
     elif case == "std_multi_device":
         wf = workflows.StdWorkflow(A.PSO(lb, ub, 16), problems.numerical.Sphere())
         state = wf.enable_multi_devices(wf.init(ex.PRNGKey(5)))

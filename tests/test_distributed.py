@@ -74,6 +74,19 @@ def test_newton_schulz_replicas_stay_identical(world, tmp_path):
     assert torch.allclose(torch.tensor(res[0]["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
 
 
+def test_sharded_checkpoint_resume_and_reshard(tmp_path):
+    """Two ranks write one checkpoint (replicated part once, row-local part per rank); resuming it reproduces the
+    uninterrupted run bit for bit, and a four-rank job and a single process can pick the same checkpoint up."""
+    env = {"EVOX_TEST_CKPT": str(tmp_path / "ckpt")}
+    res = launch("sharded_ckpt", 2, tmp_path, env)
+    assert all(r["same"] for r in res) and res[0]["rows"] == 8
+    assert res[0]["files"] == ["manifest.json", "rank00000.safetensors", "rank00001.safetensors", "tensors.safetensors"]
+    for world in (4, 1):
+        again = launch("sharded_ckpt_load", world, tmp_path, env)
+        assert again[0]["rows"] == 16 // world and again[0]["world"] == world
+        assert torch.allclose(torch.tensor(again[0]["vec"]), torch.tensor(res[0]["vec"]), atol=2e-3, rtol=2e-3)
+
+
 def test_resync_brings_a_drifted_replica_back(tmp_path):
     """``resync_every``: rank 1's covariance and step size are nudged at generation 12; after the broadcast at
     generation 15 the replicas are bit-identical again and stay so."""

@@ -66,6 +66,23 @@ def test_tensor_env_problem_is_reproducible_and_masks_done():
     assert f1.shape == (8,)
 
 
+def test_brax_visualize_html_and_frames():
+    """``Brax.visualize`` of the reference (``brax.py:99-133``): one individual, HTML or per-step frames."""
+    net = MLP([27, 16, 8])
+    problem = neuro.Brax(policy=net.batched_apply, env_name="synthetic-ant", max_episode_length=12, num_episodes=1)
+    w = net.init(ex.PRNGKey(1))
+    page = problem.visualize(ex.PRNGKey(3), w)
+    assert page.startswith("<!DOCTYPE html>") and '"obs"' in page and "__DATA__" not in page
+    frames = problem.visualize(ex.PRNGKey(3), w, output_type="rgb_array", width=108, height=64)
+    assert len(frames) == 13 and frames[0].shape == (64, 108, 3) and frames[0].dtype == np.uint8
+    assert any((f != frames[0]).any() for f in frames[1:])
+    obs, rew, done = problem.rollout(ex.PRNGKey(3), w)
+    obs2, rew2, _ = problem.rollout(ex.PRNGKey(3), w)
+    assert torch.equal(obs, obs2) and torch.equal(rew, rew2) and obs.shape == (13, 27)
+    with pytest.raises(AssertionError):
+        problem.visualize(ex.PRNGKey(3), w, output_type="gif")
+
+
 def _cartpole_policy(weights, obs):
     # weights (P, 4), obs (P, 4) -> discrete action
     return ((weights * obs).sum(-1) > 0).to(torch.int64)
