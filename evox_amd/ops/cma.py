@@ -183,6 +183,7 @@ class NewtonSchulzSqrt:
     REC = 7
     SYM_COND_MAX = 30.0      # the symmetric-half products are used while the cond bound of two calls ago is below
     COND_EVERY = 4           # calls between refreshes of the condition estimates
+    COND_TRUST = 3.0         # the estimate from below times this factor may stand in for a looser bound from above
 
     def init_control(self, n: int, device) -> dict:
         g = torch.Generator().manual_seed(0x5EED)
@@ -308,8 +309,14 @@ class NewtonSchulzSqrt:
         if capturing:
             symmetric = bool(self._graph_symmetric)
         else:
-            symmetric = bool(self.planes and have_ws and gpu and lagged is not None
-                             and 0.0 < lagged[1] <= self.SYM_COND_MAX and not use_safe)
+            # The bound from above (an ∞-norm) overshoots by up to √n when the eigenvectors are far from the axes;
+            # the estimate from below (a power vector carried from call to call) is tight after a few refreshes.
+            # Three times the estimate is trusted when it is the smaller one — a wrong decision shows up as a
+            # residual over tolerance and sends the next calls through the safe scaling and the library products.
+            cond = 0.0
+            if lagged is not None and lagged[1] > 0.0:
+                cond = lagged[1] if not lagged[0] > 0.0 else min(lagged[1], self.COND_TRUST * lagged[0])
+            symmetric = bool(self.planes and have_ws and gpu and 0.0 < cond <= self.SYM_COND_MAX and not use_safe)
             self._graph_symmetric = symmetric
         self.symmetric_calls += int(symmetric)
         used = max(1, iters)
