@@ -171,6 +171,13 @@ class SaDE(DEBase):
             CR_memory=torch.full((self.LP, 4), float("nan"), device=dev), CRs=torch.zeros(self.batch_size, device=dev),
             strategy_ids=torch.zeros(self.batch_size, dtype=torch.int64, device=dev), iter=0)
 
+    def graph_host_counters(self):
+        return tuple(super().graph_host_counters()) + ("iter",)
+
+    def graph_variant(self, state):
+        # the learning-period branches of ask(): before, at and after the end of the first period
+        return (state.iter >= self.LP, state.iter > self.LP)
+
     def ask(self, state):
         key, k_var, k_strat, k_cr, k_cr2, k_f = rnd.split(state.key, 6)
         dev = self.lb.device

@@ -605,6 +605,13 @@ class Noise_reuse_es(_ESBase):
         return State(key=key, pert_key=key, center=self.center_init, inner_step_counter=0,
                      sigma=torch.tensor(float(self.sigma), device=dev), pert_sigma=torch.tensor(float(self.sigma), device=dev))
 
+    def graph_host_counters(self):
+        # advances by K and returns to 0 once it reaches T: a wrapping counter when K divides T
+        return (("inner_step_counter", self.T),) if self.T % self.K == 0 else ()
+
+    def graph_variant(self, state):
+        return state.inner_step_counter == 0          # ask() draws a fresh perturbation at the start of a period
+
     def ask(self, state):
         key, noise_key = rnd.split(state.key)
         if state.inner_step_counter == 0:
@@ -651,6 +658,12 @@ class PersistentES(_ESBase):
         pos = _es.noise_rows(noise_key, self.popsize // 2, self.dim) * self.sigma
         perts = torch.cat([pos, -pos], dim=0)
         return state.center + perts, state.replace(key=key, pert_accum=state.pert_accum + perts)
+
+    def graph_host_counters(self):
+        return (("inner_step_counter", self.T),) if self.T % self.K == 0 else ()
+
+    def graph_variant(self, state):
+        return state.inner_step_counter + self.K >= self.T     # tell() clears the accumulated perturbations
 
     def tell(self, state, fitness):
         grad = (fitness @ state.pert_accum) / (self.sigma ** 2) / self.popsize

@@ -152,6 +152,14 @@ class DMSPSOEL(_SwarmBase):
                      gbest_position=torch.zeros(self.dim, device=dev),
                      gbest_fitness=torch.tensor(float("inf"), device=dev), key=sk)
 
+    def graph_host_counters(self):
+        return ("iteration",)
+
+    def graph_variant(self, state):
+        # the branches of tell(): which phase, and whether this iteration regroups the swarms
+        multi = state.iteration < 0.9 * self.max_iteration
+        return (multi, multi and state.iteration % self.regrouped_iteration_num == 0)
+
     def tell(self, state, fitness):
         if state.iteration < 0.9 * self.max_iteration:
             return self._multi_swarm_phase(state, fitness)
@@ -198,8 +206,8 @@ class DMSPSOEL(_SwarmBase):
         better = fitness < state.pbest_fitness
         pbest = torch.where(better[:, None], state.population, state.pbest_position)
         pbest_fit = torch.minimum(state.pbest_fitness, fitness)
-        g = torch.argmin(pbest_fit)
-        gbest, gfit = pbest[g], pbest_fit[g]
+        g = torch.argmin(pbest_fit).reshape(1)              # gathered on the device: no index read-back
+        gbest, gfit = pbest.index_select(0, g)[0], pbest_fit.index_select(0, g)[0]
         shape = (self.pop_size, self.dim)
         vel = self.w * state.velocity + self.c_pbest * rnd.uniform(k_p, shape) * (pbest - state.population) \
             + self.c_gbest * rnd.uniform(k_g, shape) * (gbest - state.population)

@@ -60,6 +60,7 @@ class StdWorkflow(Workflow):
         num_objectives: Optional[int] = None,
         migrate_helper=None,
         graph_step: bool = False,
+        graph_mode: str = "ring",
     ):
         """
         algorithm, problem      the two halves of the loop.
@@ -76,6 +77,9 @@ class StdWorkflow(Workflow):
         migrate_helper          object with ``migrate_from_human() -> (do, pop, fit)``; when
                                 ``do`` is true ``algorithm.migrate(state, pop, fit)`` is called.
         graph_step              replay the steady-state step from a HIP graph (GPU only).
+        graph_mode              "ring": pointer-stable replay, the state tensors handed out are the recordings' own
+                                buffers (valid for one further step; clone what must live longer); "copy": value
+                                semantics, every replay copies the state in and clones it out (``utils.graph``).
         """
         super().__init__()
         self.algorithm = algorithm
@@ -97,6 +101,8 @@ class StdWorkflow(Workflow):
         self.num_objectives = num_objectives
         self.migrate_helper = migrate_helper
         self.graph_step = graph_step
+        self.graph_mode = graph_mode
+        self.graph_replays = 0
         if external_problem and num_objectives is None:
             raise ValueError("Using external problem, but num_objectives isn't set")
         self.pmap_axis_name = None
@@ -235,7 +241,14 @@ class StdWorkflow(Workflow):
         # Steady-state generations replay a recording of the bare step; the monitors observe
         # it from outside: pre_* hooks see the incoming state, post_* hooks the outgoing one,
         # with the candidates / fitness the recording produced.
+        # An algorithm whose step branches on host counters (a phase switch, a periodic regrouping) names the
+        # branch taken from the incoming state: one recording per variant.
+        variant_of = getattr(self.algorithm, "graph_variant", None)
+        variant = variant_of(state.get_child_state("algorithm")) if variant_of is not None else None
         if self._graphed is None:
+            self._graphed = {}
+        graphed = self._graphed.get(variant)
+        if graphed is None:
             from ..utils.graph import GraphedStep
 
             if self.migrate_helper is not None or self.external_problem:
@@ -245,14 +258,18 @@ class StdWorkflow(Workflow):
             for c in (extra() if extra else ()):         # names, or (name, modulus) for counters that wrap around
                 counters.append(f"children/algorithm/fields/{c}" if isinstance(c, str)
                                 else (f"children/algorithm/fields/{c[0]}", c[1]))
-            self._graphed = GraphedStep(self._bare_step, host_counters=counters)
+            graphed = self._graphed[variant] = GraphedStep(self._bare_step, host_counters=counters, mode=self.graph_mode)
         hooks = self.registered_hooks
         for m in hooks["pre_step"]:
             m.pre_step(state)
         for m in hooks["pre_ask"]:
             m.pre_ask(state)
-        new_state, aux = self._graphed(state)
-        if self._graphed.replays % 64 == 0:
+        new_state, aux = graphed(state)
+        self.graph_replays += 1
+        if any(hooks[h] for h in ("post_ask", "pre_eval", "post_eval", "pre_tell")):
+            # the recording's own buffers are overwritten a few replays later: monitors get copies they may keep
+            aux = {k: _tree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, v) for k, v in aux.items()}
+        if self.graph_replays % 64 == 0:
             check = getattr(self.algorithm, "graph_check", None)
             if check is not None and check():
                 self._graphed = None            # record again with the algorithm's updated settings

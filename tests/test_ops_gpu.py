@@ -185,8 +185,9 @@ def test_mo_algorithm_runs_on_gpu(cuda):
     assert fit.is_cuda and float(metrics.IGD(prob.pf().to(cuda))(fit)) < 0.15
 
 
-@pytest.mark.parametrize("algo_name", ["PSO", "OpenES"])
-def test_graph_step_replays_match_eager(cuda, algo_name):
+@pytest.mark.parametrize("mode", ["ring", "copy"])
+@pytest.mark.parametrize("algo_name", ["PSO", "OpenES", "DMSPSOEL", "SaDE", "Noise_reuse_es", "PersistentES"])
+def test_graph_step_replays_match_eager(cuda, algo_name, mode):
     """Every replay of the recorded step must equal the eager step: replays are interleaved with
     eager work and synchronisations, and each one is checked."""
     import evox_amd as ex
@@ -194,17 +195,28 @@ def test_graph_step_replays_match_eager(cuda, algo_name):
     from evox_amd.monitors import EvalMonitor
 
     def build(graph):
+        lb, ub = -torch.ones(64, device=cuda) * 5, torch.ones(64, device=cuda) * 5
+        c = torch.ones(64, device=cuda)
         if algo_name == "PSO":
-            algo = algorithms.PSO(lb=-torch.ones(64, device=cuda) * 5, ub=torch.ones(64, device=cuda) * 5, pop_size=512)
+            algo = algorithms.PSO(lb=lb, ub=ub, pop_size=512)
+        elif algo_name == "DMSPSOEL":       # regroups every 3 iterations, switches phase at iteration 9 of 10
+            algo = algorithms.DMSPSOEL(lb, ub, 8, 4, 16, 3, 10, 0.7, 1.5, 1.5, 1.0, 1.0)
+        elif algo_name == "SaDE":           # learning period of 3 generations
+            algo = algorithms.SaDE(lb, ub, 64, LP=3)
+        elif algo_name == "Noise_reuse_es":
+            algo = algorithms.Noise_reuse_es(64, c, lr=0.1, sigma=0.1, T=30, K=10)
+        elif algo_name == "PersistentES":
+            algo = algorithms.PersistentES(64, c, lr=0.1, sigma=0.1, T=30, K=10)
         else:
             algo = algorithms.OpenES(torch.ones(300, device=cuda), pop_size=256, learning_rate=0.05, noise_stdev=0.1)
         mon = EvalMonitor()
-        return workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), monitors=[mon], graph_step=graph), mon
+        return workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), monitors=[mon], graph_step=graph,
+                                     graph_mode=mode), mon
 
     eager, mon_e = build(False)
     graphed, mon_g = build(True)
     se, sg = eager.init(ex.PRNGKey(9)), graphed.init(ex.PRNGKey(9))
-    for step in range(8):
+    for step in range(14):
         se, sg = eager.step(se), graphed.step(sg)
         torch.cuda.synchronize()
         scratch = torch.randn(256, 256, device=cuda) @ torch.randn(256, 256, device=cuda)   # eager work in between
@@ -212,7 +224,7 @@ def test_graph_step_replays_match_eager(cuda, algo_name):
         assert sg.generation == se.generation == step + 1
         fe, fg = mon_e.get_latest_fitness(), mon_g.get_latest_fitness()
         assert torch.equal(fe, fg), (algo_name, step, (fe - fg).abs().max())
-    assert graphed._graphed is not None and graphed._graphed.replays >= 6
+    assert graphed._graphed and graphed.graph_replays >= 6
     from evox_amd.core.tree import tree_leaves
     for a, b in zip(tree_leaves(se), tree_leaves(sg)):
         if isinstance(a, torch.Tensor):
@@ -357,7 +369,7 @@ def test_cmaes_graph_step_matches_eager(cuda):
 
     _, se, means_e = run(False)
     wfg, sg, means_g = run(True)
-    assert wfg._graphed is not None and wfg._graphed.replays >= 8
+    assert wfg._graphed and wfg.graph_replays >= 8
     # The library GEMMs of the factorisation differ in the last bit between the two runs (measured: 2.4e-7 in
     # C^{1/2} from the second generation on, on the recording's side stream as well as at replay), and ten
     # generations amplify that to 1e-6 .. a few 1e-5 depending on which GEMM algorithms the plan timing picked

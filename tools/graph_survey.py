@@ -2,8 +2,8 @@
 
     python tools/graph_survey.py [--dim 100] [--pop 1024] [--steps 100] [--warmup 20]
 
-For every algorithm: eager ms/step, graphed ms/step, and whether the graphed run reproduces the
-eager one exactly.  A step that synchronises with the host or keeps a changing Python value in
+For every algorithm: eager ms/step, graphed ms/step (pointer-stable ring replay, and the copy-in / clone-out
+mode for comparison), and whether the graphed run reproduces the eager one exactly.  A step that synchronises with the host or keeps a changing Python value in
 its state is reported with the reason the recording was refused."""
 import argparse
 import json
@@ -47,9 +47,9 @@ def make(name, dim, pop, dev):
     return table[name]()
 
 
-def run(name, args, dev, graph):
+def run(name, args, dev, graph, mode="ring"):
     algo = make(name, args.dim, args.pop, dev)
-    wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), graph_step=graph)
+    wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), graph_step=graph, graph_mode=mode)
     state = wf.init(ex.PRNGKey(5).to(dev))
     for _ in range(args.warmup):
         state = wf.step(state)
@@ -96,6 +96,7 @@ if __name__ == "__main__":
             same = all(torch.equal(a, b) for a, b in zip(tree_leaves(se), tree_leaves(sg)) if isinstance(a, torch.Tensor))
             row["identical"] = bool(same)
             row["speedup"] = row["eager_ms"] / row["graph_ms"]
+            row["graph_copy_mode_ms"], _ = run(name, args, dev, True, "copy")
         except Exception as e:                                   # noqa: BLE001
             row["graph_error"] = f"{type(e).__name__}: {e}"[:200]
             torch.cuda.synchronize()
