@@ -1,5 +1,6 @@
 // Small helpers shared by every gfx950 kernel file in this directory.
 #pragma once
+#ifndef EVOX_CPU_SHIM   // tools/cpu_shim/hip_common.h stands in for this file when a kernel is run on the CPU under sanitizers
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -49,3 +50,4 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 
 }  // namespace evox
+#endif  // EVOX_CPU_SHIM

@@ -47,6 +47,12 @@ class ODE(DE):
     def setup(self, key):
         return super().setup(key).replace(counter=0)
 
+    def graph_host_counters(self):
+        return tuple(super().graph_host_counters()) + ("counter",)
+
+    def graph_variant(self, state):
+        return state.counter % 2            # ordinary and opposition generations alternate
+
     def ask(self, state):
         if state.counter % 2 == 0:
             return super().ask(state)

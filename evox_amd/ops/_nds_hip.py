@@ -16,6 +16,8 @@ _native.register_hip_api({
     "evox_hip_nds_small": (I, [P, _native.I64, I, I, I, P, P, P]),
     "evox_hip_nds_peel_all": (I, [P, _native.I64, I, I, P, P, I, I, I, P, P, P]),
     "evox_hip_crowding": (I, [P, P, P, I, I, P, P]),
+    "evox_hip_nds_sweep_build": (I, [P, I, I, P, P, P, P]),
+    "evox_hip_nds_sweep_rounds": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
 })
 
 MAX_OBJECTIVES = 8
@@ -31,6 +33,100 @@ def supported(x: torch.Tensor) -> bool:
     return x.is_cuda and x.dim() == 2 and 2 <= x.shape[1] <= MAX_OBJECTIVES and x.shape[0] > 0
 
 
+_SWEEP_MIN_N = 49152             # from here on three objectives take the O(N log² N)-per-front path (measured crossover)
+_SWEEP_ROUNDS_PER_CHECK = 8
+
+
+def _sweep_min_n() -> int:
+    import os
+
+    return int(os.environ.get("EVOX_AMD_NDS_SWEEP_MIN", str(_SWEEP_MIN_N)))
+
+
+def _sweep_m2() -> bool:
+    import os
+
+    return os.environ.get("EVOX_AMD_NDS_SWEEP_M2", "0") == "1"
+
+
+def _finish(rk64, host_sizes, target, cur, order, with_info):
+    """Common tail of the peeling drivers: the front at which the target was reached closes the ranking, everything
+    later collapses into one index."""
+    cut = next((k for k, c in enumerate(host_sizes) if c >= target), cur - 1)
+    while cut > 0 and host_sizes[cut] == host_sizes[cut - 1]:
+        cut -= 1                                            # trailing empty rounds
+    last = cut + 1
+    rk64 = torch.where((rk64 < 0) | (rk64 > cut), torch.full_like(rk64, last), rk64)
+    out = torch.empty_like(rk64)
+    out[order] = rk64
+    if with_info:
+        n_before = int(host_sizes[cut - 1]) if cut > 0 else 0
+        return out, (cut, n_before, int(host_sizes[cut]) - n_before)
+    return out
+
+
+def rank_sweep(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
+    """``rank`` for two or three objectives without the O(N²) pair tests (``csrc/nds_sweep.hip``): lexicographic
+    sort, one representative per group of identical points, a static merge-sort structure over the second objective,
+    and per front one segmented prefix-minimum pass plus a logarithmic look-up per point.  Returns None when a row
+    holds a NaN (the caller then takes the pair-test path, whose NaN behaviour is the documented one)."""
+    n, m = x.shape
+    dev = x.device
+    xf = x.float()
+    if m == 2:
+        xf = torch.cat([xf, torch.zeros(n, 1, device=dev)], dim=1)
+    order = torch.argsort(xf[:, 2], stable=True)
+    order = order[torch.argsort(xf[order, 1], stable=True)]
+    order = order[torch.argsort(xf[order, 0], stable=True)]
+    xs = xf[order]
+    is_rep = torch.ones(n, dtype=torch.bool, device=dev)
+    is_rep[1:] = (xs[1:] != xs[:-1]).any(dim=1)
+    idx = torch.arange(n, device=dev)
+    rep_idx = torch.cummax(torch.where(is_rep, idx, torch.zeros_like(idx)), dim=0).values
+    has_nan = torch.isnan(xs).any().to(torch.int32).reshape(1)
+    npad = max(2048, 1 << (n - 1).bit_length())
+    levels = npad.bit_length() - 1
+    f23 = torch.full((2, npad), float("inf"), dtype=torch.float32, device=dev)
+    # NaN keys would break the total order the merge passes rely on (slots of a level left unwritten); rows with a NaN
+    # make this function give up below, but the structure is still built and must stay well-formed
+    f23[:, :n] = torch.nan_to_num(xs[:, 1:], nan=float("inf"), posinf=float("inf"), neginf=float("-inf")).T
+    alive = torch.zeros(npad, dtype=torch.int32, device=dev)
+    alive[:n] = is_rep
+    gsize = torch.zeros(npad, dtype=torch.int32, device=dev)
+    gsize.index_add_(0, rep_idx, torch.ones(n, dtype=torch.int32, device=dev))
+    ordl = torch.empty((levels + 1, npad), dtype=torch.int32, device=dev)
+    keyl = torch.empty((levels + 1, npad), dtype=torch.float32, device=dev)
+    pos = torch.empty((levels, npad), dtype=torch.int32, device=dev)
+    lib, s = hip(), stream_of(f23)
+    check(lib.evox_hip_nds_sweep_build(f23[0].data_ptr(), npad, levels, ordl.data_ptr(), keyl.data_ptr(), pos.data_ptr(), s),
+          "nds_sweep_build")
+    chunks = npad // 2048
+    pm = torch.empty((levels, npad), dtype=torch.float32, device=dev)
+    agg = torch.empty(levels * chunks, dtype=torch.float32, device=dev)
+    cpm = torch.empty(levels * chunks, dtype=torch.float32, device=dev)
+    rk = torch.full((npad,), -1, dtype=torch.int32, device=dev)
+    state = torch.zeros(2 + n + _SWEEP_ROUNDS_PER_CHECK, dtype=torch.int32, device=dev)
+    target = n if until is None else max(1, min(int(until), n))
+    cur = 0
+    prev_ranked = -1
+    while True:
+        batch = min(_SWEEP_ROUNDS_PER_CHECK, n + _SWEEP_ROUNDS_PER_CHECK - cur)
+        check(lib.evox_hip_nds_sweep_rounds(ordl.data_ptr(), pos.data_ptr(), f23[1].data_ptr(), alive.data_ptr(),
+                                            gsize.data_ptr(), npad, levels, pm.data_ptr(), agg.data_ptr(), cpm.data_ptr(),
+                                            rk.data_ptr(), state.data_ptr(), cur, batch, target, s), "nds_sweep_rounds")
+        cur += batch
+        host = torch.cat([state[:2 + cur], has_nan]).cpu()         # one small read-back per batch of rounds
+        if int(host[-1]):
+            return None
+        ranked = int(host[0])
+        if ranked >= target or ranked >= n or ranked == prev_ranked or cur >= n:
+            break
+        prev_ranked = ranked
+    host_sizes = host[2:2 + cur].cumsum(0).tolist()
+    rk64 = rk[:n][rep_idx].to(torch.int64)
+    return _finish(rk64, host_sizes, target, cur, order, with_info)
+
+
 def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     """Front index of every row (int64).  With ``until`` peeling stops after the front that brings
     the number of ranked points to at least ``until``; all later points share the next index.
@@ -39,6 +135,12 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     peeling loop has read anyway)."""
     n, m = x.shape
     dev = x.device
+    # two objectives have many more fronts (hundreds at this size), and a front costs the sweep a full pass: they stay
+    # with the pair tests unless asked for explicitly (EVOX_AMD_NDS_SWEEP_MIN with EVOX_AMD_NDS_SWEEP_M2=1)
+    if (m == 3 or (m == 2 and _sweep_m2())) and n >= _sweep_min_n():
+        got = rank_sweep(x, until, with_info)
+        if got is not None:
+            return got
     if n <= _SMALL_MAX_N:
         xs = x.float()
         if xs.stride(1) != 1:

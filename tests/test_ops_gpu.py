@@ -186,7 +186,7 @@ def test_mo_algorithm_runs_on_gpu(cuda):
 
 
 @pytest.mark.parametrize("mode", ["ring", "copy"])
-@pytest.mark.parametrize("algo_name", ["PSO", "OpenES", "DMSPSOEL", "SaDE", "Noise_reuse_es", "PersistentES"])
+@pytest.mark.parametrize("algo_name", ["PSO", "OpenES", "DMSPSOEL", "SaDE", "Noise_reuse_es", "PersistentES", "ODE"])
 def test_graph_step_replays_match_eager(cuda, algo_name, mode):
     """Every replay of the recorded step must equal the eager step: replays are interleaved with
     eager work and synchronisations, and each one is checked."""
@@ -201,6 +201,8 @@ def test_graph_step_replays_match_eager(cuda, algo_name, mode):
             algo = algorithms.PSO(lb=lb, ub=ub, pop_size=512)
         elif algo_name == "DMSPSOEL":       # regroups every 3 iterations, switches phase at iteration 9 of 10
             algo = algorithms.DMSPSOEL(lb, ub, 8, 4, 16, 3, 10, 0.7, 1.5, 1.5, 1.0, 1.0)
+        elif algo_name == "ODE":
+            algo = algorithms.ODE(lb, ub, 64, batch_size=16)
         elif algo_name == "SaDE":           # learning period of 3 generations
             algo = algorithms.SaDE(lb, ub, 64, LP=3)
         elif algo_name == "Noise_reuse_es":
@@ -246,6 +248,47 @@ def test_nd_sort_kernel_matches_reference(cuda, n, m):
         want_u = nds.non_dominated_rank_reference(x, until=until)
         got_u = nds.non_dominated_rank(x.to(cuda), until=until)
         assert torch.equal(got_u.cpu(), want_u), until
+
+
+@pytest.mark.parametrize("n,m,kind", [(2048, 3, "random"), (5000, 3, "ties"), (3000, 2, "ties"), (40000, 3, "random"),
+                                      (40000, 2, "random"), (30000, 3, "front"), (9000, 3, "chain")])
+def test_nd_sort_sweep_matches_pair_tests(cuda, n, m, kind, monkeypatch):
+    """The O(N log² N)-per-front path for two and three objectives gives the ranks of the pair-test kernels (and of the
+    dominance-matrix oracle where that is affordable), duplicates, ties in every objective and ``until`` included."""
+    from evox_amd.ops import _nds_hip, nds
+    g = torch.Generator().manual_seed(n + m)
+    x = torch.rand(n, m, generator=g)
+    if kind == "ties":
+        x = (x * 12).round() / 12                                   # few distinct values: ties and duplicates everywhere
+        x[: n // 10] = x[n // 2: n // 2 + n // 10]
+    elif kind == "front":
+        x = x / x.norm(dim=1, keepdim=True) * (1 + 0.02 * torch.rand(n, 1, generator=g))   # near one front: few dominations
+    elif kind == "chain":
+        x = torch.sort(x, dim=0).values                              # a total order: as many fronts as points ...
+        x[1::2] = x[::2][: x[1::2].shape[0]]                         # ... halved by duplicates
+        n = 600
+        x = x[:n]
+    xd = x.to(cuda)
+    monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_M2", "1")
+    monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", str(1 << 30))
+    want = _nds_hip.rank(xd)
+    monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", "1")
+    got = _nds_hip.rank(xd)
+    assert torch.equal(got, want), int((got != want).sum())
+    if n <= 5000:
+        assert torch.equal(got.cpu(), nds.non_dominated_rank_reference(x))
+    for until in (1, n // 3, n // 2):
+        monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", str(1 << 30))
+        want_u, info_w = _nds_hip.rank(xd, until=until, with_info=True)
+        monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", "1")
+        got_u, info_g = _nds_hip.rank(xd, until=until, with_info=True)
+        assert torch.equal(got_u, want_u) and info_g == info_w, (until, info_g, info_w)
+    xn = xd.clone()
+    xn[7, 1] = float("nan")                                          # NaN rows: the pair-test path answers
+    monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", str(1 << 30))
+    want_n = _nds_hip.rank(xn)
+    monkeypatch.setenv("EVOX_AMD_NDS_SWEEP_MIN", "1")
+    assert torch.equal(_nds_hip.rank(xn), want_n)
 
 
 @pytest.mark.parametrize("n", [900, 3500])
