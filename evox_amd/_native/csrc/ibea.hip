@@ -142,6 +142,61 @@ __global__ __launch_bounds__(NT) void ibea_remove_reg_kernel(const float* __rest
   }
 }
 
+// SRA's two indicators for point j (thread), streamed over all points i like the fitness above:
+//   I1_j = 1 − Σ_i exp(−I(i, j) / 0.05)                                   (ε-indicator fitness, unscaled)
+//   I2_j = min_i ‖f_j − max(f_i, f_j)‖ = min_i sqrt(Σ_k max(f_i[k] − f_j[k], 0)²)     (shift-based density)
+// with i < j only (LOWER, the reference's form: an individual is compared with those in front of it in the merged
+// array, the first one gets +inf) or over all i ≠ j.
+template <int M, bool LOWER>
+__global__ __launch_bounds__(256) void sra_indicators_kernel(const float* __restrict__ obj, int n, float* __restrict__ I1,
+                                                             float* __restrict__ I2) {
+  __shared__ float tile[M][256];
+  __shared__ float part1[4][64], part2[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + r;
+  float mine[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) mine[k] = j < n ? obj[(int64_t)j * M + k] : 0.f;
+  float acc = 0.f, best = INFINITY;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? obj[(int64_t)ii * M + k] : 0.f;
+    __syncthreads();
+    const int lim = min(64, n - i0 - s * 64);
+    for (int q = 0; q < lim; ++q) {
+      const int c = s * 64 + q;
+      const int i = i0 + c;
+      float eps = -INFINITY, d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const float d = tile[k][c] - mine[k];
+        eps = fmaxf(eps, d);
+        const float p = fmaxf(d, 0.f);
+        d2 = fmaf(p, p, d2);
+      }
+      acc += __expf(eps * -20.0f);
+      if (LOWER ? i < j : i != j) best = fminf(best, d2);
+    }
+  }
+  part1[s][r] = acc;
+  part2[s][r] = best;
+  __syncthreads();
+  if (s == 0 && j < n) {
+    I1[j] = 1.0f - (acc + part1[1][r] + part1[2][r] + part1[3][r]);
+    I2[j] = sqrtf(fminf(fminf(best, part2[1][r]), fminf(part2[2][r], part2[3][r])));
+  }
+}
+
+template <int M>
+int launch_sra(const float* obj, int n, int lower, float* I1, float* I2, hipStream_t st) {
+  const int blocks = (n + 63) / 64;
+  if (lower) sra_indicators_kernel<M, true><<<blocks, 256, 0, st>>>(obj, n, I1, I2);
+  else sra_indicators_kernel<M, false><<<blocks, 256, 0, st>>>(obj, n, I1, I2);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_fitness(const float* obj, int n, float kappa, float* C, float* fit, hipStream_t st) {
   const int blocks = (n + 63) / 64;
@@ -192,6 +247,12 @@ int launch_remove(const float* obj, int n, const float* C, float kappa, const fl
 EVOX_API int evox_hip_ibea_fitness(const float* obj, int n, int m, float kappa, float* C, float* fit, void* stream) {
   if (n <= 0) return 0;
   EVOX_IBEA_DISPATCH(launch_fitness, obj, n, kappa, C, fit, (hipStream_t)stream)
+}
+
+// obj: (n, m) row-major fp32.  I1, I2: out (n).  lower != 0: I2 over the points in front of j only.
+EVOX_API int evox_hip_sra_indicators(const float* obj, int n, int m, int lower, float* I1, float* I2, void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_sra, obj, n, lower, I1, I2, (hipStream_t)stream)
 }
 
 // Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix

@@ -253,6 +253,87 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
   for (int i = lane; i < n; i += L) rank[i] = rk[i];
 }
 
+// The same sort pipelined over POSITIONS instead of sweeps, for long permutations.  Thread t keeps B consecutive
+// entries (element index and both keys) in registers and owns the comparators between them and the one to its right
+// neighbour's first entry.  A sweep enters a thread as the element `a` that its left neighbour carried out, walks the
+// B comparators in registers, and leaves as the carried element for the right neighbour.  Sweep s may run in thread t
+// once thread t-1 has finished sweep s and thread t+1 sweep s-1 (whose first entry it reads): thread t runs sweep s at
+// macro step t + 2s.  A macro step is B compare-swaps in registers, six LDS words exchanged and one barrier, so the
+// whole sort takes T + 2·sweeps barriers instead of sweeps·n/T·... one per single compare-swap.  The array is padded
+// to T·B entries with sentinels (both keys -inf) that no element can pass, which keeps every thread's range full.
+// Exactly the sequential result (a sweep without swaps changes nothing, so running all ⌈n/2⌉ sweeps is the same as
+// stopping early).
+template <int B>
+__global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const float* __restrict__ I1,
+                                                                          const float* __restrict__ I2,
+                                                                          const float* __restrict__ u, float pc, int n,
+                                                                          int64_t* __restrict__ rank) {
+  constexpr int T = 1024;
+  __shared__ int c_i[T], f_i[T];
+  __shared__ float c_1[T], c_2[T], f_1[T], f_2[T];
+  // Logical thread t works at macro steps of the parity of t: threads of equal parity share wavefronts (even waves
+  // hold the even t, odd waves the odd t), so that a wavefront is either fully at work or skips the step.
+  const int t = 2 * ((threadIdx.x >> 7) * 64 + (threadIdx.x & 63)) + ((threadIdx.x >> 6) & 1);
+  const int threads = (n + B - 1) / B;                   // threads that hold real entries
+  int xi[B];
+  float x1[B], x2[B];
+  unsigned use_first = 0;                                // bit q: comparator between entries q and q+1 ranks by I1
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    const int p = t * B + q;
+    xi[q] = p < n ? p : -1;
+    x1[q] = p < n ? I1[p] : -INFINITY;
+    x2[q] = p < n ? I2[p] : -INFINITY;
+    if (p < n - 1 && u[p] < pc) use_first |= 1u << q;
+  }
+  f_i[t] = xi[0]; f_1[t] = x1[0]; f_2[t] = x2[0];
+  __syncthreads();
+  const int sweeps = (n + 1) / 2;
+  const int steps = threads + 2 * sweeps;
+  const bool has_work = t < threads;
+  for (int step = 0; step < steps; ++step) {
+    const int d = step - t;
+    if (has_work && d >= 0 && !(d & 1) && (d >> 1) < sweeps) {
+      int ai; float a1, a2;
+      if (t == 0) { ai = xi[0]; a1 = x1[0]; a2 = x2[0]; }
+      else { ai = c_i[t - 1]; a1 = c_1[t - 1]; a2 = c_2[t - 1]; }
+      // the right neighbour's first entry closes this thread's range (a sentinel behind the last thread)
+      const bool last = t == threads - 1;
+      const int ni = last ? -1 : f_i[t + 1];
+      const float n1 = last ? -INFINITY : f_1[t + 1], n2 = last ? -INFINITY : f_2[t + 1];
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const int bi = q + 1 < B ? xi[q + 1] : ni;
+        const float b1 = q + 1 < B ? x1[q + 1] : n1, b2 = q + 1 < B ? x2[q + 1] : n2;
+        const bool first = (use_first >> q) & 1u;
+        if ((first ? a1 : a2) < (first ? b1 : b2)) {
+          xi[q] = bi; x1[q] = b1; x2[q] = b2;             // b moves left, a keeps bubbling right
+        } else {
+          xi[q] = ai; x1[q] = a1; x2[q] = a2;
+          ai = bi; a1 = b1; a2 = b2;
+        }
+      }
+      c_i[t] = ai; c_1[t] = a1; c_2[t] = a2;
+      f_i[t] = xi[0]; f_1[t] = x1[0]; f_2[t] = x2[0];
+    }
+    __syncthreads();
+  }
+  // Entry q of thread t is position t·B + q, except that every sweep left its carried element one slot to the right
+  // of the thread's range: position (t+1)·B holds what thread t carried out last — that is thread t+1's entry 0 as far
+  // as its own later sweeps saw it, and they all ran (thread t+1 finishes after thread t), so the registers are final.
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    const int p = t * B + q;
+    if (p < n) rank[p] = xi[q];
+  }
+}
+
+template <int B>
+int launch_ranking_blocked(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, hipStream_t st) {
+  stochastic_ranking_blocked_kernel<B><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank);
+  return last_launch_status();
+}
+
 // sequential form for permutations that do not fit the LDS (n > 40 000)
 __global__ __launch_bounds__(64) void stochastic_ranking_serial_kernel(const float* __restrict__ I1,
                                                                        const float* __restrict__ I2,
@@ -420,6 +501,12 @@ int launch_ranking(const float* I1, const float* I2, const float* u, float pc, i
 EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
                                          int64_t* rank, int* scratch, void* stream) {
   if (n <= 0) return 0;
+  if (n > 4096 && n <= 1024 * 24) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 1024 * 8) return launch_ranking_blocked<8>(I1, I2, u, pc, n, rank, st);
+    if (n <= 1024 * 16) return launch_ranking_blocked<16>(I1, I2, u, pc, n, rank, st);
+    return launch_ranking_blocked<24>(I1, I2, u, pc, n, rank, st);
+  }
   const size_t perm = (size_t)n * sizeof(int);
   if (perm <= 160 * 1024) {
     const size_t with_keys = perm * 4;

@@ -134,11 +134,20 @@ def _hv_kernel_enabled() -> bool:
     return os.environ.get("EVOX_AMD_HV", "hip") == "hip"
 
 
-def cal_hv(points, ref, k, n_sample, key):
+def cal_hv(points, ref, k, n_sample, key, tight: bool = False):
     """HypE's Monte-Carlo estimate of each point's hypervolume contribution when ``k`` points
-    are to be removed: a sample dominated by j points credits each of them α_j."""
+    are to be removed: a sample dominated by j points credits each of them α_j.
+
+    ``tight``: sample the box between the points' minimum and ``min(ref, 1.1 · their maximum)`` instead of the box up
+    to ``ref``.  The reference point is fixed at 1.2 × the largest objective of the initial population
+    (``hype.py:107-110``); once the population has converged most of that box lies far behind the front, where a sample
+    is dominated by (almost) every point and tells them nothing apart — with the default 10 000 samples and a few
+    thousand points that leaves a few hundred informative samples.  The slab between 1.1 · max and ``ref`` adds the same
+    credit to every point whose other coordinates it covers, so dropping it changes the ranking only at the extremes."""
     n, m = points.shape
     dev = points.device
+    if tight:
+        ref = torch.minimum(ref, points.amax(0) * 1.1 + 1e-12)
     i = torch.arange(1, n, device=dev, dtype=torch.float32)
     # α_j = Π_{i<j} (k−i)/(n−i) / j vanishes for j > k; clamping the factors keeps a parallel scan from
     # multiplying that zero with an overflowed tail (the factors beyond k grow up to n−1−k)
@@ -167,9 +176,16 @@ def cal_hv(points, ref, k, n_sample, key):
 
 
 class HypE(MOAlgorithm):
-    def __init__(self, lb, ub, n_objs, pop_size, n_sample=10000, mutation_op=None, crossover_op=None):
+    """Environmental selection: whole fronts, then the cut front by estimated hypervolume contribution (the reference
+    applies the estimate to the last front of the merged population instead, ``hype.py:130-140``, which never decides a
+    cut).  ``tight_sampling`` (default) confines the Monte-Carlo samples to the region where they separate points, see
+    :func:`cal_hv`; ``False`` samples the reference's fixed box."""
+
+    def __init__(self, lb, ub, n_objs, pop_size, n_sample=10000, mutation_op=None, crossover_op=None,
+                 tight_sampling: bool = True):
         self._init_mo(lb, ub, n_objs, pop_size, mutation_op, crossover_op)
         self.n_sample = n_sample
+        self.tight_sampling = bool(tight_sampling)
         self.selection = selection.Tournament(n_round=self.pop_size, multi_objective=True)
 
     def setup(self, key):
@@ -181,7 +197,7 @@ class HypE(MOAlgorithm):
 
     def ask(self, state):
         key, k_hv, k_sel, k_x, k_mut = rnd.split(state.key, 5)
-        hv = cal_hv(state.fitness, state.ref_point, self.pop_size, self.n_sample, k_hv)
+        hv = cal_hv(state.fitness, state.ref_point, self.pop_size, self.n_sample, k_hv, self.tight_sampling)
         parents, _ = self.selection(k_sel, state.population, -hv)
         nxt = self._vary(k_x, k_mut, parents)
         return nxt, state.replace(next_generation=nxt, key=key)
@@ -194,7 +210,9 @@ class HypE(MOAlgorithm):
         order = torch.argsort(rank, stable=True)
         cut_rank = rank[order[self.pop_size - 1]]
         mask = rank == cut_rank
-        hv = cal_hv(obj, state.ref_point, n, self.n_sample, k_hv)
+        # k = the number of points that will be removed, as in the HypE paper (the reference passes k = n, ``hype.py:136``,
+        # which weights a sample dominated by j points with 1/j whatever j is)
+        hv = cal_hv(obj, state.ref_point, n - self.pop_size, self.n_sample, k_hv, self.tight_sampling)
         tie = torch.where(mask, -hv, torch.zeros_like(hv))
         idx = torch.argsort(tie, stable=True)
         idx = idx[torch.argsort(rank[idx], stable=True)][: self.pop_size]

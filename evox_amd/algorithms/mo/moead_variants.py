@@ -23,16 +23,26 @@ class EAGMOEAD(MOAlgorithm):
     offspring recently entered the archive (success history over the last ``LGs`` generations)
     are given more offspring.  The neighbourhood replacement of the working population is the
     scatter-min form described in ``moead.py`` (an offspring replaces every neighbour it is at
-    least as good as; the best offspring wins a contested sub-problem)."""
+    least as good as; the best offspring wins a contested sub-problem).
 
-    def __init__(self, lb, ub, n_objs, pop_size, LGs=8, selection_op=None, mutation_op=None, crossover_op=None):
+    ``aggregation``: the scalarising function of the working population.  The reference hard-codes ``"weighted_sum"``
+    (``eagmoead.py:79``; the algorithm was proposed for combinatorial problems), under which the working population of a
+    problem with a concave front collapses onto the corners of the front and the archive is fed from there only.  The
+    default here is ``"tchebycheff"`` against the running ideal point, which reaches the interior of such fronts;
+    ``aggregation="weighted_sum"`` reproduces the reference."""
+
+    def __init__(self, lb, ub, n_objs, pop_size, LGs=8, selection_op=None, mutation_op=None, crossover_op=None,
+                 aggregation: str = "tchebycheff"):
         self._init_mo(lb, ub, n_objs, pop_size, mutation_op,
                       crossover_op if crossover_op is not None else crossover.SimulatedBinary(type=2),
                       selection_op if selection_op is not None else selection.RouletteWheelSelection(int(pop_size)))
         self.LGs = LGs
         self.T = math.ceil(self.pop_size / 10)
         self.sample = LatinHypercubeSampling(self.pop_size, self.n_objs)
-        self.aggregate_func = AggregationFunction("weighted_sum")
+        if aggregation not in ("weighted_sum", "tchebycheff"):
+            raise ValueError("aggregation must be 'weighted_sum' or 'tchebycheff'")
+        self.aggregation = aggregation
+        self.aggregate_func = AggregationFunction(aggregation)
 
     def setup(self, key):
         f = self._base_fields(key)
@@ -43,10 +53,10 @@ class EAGMOEAD(MOAlgorithm):
         n, dev = self.pop_size, self.device
         return State(inner_pop=f["population"], inner_obj=f["fitness"], weight_vector=w, B=B,
                      s=torch.zeros((n, self.LGs), device=dev), offspring_loc=torch.zeros(n, dtype=torch.int64, device=dev),
-                     gen=0, **f)
+                     ideal=torch.full((self.n_objs,), float("inf"), device=dev), gen=0, **f)
 
     def init_tell(self, state, fitness):
-        return state.replace(fitness=fitness, inner_obj=fitness)
+        return state.replace(fitness=fitness, inner_obj=fitness, ideal=fitness.amin(0))
 
     def ask(self, state):
         key, k_perm, k_sel, k_x, k_mut = rnd.split(state.key, 5)
@@ -66,8 +76,13 @@ class EAGMOEAD(MOAlgorithm):
         n = self.pop_size
         w, B, loc = state.weight_vector, state.B, state.offspring_loc
         nb = B[loc]                                                                 # (n, T) targets of offspring i
-        g_old = self.aggregate_func(state.inner_obj, w)
-        g_new = (fitness[:, None, :] * w[nb]).sum(-1)
+        ideal = torch.minimum(state.ideal, fitness.amin(0))
+        if self.aggregation == "weighted_sum":
+            g_old = self.aggregate_func(state.inner_obj, w)
+            g_new = (fitness[:, None, :] * w[nb]).sum(-1)
+        else:
+            g_old = self.aggregate_func(state.inner_obj, w, ideal)
+            g_new = ((fitness[:, None, :] - ideal).abs() * w[nb]).amax(-1)
         bar = torch.nextafter(g_old, torch.full_like(g_old, float("inf")))          # ">=" replaces
         _, winner = _scatter_best(g_new, nb, n, bar)
         take = winner >= 0
@@ -78,12 +93,13 @@ class EAGMOEAD(MOAlgorithm):
         keep = rank_crowding_truncate(pop, obj, n)
         entered = keep >= n
         hist = torch.zeros(n, device=obj.device).scatter_add(0, loc[(keep - n).clamp_min(0)], entered.to(torch.float32))
-        s = state.s
-        if bool(entered.any()):
-            s = s.clone()
-            s[:, gen % self.LGs] = hist
+        # the success history changes only in generations in which an offspring entered the archive (no read-back:
+        # the column is rewritten with its old content otherwise)
+        col = gen % self.LGs
+        s = state.s.clone()
+        s[:, col] = torch.where(entered.any(), hist, state.s[:, col])
         return state.replace(population=pop[keep], fitness=obj[keep], inner_pop=inner_pop, inner_obj=inner_obj, s=s,
-                             gen=gen)
+                             ideal=ideal, gen=gen)
 
 
 class M2MCrossover:

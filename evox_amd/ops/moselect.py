@@ -27,6 +27,7 @@ _native.register_hip_api({
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
     "evox_hip_ibea_remove_obj_max": (I64, [I]),
+    "evox_hip_sra_indicators": (I, [P, I, I, I, P, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
 })
 
@@ -223,3 +224,31 @@ def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
     else:
         _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
     return rank
+
+
+def sra_indicators(obj: torch.Tensor, lower_only: bool = False):
+    """SRA's indicators from the objective vectors, without the n × n matrices (``csrc/ibea.hip``):
+    ``I1_j = 1 − Σ_i exp(−max_k(f_i − f_j)_k / 0.05)`` and the shift-based density
+    ``I2_j = min_i ‖f_j − max(f_i, f_j)‖`` over ``i ≠ j`` — or over ``i < j`` only (``lower_only``), which is what the
+    reference computes (``algorithms/mo/sra.py:94-107``)."""
+    n, m = obj.shape
+    if on_gpu(obj) and 2 <= m <= 8 and obj.dtype == torch.float32:
+        o = obj.contiguous()
+        I1 = torch.empty(n, dtype=torch.float32, device=obj.device)
+        I2 = torch.empty(n, dtype=torch.float32, device=obj.device)
+        check(hip().evox_hip_sra_indicators(o.data_ptr(), n, m, int(bool(lower_only)), I1.data_ptr(), I2.data_ptr(),
+                                            stream_of(o)), "sra_indicators")
+        return I1, I2
+    I1 = torch.zeros(n, dtype=obj.dtype, device=obj.device)
+    I2 = torch.full((n,), float("inf"), dtype=obj.dtype, device=obj.device)
+    step = max(1, (1 << 22) // max(n * m, 1))
+    idx = torch.arange(n, device=obj.device)
+    for s0 in range(0, n, step):
+        a = obj[s0:s0 + step, None, :]                                   # points j of this block
+        d = obj[None, :, :] - a                                          # f_i − f_j
+        I1[s0:s0 + step] = 1.0 - torch.exp(-d.amax(-1) / 0.05).sum(1)
+        sde = torch.linalg.vector_norm(d.clamp_min(0), dim=-1)
+        jj = idx[s0:s0 + step, None]
+        allowed = (idx[None, :] < jj) if lower_only else (idx[None, :] != jj)
+        I2[s0:s0 + step] = torch.where(allowed, sde, torch.full_like(sde, float("inf"))).amin(1)
+    return I1, I2

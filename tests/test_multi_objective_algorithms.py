@@ -16,8 +16,8 @@ N, M, POP = 12, 3, 100
 CASES = [
     ("NSGA2", {}, 100, 0.12), ("NSGA3", {}, 100, 0.10), ("GDE3", {}, 100, 0.13), ("RVEA", {"max_gen": 100}, 100, 0.10),
     ("RVEAa", {"max_gen": 100}, 100, 0.10), ("MOEAD", {}, 100, 0.10), ("MOEADDRA", {}, 100, 0.15),
-    ("MOEADM2M", {"max_gen": 100}, 100, 0.20), ("EAGMOEAD", {}, 100, 0.40), ("IBEA", {}, 100, 0.14),
-    ("BCEIBEA", {}, 201, 0.10), ("SPEA2", {}, 100, 0.10), ("HypE", {}, 100, 0.55), ("KnEA", {}, 100, 0.10),
+    ("MOEADM2M", {"max_gen": 100}, 100, 0.20), ("EAGMOEAD", {}, 100, 0.15), ("IBEA", {}, 100, 0.14),
+    ("BCEIBEA", {}, 201, 0.10), ("SPEA2", {}, 100, 0.10), ("HypE", {}, 100, 0.20), ("KnEA", {}, 100, 0.10),
     ("BiGE", {}, 100, 0.13), ("TDEA", {}, 100, 0.10), ("SRA", {}, 100, 0.15), ("LMOCSO", {"max_gen": 100}, 100, 0.12),
     ("IMMOEA", {}, 100, 0.14),
 ]

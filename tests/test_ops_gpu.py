@@ -732,7 +732,7 @@ def test_mlp_kernel_mirrored_pairs_match_row_by_row_evaluation(cuda, sizes, E, d
         assert err_pair <= 3.0 * err_rows + 1e-2, (err_pair, err_rows)
 
 
-@pytest.mark.parametrize("n", [2, 3, 64, 129, 700, 5000])
+@pytest.mark.parametrize("n", [2, 3, 64, 129, 700, 4096, 4097, 5000, 8192, 8193, 12001, 16385, 20000, 24576])
 def test_pipelined_stochastic_ranking_equals_sequential_sort(cuda, n):
     """The wave-pipelined bubble sort (64 sweeps in flight) against the sequential host twin, with
     ties and for sizes around the pipeline depth; n = 5000 keeps the keys out of the LDS copy."""
@@ -746,6 +746,20 @@ def test_pipelined_stochastic_ranking_equals_sequential_sort(cuda, n):
     ref = moselect.stochastic_ranking(I1, I2, u, 0.45)                   # native host implementation
     assert torch.equal(got.cpu(), ref)
     assert sorted(got.tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("n,m", [(50, 2), (777, 3), (3000, 5)])
+@pytest.mark.parametrize("lower", [True, False])
+def test_sra_indicators_kernel_matches_matrix_form(cuda, n, m, lower):
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n)
+    obj = torch.rand(n, m, generator=g)
+    obj[5] = obj[9]                                                      # a duplicate: shifted distance 0
+    want1, want2 = moselect.sra_indicators(obj.double(), lower_only=lower)   # host path, fp64
+    got1, got2 = moselect.sra_indicators(obj.to(cuda), lower_only=lower)
+    assert torch.allclose(got1.cpu().double(), want1, rtol=1e-4, atol=1e-3 * n / 100)
+    assert torch.allclose(got2.cpu().double(), want2, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("pop,dim,phi", [(1024, 100, 0.0), (101, 7, 0.1), (4, 3, 0.2)])
