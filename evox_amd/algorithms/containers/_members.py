@@ -32,3 +32,32 @@ def member_ask(member, state, first):
 def member_tell(member, state, fitness, first):
     fn = member.init_tell if (first and has_init_tell(member)) else member.tell
     return use_state(fn)(state, fitness)
+
+
+def widen(base, times: int):
+    """One instance of ``base`` over ``times`` concatenated copies of its decision vector, or None when the algorithm
+    does not declare itself separable.
+
+    An algorithm whose update treats every decision variable independently given the fitness (it sets
+    ``dimension_separable = True``: PSO, CSO) run on ``times`` blocks that are all told the same fitness IS that
+    algorithm on the concatenated vector — same distribution, the random numbers are merely drawn from one stream
+    instead of ``times``.  The copy has its bound vectors (and vector-valued ``mean`` / ``stdev``) tiled."""
+    import dataclasses
+
+    import torch
+
+    if not getattr(type(base), "dimension_separable", False):
+        return None
+
+    def tile(v):
+        return v.repeat(times) if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == base.dim else v
+
+    new = {name: tile(getattr(base, name)) for name in ("lb", "ub", "mean", "stdev") if hasattr(base, name)}
+    if dataclasses.is_dataclass(base):
+        wide = dataclasses.replace(base, **{k: v for k, v in new.items() if k in {f.name for f in dataclasses.fields(base) if f.init}})
+    else:
+        wide = copy.copy(base)
+        for k, v in new.items():
+            setattr(wide, k, v)
+        wide.dim = base.dim * times
+    return wide

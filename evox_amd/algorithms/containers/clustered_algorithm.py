@@ -2,10 +2,17 @@
 base algorithm per block, all blocks being told the same fitness.
 Reference: ``src/evox/algorithms/containers/clustered_algorithm.py:11-160``.
 
-The reference vmaps one algorithm over stacked states.  Here every block owns a member
-algorithm (own key, own state) driven in sequence – each member's ask/tell is already a
-population-wide kernel sequence, so blocks cost launches, not efficiency; members may also
-differ in hyper-parameters (pass a list)."""
+The reference vmaps one algorithm over stacked states, i.e. runs one fused program for all blocks.  Three forms here:
+
+* **fused** – a base algorithm that is separable over decision variables (``dimension_separable``: PSO, CSO) is run
+  as ONE instance over the concatenated vector: the same kernels as a single block, num_cluster times wider, no
+  per-block launches at all (``_members.widen``);
+* **member loop** – any other base algorithm (CMA-ES, …), or a list of differently configured members: every block
+  owns a member with its own key and state, driven in sequence; each ask/tell is a population-wide kernel sequence,
+  and the whole generation is one HIP-graph replay under ``StdWorkflow(graph_step=True)``;
+* **distributed** (``distribute=True``, one process per GPU) – the blocks are dealt out over the ranks: rank r evolves
+  blocks ``[r·C/W, (r+1)·C/W)``, the sub-populations are all-gathered along the variable axis into the full
+  candidates, every rank evaluates its row slice as usual and all are told the same fitness."""
 from __future__ import annotations
 
 import torch
@@ -13,24 +20,63 @@ import torch
 from ...core import random as rnd
 from ...core.algorithm import Algorithm
 from ...core.state import State
-from ._members import as_stack, member_ask, member_tell
+from ...core import distributed as dist
+from ...core.module import Stateful
+from ._members import as_stack, member_ask, member_tell, widen
 
 
 class ClusterdAlgorithm(Algorithm):
-    def __init__(self, base_algorithm, dim: int, num_cluster: int):
+    def __init__(self, base_algorithm, dim: int, num_cluster: int, fuse="auto", distribute: bool = False):
+        """``fuse``: "auto" (fuse when the base algorithm allows it), True (require it) or False (member loop).
+        ``distribute``: deal the blocks out over the ranks of the job (``num_cluster`` divisible by the world size)."""
         super().__init__()
         assert dim % num_cluster == 0
         self.dim, self.num_cluster = dim, num_cluster
         self.subproblem_dim = dim // num_cluster
-        self.members = as_stack(base_algorithm, num_cluster)
-        assert len(self.members) == num_cluster
+        self.distribute = bool(distribute)
+        local = num_cluster
+        if self.distribute:
+            world = dist.get_world_size()
+            if num_cluster % world:
+                raise ValueError(f"num_cluster={num_cluster} is not divisible by the number of ranks {world}")
+            local = num_cluster // world
+        self.local_clusters = local
+        wide = None
+        if fuse in ("auto", True) and isinstance(base_algorithm, Stateful) and not isinstance(base_algorithm, (list, tuple)):
+            wide = widen(base_algorithm, local)
+        if fuse is True and wide is None:
+            raise TypeError(f"{type(base_algorithm).__name__} is not separable over decision variables: it cannot be fused")
+        self.fused = wide is not None
+        if self.fused:
+            self.members = as_stack([wide])
+        elif self.distribute:
+            full = as_stack(base_algorithm, num_cluster)
+            rank = dist.get_process_id()
+            self.members = as_stack([full[i] for i in range(rank * local, (rank + 1) * local)])
+        else:
+            self.members = as_stack(base_algorithm, num_cluster)
+            assert len(self.members) == num_cluster
+
+    def setup(self, key):
+        return State()
+
+    def init(self, key=None, no_state: bool = False):
+        # ranks must not evolve identical blocks: every rank derives its own key
+        if self.distribute and key is not None and dist.get_world_size() > 1:
+            key = rnd.fold_in(key, dist.get_process_id())
+        return super().init(key, no_state)
 
     def _ask(self, state, first):
         pops = []
         for m in self.members:
             pop, state = member_ask(m, state, first)
             pops.append(pop)
-        return torch.cat(pops, dim=1), state
+        pop = pops[0] if len(pops) == 1 else torch.cat(pops, dim=1)
+        if self.distribute and dist.get_world_size() > 1:
+            # (P, C_local·d) per rank -> (P, C·d): ranks hold consecutive blocks
+            w = dist.get_world_size()
+            pop = dist.all_gather(pop.T.contiguous(), axis=0, tiled=True).T.contiguous() if w > 1 else pop
+        return pop, state
 
     def _tell(self, state, fitness, first):
         for m in self.members:

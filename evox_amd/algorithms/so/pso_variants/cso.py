@@ -24,6 +24,8 @@ class CSOState:
 
 @dataclass
 class CSO(Algorithm):
+    dimension_separable = True          # per-variable update given the fitness: containers may fuse blocks
+
     lb: torch.Tensor
     ub: torch.Tensor
     pop_size: int = pytree_field(static=True)

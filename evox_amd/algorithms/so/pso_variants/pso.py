@@ -14,6 +14,9 @@ from ....ops import swarm as _swarm
 
 
 class PSO(Algorithm):
+    # every decision variable is updated on its own given the fitness: containers may fuse blocks (containers/_members.py)
+    dimension_separable = True
+
     def __init__(self, lb, ub, pop_size, inertia_weight=0.6, cognitive_coefficient=2.5, social_coefficient=0.8,
                  mean=None, stdev=None):
         super().__init__()

@@ -85,6 +85,18 @@ def main():
         for _ in range(6):
             state = wf.step(state)
         result = {"rows": rows, "vec": state.get_child_state("algorithm").mean.tolist(), "world": state.world_size}
+    elif case == "clustered_dist":
+        # blocks dealt out over the ranks: each rank evolves its share, candidates are gathered along the variable axis
+        base = A.CMAES(torch.full((5,), 3.0, device=dev), init_stdev=2.0, pop_size=16)
+        algo = A.ClusterdAlgorithm(base, dim=20, num_cluster=4, distribute=True)
+        mon = monitors.EvalMonitor()
+        wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), monitors=[mon])
+        state = wf.enable_multi_devices(wf.init(ex.PRNGKey(5)))
+        cands, _ = wf.algorithm.init_ask(state.get_child_state("algorithm"))
+        for _ in range(60):
+            state = wf.step(state)
+        result = {"members": len(algo.members), "cand_shape": list(cands.shape), "best": float(mon.get_best_fitness()),
+                  "cands": cands.reshape(-1)[:40].tolist()}
     elif case == "std_multi_device":
         wf = workflows.StdWorkflow(A.PSO(lb, ub, 16), problems.numerical.Sphere())
         state = wf.enable_multi_devices(wf.init(ex.PRNGKey(5)))

@@ -24,6 +24,23 @@ def test_clustered_cma_es():
     assert best < 2
 
 
+def test_clustered_separable_base_runs_as_one_fused_instance():
+    """PSO / CSO treat every decision variable on its own, so all blocks together are one wider instance: no member loop,
+    and the same optimisation behaviour as the loop."""
+    results = {}
+    for fuse in (False, "auto"):
+        base = algorithms.CSO(lb=torch.full((10,), -32.0), ub=torch.full((10,), 32.0), pop_size=100)
+        algo = algorithms.ClusterdAlgorithm(base_algorithm=base, dim=80, num_cluster=8, fuse=fuse)
+        assert algo.fused == (fuse == "auto") and len(algo.members) == (1 if algo.fused else 8)
+        results[fuse], state = _run(algo, 250)
+        pop = state.get_child_state("algorithm").get_child_state("members").get_child_state("m0000").population
+        assert pop.shape == (100, 80 if algo.fused else 10)
+    assert results["auto"] < 6 and results[False] < 6
+    with pytest.raises(TypeError):
+        algorithms.ClusterdAlgorithm(algorithms.CMAES(torch.zeros(10), init_stdev=1.0, pop_size=10), dim=40, num_cluster=4,
+                                     fuse=True)
+
+
 @pytest.mark.parametrize("random_subpop", [True, False])
 def test_vectorized_coevolution(random_subpop):
     base = algorithms.CSO(lb=torch.full((20,), -32.0), ub=torch.full((20,), 32.0), pop_size=100)

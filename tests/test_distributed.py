@@ -111,6 +111,15 @@ def test_enable_multi_devices(tmp_path):
         assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=1e-5)
 
 
+def test_clustered_algorithm_blocks_dealt_out_over_ranks(tmp_path):
+    """Cross-process decomposition: 4 blocks on 2 ranks, two member algorithms per rank, identical full candidates on
+    both ranks, and the optimisation converges."""
+    res = launch("clustered_dist", 2, tmp_path)
+    assert all(r["members"] == 2 and r["cand_shape"] == [16, 20] for r in res)
+    assert res[0]["cands"] == res[1]["cands"]
+    assert all(r["best"] < 1.0 for r in res)
+
+
 def test_island_model(tmp_path):
     res = launch("island", 2, tmp_path)
     assert res[0]["first"] != res[1]["first"], "islands must start from different populations"
