@@ -424,35 +424,64 @@ class SepCMAES(CMAES):
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
-    ask_sharded = None
-    tell_sharded = None
-
     def graph_signature(self, state):
         return ()
 
     def graph_host_counters(self):
         return ("count_iter",)                 # only counts; the device work reads count_iter_dev
 
+    def _rows(self, state, sample_key, rows: int, row_offset: int):
+        # noise rows addressed by their index in the whole population: a rank's rows are exactly those rows of the
+        # single-process sample
+        from ....ops import es as _es
+        noise = _es.noise_rows(sample_key, rows, self.dim, row_offset)
+        return state.mean + state.sigma * torch.sqrt(state.C) * noise
+
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
-        noise = rnd.normal(sample_key, (self.pop_size, self.dim))
-        population = state.mean + state.sigma * torch.sqrt(state.C) * noise
+        population = self._rows(state, sample_key, self.pop_size, 0)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
 
     def _whiten(self, state, delta):
         return delta / torch.sqrt(state.C)
 
-    def tell(self, state, fitness):
-        order = _sort.argsort(fitness)
-        elite = state.population[order[: self.mu]]
-        mean = state.mean + self.cm * (self.weights @ (elite - state.mean))
+    def _update(self, state, step_sum, ysq_sum):
+        """``step_sum = Σ w_i (x_i − m)``, ``ysq_sum = Σ w_i ((x_i − m)/σ)²`` over the selected individuals."""
+        mean = state.mean + self.cm * step_sum
         ps, pc, hsig, sigma = self._paths(state, mean)
-        y = (elite - state.mean) / state.sigma
         C = ((1 - self.c1 - self.cmu) * state.C
              + self.c1 * (pc * pc + (1 - hsig) * self.cc * (2 - self.cc) * state.C)
-             + self.cmu * (self.weights @ (y * y)))
+             + self.cmu * ysq_sum)
         return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma)
+
+    def tell(self, state, fitness):
+        order = _sort.argsort(fitness)
+        d = state.population[order[: self.mu]] - state.mean
+        y = d / state.sigma
+        return self._update(state, self.weights @ d, self.weights @ (y * y))
+
+    # Row-sharded: 2·dim floats per generation (the two weighted sums), nothing of size dim² anywhere.
+    def ask_sharded(self, state, rank: int, world: int):
+        if self.pop_size % world:
+            raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
+        local = self.pop_size // world
+        key, sample_key = rnd.split(state.key)
+        population = self._rows(state, sample_key, local, rank * local)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        local = self.pop_size // world
+        _, ranking = _sort.argsort_with_rank(fitness)
+        padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
+        w_local = padded[ranking[rank * local:(rank + 1) * local]]          # 0 outside the best μ
+        d = state.population - state.mean
+        y = d / state.sigma
+        packed = dist.all_reduce(torch.cat([w_local @ d, w_local @ (y * y)]))
+        return self._update(state, packed[: self.dim], packed[self.dim:])
 
 
 class IPOPCMAES(CMAES):

@@ -79,6 +79,31 @@ class _ESBase(Algorithm):
         self.center_init = torch.as_tensor(center_init, dtype=torch.float32)
         self.dim = self.center_init.shape[0]
 
+    # Row-sharded protocol shared by the strategies whose update is "per-row weights from the whole fitness vector,
+    # then weighted sums of the noise rows" (ARS, DES, SNES; OpenES and PGPE carry specialised forms).  The noise is
+    # regenerated from its key, so a rank perturbs and later re-reads only its rows [r·N/W, (r+1)·N/W) of the logical
+    # population; the fitness is all-gathered by the workflow, every rank derives the same weights from it, and one
+    # all-reduce of dim (or 2·dim) floats completes the sums.
+    def _ask_rows(self, state, scale, pop_size: int, mirrored: bool, rank: int, world: int):
+        if pop_size % world:
+            raise ValueError(f"pop_size {pop_size} is not divisible by the number of ranks {world}")
+        local = pop_size // world
+        key, noise_key = rnd.split(state.key)
+        x = _es.perturb(noise_key, state.center, scale, local, mirrored, row_offset=rank * local, total_rows=pop_size)
+        return x, state.replace(key=key, noise_key=noise_key)
+
+    def _noise_sums(self, state, w_rows, v_rows, pop_size: int, mirrored: bool, rank: int, world: int):
+        """All-reduced ``(Σ_i w_i z_i, Σ_i v_i (z_i² − 1))`` over the logical population (``v_rows`` may be None);
+        ``w_rows`` / ``v_rows`` hold one weight per logical row."""
+        from ....core import distributed as dist
+
+        if v_rows is None:
+            g = _mirrored_local_sum(state.noise_key, w_rows, self.dim, pop_size, mirrored, rank, world)
+            return dist.all_reduce(g), None
+        g, s = _mirrored_local_sum(state.noise_key, w_rows, self.dim, pop_size, mirrored, rank, world, v_full=v_rows)
+        packed = dist.all_reduce(torch.cat([g, s]))
+        return packed[: self.dim], packed[self.dim:]
+
     def _step_center(self, state, grad):
         """center ← center + optimizer(grad); returns (center, state)."""
         updates, state = use_state(self.optimizer.update)(state, grad, state.center)
@@ -254,15 +279,28 @@ class ARS(_ESBase):
         x = _es.perturb(noise_key, state.center, self.sigma, self.pop_size, mirrored=True)
         return x, state.replace(key=key, noise_key=noise_key)
 
-    def tell(self, state, fitness):
+    def _pair_weights(self, fitness):
         h = self.pop_size // 2
         f1, f2 = fitness[:h], fitness[h:]
         elite = torch.argsort(torch.minimum(f1, f2), stable=True)[: self.elite_pop_size]
         spread = torch.cat([f1[elite], f2[elite]]).std(unbiased=False) + 1e-5
-        w = torch.zeros_like(f1).index_copy(0, elite, (f1 - f2)[elite])
+        return torch.zeros_like(f1).index_copy(0, elite, (f1 - f2)[elite]), spread
+
+    def tell(self, state, fitness):
+        w, spread = self._pair_weights(fitness)
         g, _ = _es.weighted_noise_sum(state.noise_key, w, self.dim)
         grad = g / (self.elite_pop_size * spread)
         center, state = self._step_center(state, grad)
+        return state.replace(center=center)
+
+    def ask_sharded(self, state, rank: int, world: int):
+        return self._ask_rows(state, self.sigma, self.pop_size, True, rank, world)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        w, spread = self._pair_weights(fitness)
+        # logical rows: +z_i carries w_i/2, its mirror −z_i carries −w_i/2 (the halves add up to w_i z_i)
+        g, _ = self._noise_sums(state, torch.cat([w, -w]) * 0.5, None, self.pop_size, True, rank, world)
+        center, state = self._step_center(state, g / (self.elite_pop_size * spread))
         return state.replace(center=center)
 
 
@@ -293,16 +331,30 @@ class DES(_ESBase):
         x = _es.perturb(noise_key, state.center, state.sigma, self.popsize)
         return x, state.replace(key=key, noise_key=noise_key)
 
-    def tell(self, state, fitness):
+    def _row_weights(self, state, fitness):
         order = torch.argsort(fitness, stable=True)
-        w = torch.zeros_like(fitness).index_copy(0, order, state.weights)      # weight of row i by its rank
-        g, s = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        return torch.zeros_like(fitness).index_copy(0, order, state.weights)   # weight of row i by its rank
+
+    def _update(self, state, w, g, s):
         wsum = w.sum()
         weighted_mean = wsum * state.center + state.sigma * g
         weighted_sigma = torch.sqrt(state.sigma ** 2 * (s + wsum) + 1e-6)
         center = state.center + self.lrate_mean * (weighted_mean - state.center)
         sigma = state.sigma + self.lrate_sigma * (weighted_sigma - state.sigma)
         return state.replace(center=center, sigma=sigma)
+
+    def tell(self, state, fitness):
+        w = self._row_weights(state, fitness)
+        g, s = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        return self._update(state, w, g, s)
+
+    def ask_sharded(self, state, rank: int, world: int):
+        return self._ask_rows(state, state.sigma, self.popsize, False, rank, world)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        w = self._row_weights(state, fitness)
+        g, s = self._noise_sums(state, w, w, self.popsize, False, rank, world)
+        return self._update(state, w, g, s)
 
 
 class ESMC(_ESBase):
@@ -377,13 +429,27 @@ class SNES(_ESBase):
         x = _es.perturb(noise_key, state.center, state.sigma, self.popsize)
         return x, state.replace(key=key, noise_key=noise_key)
 
-    def tell(self, state, fitness):
+    def _row_weights(self, state, fitness):
         order = torch.argsort(fitness, stable=True)
-        w = torch.zeros_like(fitness).index_copy(0, order, state.weights)
-        grad_mean, grad_sigma = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        return torch.zeros_like(fitness).index_copy(0, order, state.weights)
+
+    def _update(self, state, grad_mean, grad_sigma):
         center = state.center + self.lrate_mean * state.sigma * grad_mean
         sigma = state.sigma * torch.exp(self.lrate_sigma / 2 * grad_sigma)
         return state.replace(center=center, sigma=sigma)
+
+    def tell(self, state, fitness):
+        w = self._row_weights(state, fitness)
+        grad_mean, grad_sigma = _es.weighted_noise_sum(state.noise_key, w, self.dim, v=w)
+        return self._update(state, grad_mean, grad_sigma)
+
+    def ask_sharded(self, state, rank: int, world: int):
+        return self._ask_rows(state, state.sigma, self.popsize, False, rank, world)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        w = self._row_weights(state, fitness)
+        grad_mean, grad_sigma = self._noise_sums(state, w, w, self.popsize, False, rank, world)
+        return self._update(state, grad_mean, grad_sigma)
 
 
 class SeparableNES(Algorithm):

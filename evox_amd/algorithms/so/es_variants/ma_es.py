@@ -26,9 +26,6 @@ class MAES(CMAES):
                      sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
                      population=torch.empty((self.pop_size, self.dim), device=dev))
 
-    ask_sharded = None
-    tell_sharded = None
-
     def graph_signature(self, state):
         return ()
 
@@ -41,6 +38,37 @@ class MAES(CMAES):
         population = _cma.sample(sample_key, state.mean, state.sigma, state.M, ones, self.pop_size, self.precision)
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=state.count_iter_dev + 1, key=key)
+
+    # Row-sharded: a rank samples its rows of the population (the counter-based generator addresses rows by their
+    # index in the whole population), reduces its share of the selected steps, and one all-reduce of dim + dim² floats
+    # completes the mean shift and the rank-μ term.
+    def ask_sharded(self, state, rank: int, world: int):
+        if self.pop_size % world:
+            raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
+        local = self.pop_size // world
+        key, sample_key = rnd.split(state.key)
+        ones = torch.ones(self.dim, device=state.M.device)
+        population = _cma.sample(sample_key, state.mean, state.sigma, state.M, ones, local, self.precision,
+                                 row_offset=rank * local)
+        return population, state.replace(population=population, count_iter=state.count_iter + 1,
+                                         count_iter_dev=state.count_iter_dev + 1, key=key)
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        local = self.pop_size // world
+        _, ranking = _sort.argsort_with_rank(fitness)
+        padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
+        w_local = padded[ranking[rank * local:(rank + 1) * local]]          # 0 outside the best μ
+        d = state.population - state.mean
+        y = d / state.sigma
+        gram = (y * w_local[:, None]).T @ y
+        packed = dist.all_reduce(torch.cat([w_local @ d, gram.reshape(-1)]))
+        mean = state.mean + self.cm * packed[: self.dim]
+        ps, pc, hsig, sigma = self._paths(state, mean)
+        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+        M = alpha * state.M + self.c1 * torch.outer(pc, pc) + self.cmu * packed[self.dim:].reshape(self.dim, self.dim)
+        return state.replace(mean=mean, ps=ps, pc=pc, M=M, sigma=sigma)
 
     def _whiten(self, state, delta):
         return state.M @ delta
@@ -61,6 +89,9 @@ class MAES(CMAES):
 class LMMAES(MAES):
     """Limited-memory variant: the rank-μ term is built from a ring buffer of the last
     ``memory_size`` selected steps."""
+
+    ask_sharded = None           # the step memory is built from the whole selected set in rank order
+    tell_sharded = None
 
     def __init__(self, *args, memory_size=None, **kwargs):
         super().__init__(*args, **kwargs)

@@ -48,7 +48,7 @@ def test_collectives(tmp_path):
         assert r["bcast"] == [10.0, 11.0, 12.0] and r["gather_axis1"] == [1, 6]
 
 
-@pytest.mark.parametrize("case", ["cmaes", "openes", "pgpe"])
+@pytest.mark.parametrize("case", ["cmaes", "openes", "pgpe", "ars", "des", "snes", "sepcmaes", "maes"])
 def test_row_sharded_matches_single_process(case, tmp_path):
     base = launch(case, 1, tmp_path)[0]
     for world in (2, 4):
@@ -57,7 +57,7 @@ def test_row_sharded_matches_single_process(case, tmp_path):
             assert r["row_sharded"] and r["world"] == world
             assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=2e-3, rtol=2e-3)
         assert all(r["vec"] == res[0]["vec"] for r in res), "replicas diverged"
-        if case == "cmaes":
+        if case in ("cmaes", "sepcmaes"):
             assert res[0]["local_rows"] == 16 // world
 
 
