@@ -32,6 +32,10 @@ _native.register_hip_api({"evox_hip_shift_rotate": (_native.I, [_native.P, _nati
 _native.register_hip_api({"evox_hip_cec_simple": (_native.I, [_native.P, _native.I64, _native.P, _native.P, _native.F, _native.I,
                                                              _native.F, _native.I, _native.I, _native.P, _native.P])})
 
+_native.register_hip_api({"evox_hip_cec_full": (_native.I, [_native.P, _native.I64, _native.P, _native.I64, _native.P, _native.I,
+                                                           _native.P, _native.I, _native.F, _native.I, _native.I, _native.P,
+                                                           _native.P])})
+
 _DATA = Path(__file__).parent / "data" / "cec2022.npz"
 
 
@@ -204,10 +208,38 @@ class CEC2022Function(Problem):
     def _f(self, x, c):
         raise NotImplementedError
 
+    def _floor(self, d: int) -> float:
+        return self.floor
+
+    def _fused(self, X):
+        """Functions 3 and 6-12 in one launch (``csrc/cec2022.hip``): shift, rotations, shuffle, basic functions or
+        composition, zero floor.  None when the input is not an fp32 GPU matrix of a dimension the suite defines."""
+        f = self.func_num
+        if not (X.is_cuda and X.dtype == torch.float32 and X.dim() == 2 and X.shape[0] > 0 and (f == 3 or 6 <= f <= 12)):
+            return None
+        d = X.shape[1]
+        if d not in self._rot or (6 <= f <= 8 and d not in self._shuffle):
+            return None
+        c = self._consts(d, X)
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        o, M = c["o"].contiguous(), c["M"][:6].contiguous()        # the data files hold ten matrices; at most six are used
+        S = c["S"].contiguous() if "S" in c else None
+        out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+        _check(_hip().evox_hip_cec_full(X.data_ptr(), X.stride(0), o.data_ptr(), o.stride(0), M.data_ptr(), int(M.shape[0]),
+                                        S.data_ptr() if S is not None else None, f, float(self._floor(d)), X.shape[0], d,
+                                        out.data_ptr(), _stream_of(X)), "cec_full")
+        return out
+
     def evaluate(self, state, X):
         X = X.to(torch.float32) if not X.is_floating_point() else X
+        import os
+        fused = self._fused(X) if os.environ.get("EVOX_AMD_CEC_FUSED", "1") == "1" else None
+        if fused is not None:
+            return fused, state
         f = self._f(X, self._consts(X.shape[1], X))
-        return torch.where(f < self.floor, torch.zeros_like(f), f), state
+        floor = self._floor(X.shape[1])
+        return torch.where(f < floor, torch.zeros_like(f), f), state
 
     def _compose(self, x, fs, c, bias, sigma, lamb):
         d = x.shape[1]
@@ -325,10 +357,8 @@ class F11_CEC2022(CEC2022Function):
                           rastrigin(self._ssr(x, o[4], M[4]))], dim=1)
         return self._compose(x, fs, c, [0, 200, 300, 400, 200], [20, 20, 30, 30, 20], [5e-4, 1, 10, 1, 10])
 
-    def evaluate(self, state, X):
-        f = self._f(X, self._consts(X.shape[1], X))
-        floor = 5.07e-6 if X.shape[1] == 10 else 1.46e-5
-        return torch.where(f < floor, torch.zeros_like(f), f), state
+    def _floor(self, d: int) -> float:
+        return 5.07e-6 if d == 10 else 1.46e-5
 
 
 class F12_CEC2022(CEC2022Function):

@@ -1060,6 +1060,43 @@ def test_cec2022_fused_simple_functions(func, d):
     assert float(at_opt[0]) == 0.0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("func", [3, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("d", [2, 10, 20])
+def test_cec2022_fused_hybrid_and_composition_functions(func, d, monkeypatch):
+    """F3 and F6-F12 in one launch against the float64 tensor formulation, near and far from the optimum, on strided
+    rows, and exactly at the optimum (a composition's weight collapses onto that component)."""
+    from evox_amd import problems
+
+    if d == 2 and 6 <= func <= 8:
+        pytest.skip("the hybrid functions are defined for D = 10 and 20")
+    prob = problems.numerical.CEC2022TestSuit.create(func)
+    g = torch.Generator().manual_seed(func * 100 + d)
+    opt = torch.as_tensor(prob._shift[0, :d], dtype=torch.float32)
+    x = torch.cat([torch.rand(500, d, generator=g) * 200 - 100, opt + torch.randn(200, d, generator=g) * 3.0])
+    ref, _ = prob.evaluate(None, x.double())
+    got, _ = prob.evaluate(None, x.cuda())
+    monkeypatch.setenv("EVOX_AMD_CEC_FUSED", "0")
+    unfused, _ = prob.evaluate(None, x.cuda())
+    monkeypatch.setenv("EVOX_AMD_CEC_FUSED", "1")
+    err_fused = (got.cpu().double() - ref).abs()
+    err_torch = (unfused.cpu().double() - ref).abs()
+    tol = 5e-4 * ref.abs() + 1e-4 * float(ref.abs().median()) + 1e-3
+    # as accurate as the fp32 tensor formulation allows (Katsuura and the periodic terms amplify input rounding)
+    assert bool(((err_fused <= tol) | (err_fused <= 4 * err_torch + 1e-6)).all()), float((err_fused / (ref.abs() + 1)).max())
+    view = (torch.rand(300, 32, generator=g) * 200 - 100).cuda()[:, :d]
+    got2, _ = prob.evaluate(None, view)
+    ref2, _ = prob.evaluate(None, view.cpu().double())
+    assert torch.allclose(got2.cpu().double(), ref2, rtol=2e-3, atol=1e-3 * float(ref2.abs().median()) + 1e-3)
+    # at the optimum the fp32 shift cancels exactly (the float64 formulation sees the rounding of the optimum itself):
+    # compare with the fp32 tensor formulation there
+    at_opt, _ = prob.evaluate(None, opt[None, :].cuda())
+    monkeypatch.setenv("EVOX_AMD_CEC_FUSED", "0")
+    ref_opt, _ = prob.evaluate(None, opt[None, :].cuda())
+    monkeypatch.setenv("EVOX_AMD_CEC_FUSED", "1")
+    assert abs(float(at_opt[0]) - float(ref_opt[0])) <= 1e-3 and float(at_opt[0]) >= 0.0
+
+
 # ---------------------------------------------------------------------------------------------------
 # bf16 matrix-core kernels of the CMA-ES generation (csrc/bf16_gemm.h, csrc/cma_bf16.hip)
 # ---------------------------------------------------------------------------------------------------
