@@ -104,7 +104,8 @@ class CMAES(Algorithm):
         self._generations = {}
         if decomposition == "newton_schulz":
             planes = int(os.environ.get("EVOX_AMD_NS_PLANES", "2")) if self._bf16_kernels else 0
-            self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16" and not planes, planes=planes)
+            self._ns = _cma.NewtonSchulzSqrt(bf16_copy=precision == "bf16" and not planes, planes=planes,
+                                             initial_cond=1.0)        # the covariance starts as the identity
         else:
             self._ns = None
 
@@ -181,6 +182,24 @@ class CMAES(Algorithm):
         """Polled by the workflow every few dozen replays: True asks for a new recording (the
         Newton–Schulz iteration count frozen in the graph no longer reaches the tolerance)."""
         return self._ns is not None and self._ns.needs_more_iterations()
+
+    def graph_retune(self, state):
+        """Polled by the workflow every few dozen replays of a recorded step.  A recording freezes the host decisions of
+        the factorisation (iteration count, scaling mode, which driver); here the record that the last replay left on the
+        device is read (one small synchronising copy) and put through the same policy as in eager mode.  Returns the
+        algorithm state with the new decisions when they differ — the workflow then records again — else None."""
+        ns = self._ns
+        if ns is None or "ns_res1" not in state:
+            return None
+        rec = [float(v) for v in state.ns_res1.tolist()]
+        old_iters, old_safe = int(state.ns_iters), int(state.ns_safe)
+        # the safe-scaling countdown does not run inside a recording: it is advanced here, by the shortest polling period
+        iters, safe = ns._policy(old_iters, max(0, old_safe - 8), rec[5], rec[6] != 0.0, max(1, old_iters))
+        cond = rec[1] if not rec[0] > 0.0 else min(rec[1], ns.COND_TRUST * rec[0])
+        symmetric = bool(ns.planes and 0.0 < cond <= ns.SYM_COND_MAX and safe == 0)
+        if iters == old_iters and (safe > 0) == (old_safe > 0) and symmetric == bool(int(state.ns_sym)):
+            return None
+        return state.replace(ns_iters=iters, ns_safe=safe, ns_sym=int(symmetric))
 
     def _sample_scale(self, state):
         # the Newton–Schulz mode stores the whole factor C^{1/2} in B and leaves D at ones

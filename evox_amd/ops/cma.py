@@ -144,7 +144,7 @@ class NewtonSchulzSqrt:
     """
 
     def __init__(self, tol: float | None = None, min_iters: int = 2, max_iters: int = 40, start_iters: int = 6,
-                 bf16_copy: bool = False, planes: int = 0):
+                 bf16_copy: bool = False, planes: int = 0, initial_cond: float | None = None):
         # Two bf16 planes carry 16 significant bits: the residual of such an iteration bottoms out near 1e-5, and
         # its consumers (a sampling factor rounded to bf16, relative error 4e-3; the whitening of the path update)
         # do not see a residual of a few 1e-4.
@@ -154,6 +154,9 @@ class NewtonSchulzSqrt:
         self.min_iters, self.max_iters, self.start_iters = min_iters, max_iters, start_iters
         self.bf16_copy = bf16_copy        # also emit the square root rounded to bf16 (fp32 library driver)
         self.planes = int(planes)
+        # condition number the caller vouches for during the first two calls, before any estimate exists (CMA-ES starts
+        # from C = I); None: unknown, the first calls take the fp32 library products
+        self.initial_cond = initial_cond
         self.last_residual = None
         self.fallbacks = 0                # times the guarded outputs passed the previous factors on
         self._eye = None
@@ -161,7 +164,6 @@ class NewtonSchulzSqrt:
         self._pinned = {}                 # id(record tensor) -> (weakref, event, pinned copy)
         self._ring, self._ring_next = [], 0
         self._graph_scal = None
-        self._graph_symmetric = False     # which GPU driver the last eager call used (a recording keeps it)
         self._scratch = None
         self.symmetric_calls = 0          # calls served by the symmetric bf16 driver
         self._ctrl = None                 # control of the stand-alone use ``ns(C)``
@@ -189,10 +191,11 @@ class NewtonSchulzSqrt:
         g = torch.Generator().manual_seed(0x5EED)
         v = torch.randn(2, n, generator=g)
         zero = torch.zeros(self.REC, dtype=torch.float32, device=device)
-        return {"ns_iters": int(self.start_iters), "ns_safe": 0, "ns_calls": 0, "ns_used1": 0, "ns_used2": 0,
+        return {"ns_iters": int(self.start_iters), "ns_safe": 0, "ns_calls": 0, "ns_used1": 0, "ns_used2": 0, "ns_sym": 0,
                 "ns_vec": (v / v.norm(dim=1, keepdim=True)).to(device), "ns_res1": zero, "ns_res2": zero.clone()}
 
-    CONTROL_FIELDS = ("ns_iters", "ns_safe", "ns_calls", "ns_used1", "ns_used2", "ns_vec", "ns_res1", "ns_res2")
+    # ns_sym: which GPU driver the last call used (1: symmetric bf16 planes); a recorded step keeps using it
+    CONTROL_FIELDS = ("ns_iters", "ns_safe", "ns_calls", "ns_used1", "ns_used2", "ns_sym", "ns_vec", "ns_res1", "ns_res2")
 
     def _policy(self, iters: int, safe: int, r: float, failed: bool, used: int):
         self.last_residual = r
@@ -307,17 +310,18 @@ class NewtonSchulzSqrt:
         if use_safe and not capturing:
             safe -= 1
         if capturing:
-            symmetric = bool(self._graph_symmetric)
+            symmetric = bool(int(ctrl.get("ns_sym", 0))) and bool(self.planes and have_ws and gpu)
         else:
             # The bound from above (an ∞-norm) overshoots by up to √n when the eigenvectors are far from the axes;
             # the estimate from below (a power vector carried from call to call) is tight after a few refreshes.
             # Three times the estimate is trusted when it is the smaller one — a wrong decision shows up as a
             # residual over tolerance and sends the next calls through the safe scaling and the library products.
             cond = 0.0
+            if lagged is None and calls < 2 and self.initial_cond is not None:
+                cond = float(self.initial_cond)
             if lagged is not None and lagged[1] > 0.0:
                 cond = lagged[1] if not lagged[0] > 0.0 else min(lagged[1], self.COND_TRUST * lagged[0])
             symmetric = bool(self.planes and have_ws and gpu and 0.0 < cond <= self.SYM_COND_MAX and not use_safe)
-            self._graph_symmetric = symmetric
         self.symmetric_calls += int(symmetric)
         used = max(1, iters)
         return {"iters": iters, "safe": safe, "use_safe": use_safe, "symmetric": symmetric, "used": used, "calls": calls,
@@ -332,7 +336,8 @@ class NewtonSchulzSqrt:
             # a recording freezes the host values: only the call counter moves (the replay advances it on the host)
             return dict(ctrl, ns_calls=plan["calls"] + 1, ns_vec=new_vec, ns_res1=rec, ns_res2=ctrl["ns_res1"])
         return {"ns_iters": plan["iters"], "ns_safe": plan["safe"], "ns_calls": plan["calls"] + 1, "ns_used1": plan["used"],
-                "ns_used2": int(ctrl["ns_used1"]), "ns_vec": new_vec, "ns_res1": rec, "ns_res2": ctrl["ns_res1"]}
+                "ns_used2": int(ctrl["ns_used1"]), "ns_sym": int(plan["symmetric"]), "ns_vec": new_vec, "ns_res1": rec,
+                "ns_res2": ctrl["ns_res1"]}
 
     def library_workspace(self, n: int, device):
         from . import blas as _blas

@@ -269,10 +269,21 @@ class StdWorkflow(Workflow):
         if any(hooks[h] for h in ("post_ask", "pre_eval", "post_eval", "pre_tell")):
             # the recording's own buffers are overwritten a few replays later: monitors get copies they may keep
             aux = {k: _tree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, v) for k, v in aux.items()}
-        if self.graph_replays % 64 == 0:
-            check = getattr(self.algorithm, "graph_check", None)
-            if check is not None and check():
-                self._graphed = None            # record again with the algorithm's updated settings
+        # host decisions frozen into the recording are revisited now and then (often at first, while an iteration
+        # control settles from its conservative start): the algorithm may hand back a state with new decisions, which
+        # is then recorded afresh
+        period = 8 if self.graph_replays <= 160 else 64
+        if self.graph_replays % period == 0:
+            retune = getattr(self.algorithm, "graph_retune", None)
+            if retune is not None:
+                tuned = retune(new_state.get_child_state("algorithm"))
+                if tuned is not None:
+                    new_state = new_state.replace_child("algorithm", tuned)
+                    self._graphed = None
+            else:
+                check = getattr(self.algorithm, "graph_check", None)
+                if check is not None and check():
+                    self._graphed = None        # record again with the algorithm's updated settings
         for m in hooks["post_ask"]:
             m.post_ask(new_state, aux["cands"])
         for m in hooks["pre_eval"]:

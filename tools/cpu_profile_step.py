@@ -21,7 +21,16 @@ for _ in range(100):
 t_issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_total = time.perf_counter() - t0
-print(f"issue time per step {t_issue*1e4:.1f} us, total per step {t_total*1e4:.1f} us (100 steps)")
+print(f"back-to-back: loop time per step {t_issue*1e4:.1f} us, with the final synchronisation {t_total*1e4:.1f} us (100 steps; "
+      "when the GPU is the bottleneck the launches block on the full queue and the two agree)")
+# issue cost proper: every step is issued into an EMPTY queue (synchronise first), so no launch ever blocks
+acc = 0.0
+for _ in range(200):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    state = wf.step(state)
+    acc += time.perf_counter() - t0
+print(f"issue time per step into an empty queue {acc / 200 * 1e6:.1f} us (Python + ctypes + kernel launches, nothing waited for)")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(300):
