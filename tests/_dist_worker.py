@@ -36,7 +36,8 @@ def main():
         algo = {"cmaes_resync": lambda: A.CMAES(c, 1.0, pop_size=16),
                 "cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
                 # local shares wide enough that only the rank-ordered head of the local rows is processed
-                "cmaes_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
+                "cmaes_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh"),
+                                              precision=os.environ.get("EVOX_TEST_PRECISION", "fp32")),
                 "openes": lambda: A.OpenES(c, 16, 0.05, 0.1),
                 "ars": lambda: A.ARS(16, c, elite_ratio=0.5, lr=0.1, sigma=0.1), "des": lambda: A.DES(16, c, sigma_init=0.5),
                 "snes": lambda: A.SNES(16, c, sigma=0.5),

@@ -251,6 +251,21 @@ def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
 
 
 @pytest.mark.gpu
+def test_row_sharded_bf16_kernels_on_gpu_match_single_process(tmp_path):
+    """The configuration of the multi-GPU benchmark: bf16 operands on the hand-written sampling / covariance kernels,
+    Newton-Schulz factorisation, row-sharded over 2 and 4 ranks (sharing the one GPU, gloo).  bf16 rounding of the local
+    covariance shares differs with the split, so the means agree to bf16-level tolerance, and the replicas exactly."""
+    env = {"EVOX_TEST_DEVICE": "cuda", "EVOX_TEST_DECOMP": "newton_schulz", "EVOX_TEST_PRECISION": "bf16"}
+    base = launch("cmaes_wide", 1, tmp_path, env)[0]
+    for world in (2, 4):
+        res = launch("cmaes_wide", world, tmp_path, env)
+        for r in res:
+            assert r["row_sharded"] and r["world"] == world
+            assert torch.allclose(torch.tensor(r["vec"]), torch.tensor(base["vec"]), atol=5e-2, rtol=5e-2)
+        assert all(r["vec"] == res[0]["vec"] for r in res), "replicas diverged"
+
+
+@pytest.mark.gpu
 def test_resync_on_gpu_leaves_identical_replicas(tmp_path):
     """Two ranks on the one GPU (gloo, device tensors staged through the host): a nudged replica and whatever
     last-bit differences the ranks' library GEMMs produce are gone after the broadcast that ends generation 30."""

@@ -121,3 +121,26 @@ def test_every_registered_hip_entry_point_is_exported():
     lib = ctypes.CDLL(path)
     missing = [name for name in _native._HIP_API if not hasattr(lib, name)]
     assert not missing, missing
+
+
+def test_rank_launcher_relays_rank0_and_fails_fast(tmp_path):
+    """``utils/launch.py`` (what ``bench.py --gpus N`` uses): N child processes with the rendezvous environment, rank 0's
+    output relayed, and a failing rank takes its peers down instead of leaving them waiting."""
+    import importlib.util
+    import os
+    import time
+
+    import evox_amd
+
+    spec = importlib.util.spec_from_file_location(
+        "_launch", os.path.join(os.path.dirname(evox_amd.__file__), "utils", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nif os.environ['RANK'] == '0':\n    print('world', os.environ['WORLD_SIZE'], os.environ['MASTER_ADDR'])\n")
+    assert launch.launch_ranks(str(ok), [], 3) == 0
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(60)\n")
+    t0 = time.time()
+    assert launch.launch_ranks(str(bad), [], 3) == 7
+    assert time.time() - t0 < 30
