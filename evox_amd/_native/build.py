@@ -98,10 +98,39 @@ def _compile_hip(src: Path, verbose: bool) -> Path:
     return obj
 
 
+class _BuildLock:
+    """Inter-process lock around a rebuild: the ranks of a multi-process job import the package at the same time, and
+    only one of them may compile (the others then find the library fresh)."""
+
+    def __init__(self, name: str):
+        self.path = HIP_LIB.parent / name
+        self.fd = None
+
+    def __enter__(self):
+        import fcntl
+
+        self.fd = open(self.path, "w")
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        self.fd.close()
+
+
 def build_hip(force: bool = False, verbose: bool = False, jobs: int | None = None) -> Path:
     srcs = hip_sources()
     if not force and _newer(HIP_LIB, srcs + headers()):
         return HIP_LIB
+    with _BuildLock(".build_hip.lock"):
+        if not force and _newer(HIP_LIB, srcs + headers()):
+            return HIP_LIB                   # another process built it while this one waited
+        return _build_hip_locked(srcs, force, verbose, jobs)
+
+
+def _build_hip_locked(srcs, force: bool, verbose: bool, jobs) -> Path:
     if force and OBJ.exists():
         shutil.rmtree(OBJ)
     jobs = jobs or min(8, max(1, (os.cpu_count() or 2) // 2), int(os.environ.get("MAX_JOBS", "8")))

@@ -79,5 +79,19 @@ for _ in range(2):
     fc1, _ = cec.evaluate(None, pop20)                                       # cec_simple_kernel<20>
     r1 = nds.non_dominated_rank(torch.rand(800, 3, device=dev))             # nds_small_kernel (one launch)
     r2 = nds.non_dominated_rank(torch.rand(4000, 2, device=dev))            # four rounds, then nds_peel_all_kernel
+# kernels of the sweep non-dominated sort, the fused CEC 2022 evaluation, SRA, and the bf16 CMA-ES generation
+from evox_amd import algorithms as _A, workflows as _W
+for _ in range(2):
+    r3 = nds.non_dominated_rank(torch.rand(200000, 3, device=dev), until=100000)   # sweep_merge / scan / chunks / query
+    for fnum in (3, 7, 9, 12):
+        fcx, _ = problems.numerical.CEC2022TestSuit.create(fnum).evaluate(None, pop20)   # cec_full_kernel<20>
+    i1, i2 = moselect.sra_indicators(torch.rand(20000, 3, device=dev), lower_only=True)   # sra_indicators_kernel
+    rk2 = moselect.stochastic_ranking(i1, i2, torch.rand(20000, device=dev), 0.45)        # stochastic_ranking_blocked_kernel<24>
+algo = _A.CMAES(center_init=torch.full((n,), 2.0, device=dev), init_stdev=1.0, pop_size=lam, decomposition="newton_schulz",
+                precision="bf16")
+wf = _W.StdWorkflow(algo, problems.numerical.Ackley())
+st = wf.init(rnd.PRNGKey(1))
+for _ in range(12):                                                          # gemm_nt_kernel family, cma_bf16 / cma_step kernels
+    st = wf.step(st)
 torch.cuda.synchronize()
 print("done")
