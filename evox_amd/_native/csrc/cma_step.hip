@@ -13,6 +13,7 @@
 
 extern "C" {
 int evox_hip_split(const int32_t* keys, int32_t* out, int64_t nkeys, int64_t n, void* stream);
+int evox_hip_split_count(const int32_t* key, int32_t* out, int64_t n, const float* count_in, float* count_out, void* stream);
 int evox_hip_normal_bf16_pitched(const int32_t* key, void* out, int64_t rows, int64_t n, int64_t ld, int64_t row_offset,
                                  void* stream);
 int evox_hip_bf16_sample(const void* Z, int64_t ldz, const void* S, int64_t lds, const float* mean, const float* sigma,
@@ -40,8 +41,15 @@ namespace {
 using namespace evox;
 
 // y = A x for a row-major n x n matrix: one wavefront per row, 16-byte loads
+// ctrl (optional): the 2 x n power vectors of the factorisation control, laid out into vec4 = [v | scratch | v2 | scratch2]
+// on the way (a copy that would otherwise be a launch of its own).
 __global__ __launch_bounds__(256) void matvec_kernel(const float* __restrict__ A, int n, const float* __restrict__ x,
-                                                     float* __restrict__ y) {
+                                                     float* __restrict__ y, const float* __restrict__ ctrl,
+                                                     float* __restrict__ vec4) {
+  if (ctrl != nullptr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * n; i += gridDim.x * blockDim.x)
+      vec4[(i / n) * 2 * n + (i % n)] = ctrl[i];
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int row = blockIdx.x * 4 + wave; row < n; row += gridDim.x * 4) {
     const float* r = A + (size_t)row * n;
@@ -66,18 +74,19 @@ __global__ void copy_floats_kernel(const float* __restrict__ src, float* __restr
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) dst[i] = src[i];
 }
-// vec4 = [v | scratch | v2 | scratch2] <- ctrl (2 x n); and back
-__global__ void vec_in_kernel(const float* __restrict__ ctrl, float* __restrict__ vec4, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < 2 * n) vec4[(i / n) * 2 * n + (i % n)] = ctrl[i];
-}
 // The control vectors and the 7-float record of the call leave together.  Without a refresh of the condition
-// estimates (`carry` set) the two estimates of the previous record are carried over.
+// estimates (`carry` set) the two estimates of the previous record are carried over.  rec_host (optional): the same
+// record written straight into pinned host memory, where the iteration control reads it two calls later — no copy
+// command, the write is visible once the kernel has completed.
 __global__ void ctrl_out_kernel(const float* __restrict__ vec4, const float* __restrict__ scal, const float* __restrict__ carry,
-                                float* __restrict__ ctrl, float* __restrict__ rec, int n) {
+                                float* __restrict__ ctrl, float* __restrict__ rec, float* __restrict__ rec_host, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 2 * n) ctrl[i] = vec4[(i / n) * 2 * n + (i % n)];
-  if (i < 7) rec[i] = (carry != nullptr && i < 2) ? carry[i] : scal[9 + i];
+  if (i < 7) {
+    const float v = (carry != nullptr && i < 2) ? carry[i] : scal[9 + i];
+    rec[i] = v;
+    if (rec_host != nullptr) rec_host[i] = v;
+  }
 }
 
 }  // namespace
@@ -87,9 +96,18 @@ EVOX_API int evox_hip_matvec(const float* A, int n, const float* x, float* y, vo
   if (n <= 0) return (int)hipErrorInvalidValue;
   int mv_blocks = (n + 3) / 4;
   if (mv_blocks > kNumCU * 4) mv_blocks = kNumCU * 4;
-  matvec_kernel<<<mv_blocks, 256, 0, (hipStream_t)stream>>>(A, n, x, y);
+  matvec_kernel<<<mv_blocks, 256, 0, (hipStream_t)stream>>>(A, n, x, y, nullptr, nullptr);
   return last_launch_status();
 }
+
+namespace {
+int matvec_with_control(const float* A, int n, const float* x, float* y, const float* ctrl, float* vec4, hipStream_t st) {
+  int mv_blocks = (n + 3) / 4;
+  if (mv_blocks > kNumCU * 4) mv_blocks = kNumCU * 4;
+  matvec_kernel<<<mv_blocks, 256, 0, st>>>(A, n, x, y, ctrl, vec4);
+  return last_launch_status();
+}
+}  // namespace
 
 struct CmaAsk {
   const int32_t* key;        // [2]
@@ -111,6 +129,9 @@ struct CmaAsk {
   void* ev_side;
   int32_t* keys_next;        // [2][2]
   void* z_next;              // the draw buffer that is not `z`
+  // generation counter on the device, advanced by the split kernel (optional)
+  const float* count_in;
+  float* count_out;
 };
 
 EVOX_API void* evox_hip_event_create() {
@@ -129,7 +150,10 @@ EVOX_API int evox_hip_cma_ask(const CmaAsk* a, void* stream) {
     if (hipStreamWaitEvent(main_st, (hipEvent_t)a->ev_side, 0) != hipSuccess) return (int)hipErrorUnknown;
   }
   if (a->split) {
-    e = evox_hip_split(a->key, a->keys_out, 1, 2, stream);
+    e = evox_hip_split_count(a->key, a->keys_out, 2, a->count_in, a->count_out, stream);
+    if (e) return e;
+  } else if (a->count_out != nullptr) {
+    e = evox_hip_split_count(a->key, a->keys_out, 0, a->count_in, a->count_out, stream);
     if (e) return e;
   }
   if (a->draw) {
@@ -187,6 +211,7 @@ struct CmaTell {
   // factorisation control
   int factor;                // 0: skip the factorisation (decomp_per_iter > 1)
   int ns_iters, ns_power, ns_safe, ns_symmetric, ns_cond, ns_first_poly4, ns_tune;
+  float* rec_host;           // device-visible address of 7 pinned floats, or null
 };
 
 EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
@@ -197,7 +222,7 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
                             t->step, t->mu, n, t->lam, stream);
   if (e) return e;
-  e = evox_hip_matvec(t->invsqrtC, n, t->step, t->whitened, stream);
+  e = matvec_with_control(t->invsqrtC, n, t->step, t->whitened, t->factor ? t->ctrl_vec : nullptr, t->vec4, st);
   if (e) return e;
   e = evox_hip_cma_paths(t->mean, t->step, t->whitened, t->ps, t->pc, t->sigma, t->iter_dev, t->consts, n, t->mean_o, t->ps_o,
                          t->pc_o, t->scalars_o, stream);
@@ -205,7 +230,6 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   e = evox_hip_bf16_cov(t->yt, t->ldmu, n, t->mu, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->C_o,
                         t->cov_ws, t->cov_ws_floats, stream);
   if (e || !t->factor) return e;
-  vec_in_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->ctrl_vec, t->vec4, n);
   if (t->ns_symmetric) {
     e = evox_hip_ns_sqrt_bf16(t->C_o, n, t->ldn, t->ns_planes, t->ns_iters, t->ns_power, t->ns_safe, t->planes, t->ns_f32,
                               t->vec4, t->scal, t->B, t->invsqrtC, t->B_o, t->inv_o, t->b16_o, stream);
@@ -220,6 +244,6 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
     if (e) return e;
   }
   ctrl_out_kernel<<<(2 * n + 255) / 256, 256, 0, st>>>(t->vec4, t->scal, t->ns_cond ? nullptr : t->prev_rec, t->ctrl_vec_o,
-                                                      t->rec_o, n);
+                                                      t->rec_o, t->rec_host, n);
   return last_launch_status();
 }

@@ -94,6 +94,19 @@ __global__ void split_kernel(const int32_t* __restrict__ keys, int32_t* __restri
   }
 }
 
+// split of ONE key into n keys, and a float counter advanced by one in the same launch (the generation counter of an
+// algorithm whose ask() splits its key: one launch instead of two)
+__global__ void split_count_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ out, int64_t n,
+                                   const float* __restrict__ count_in, float* __restrict__ count_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const u32x4 b = philox_block((uint32_t)key[0], (uint32_t)key[1], (uint64_t)t, kStreamSplit);
+    out[2 * t] = (int32_t)b.x;
+    out[2 * t + 1] = (int32_t)b.y;
+  }
+  if (t == 0 && count_out != nullptr) *count_out = *count_in + 1.0f;
+}
+
 __global__ void fold_kernel(const int32_t* __restrict__ keys, int32_t* __restrict__ out, int64_t nkeys,
                             int64_t data) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,6 +167,13 @@ EVOX_API int evox_hip_split(const int32_t* keys, int32_t* out, int64_t nkeys, in
   const int64_t total = nkeys * n;
   if (total <= 0) return 0;
   split_kernel<<<stream_grid(total, 64), 64, 0, (hipStream_t)stream>>>(keys, out, nkeys, n);
+  return last_launch_status();
+}
+
+EVOX_API int evox_hip_split_count(const int32_t* key, int32_t* out, int64_t n, const float* count_in, float* count_out,
+                                  void* stream) {
+  if (n < 0 || (n == 0 && count_out == nullptr)) return (int)hipErrorInvalidValue;     // n == 0: the counter alone
+  split_count_kernel<<<n > 0 ? (int)((n + 63) / 64) : 1, 64, 0, (hipStream_t)stream>>>(key, out, n, count_in, count_out);
   return last_launch_status();
 }
 

@@ -230,13 +230,15 @@ class CMAES(Algorithm):
     def ask(self, state):
         if self._native_calls and state.mean.is_cuda:
             ws = self._workspace(self.pop_size, self.mu)
-            population, key = self._generation(ws).ask(state.key, self._factor_bf16(state, ws), state.mean, state.sigma,
-                                                       self.pop_size, 0, self._prefetch_draws)
+            population, key, count = self._generation(ws).ask(state.key, self._factor_bf16(state, ws), state.mean,
+                                                              state.sigma, self.pop_size, 0, self._prefetch_draws,
+                                                              count=state.count_iter_dev)
         else:
             key, sample_key = self._keys(state)
             population = self._sample(state, key, sample_key, self.pop_size)
+            count = state.count_iter_dev + 1
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
-                                         count_iter_dev=state.count_iter_dev + 1, key=key)
+                                         count_iter_dev=count, key=key)
 
     # -- pieces of tell ------------------------------------------------------------------
     def _paths(self, state, mean, order=None):

@@ -222,17 +222,41 @@ class NewtonSchulzSqrt:
             return [float(x) for x in host]
         return [float(x) for x in rec.detach().cpu()]
 
+    def pinned_slot(self):
+        """``(host tensor, event, device-visible address)`` of the next slot of the pinned record ring: a native driver
+        writes its record there directly (no copy command) and hands the slot back through :meth:`adopt`."""
+        import ctypes
+
+        if len(self._ring) < 4:
+            host = torch.empty(self.REC, dtype=torch.float32, pin_memory=True)
+            dev_ptr = ctypes.c_void_p()
+            from .. import _native
+            _native.register_hip_api({"evox_hip_host_device_ptr": (_native.I, [_native.P, _native.P])})
+            check(hip().evox_hip_host_device_ptr(host.data_ptr(), ctypes.byref(dev_ptr)), "hipHostGetDevicePointer")
+            self._ring.append((host, torch.cuda.Event(), dev_ptr.value))
+        slot = self._ring[self._ring_next]
+        self._ring_next = (self._ring_next + 1) % 4
+        return slot
+
+    def adopt(self, rec: torch.Tensor, slot) -> None:
+        """``rec``'s values are (being) written into ``slot`` by work already issued on the current stream."""
+        import weakref
+
+        host, ev, _ = slot
+        ev.record()
+        self._pinned[id(rec)] = (weakref.ref(rec), ev, host)
+        self._adopted = id(rec)
+
     def _publish(self, rec: torch.Tensor):
         """Start the copy of a fresh record to pinned memory (read two calls later)."""
         import weakref
 
         if len(self._pinned) > 8:          # records of abandoned states
             self._pinned = {k: e for k, e in self._pinned.items() if e[0]() is not None}
+        if getattr(self, "_adopted", None) == id(rec) and id(rec) in self._pinned:
+            return                             # the native driver has written this record into its slot already
         if rec.is_cuda:
-            if len(self._ring) < 4:
-                self._ring.append((torch.empty(self.REC, dtype=torch.float32, pin_memory=True), torch.cuda.Event()))
-            host, ev = self._ring[self._ring_next]
-            self._ring_next = (self._ring_next + 1) % 4
+            host, ev, _ = self.pinned_slot()
             host.copy_(rec, non_blocking=True)
             ev.record()
             self._pinned[id(rec)] = (weakref.ref(rec), ev, host)

@@ -26,7 +26,8 @@ class _Ask(ctypes.Structure):
     _fields_ = [("key", c_void_p), ("keys_out", c_void_p), ("z", c_void_p), ("s16", c_void_p), ("mean", c_void_p),
                 ("sigma", c_void_p), ("x", c_void_p), ("ldn", c_int64), ("row_offset", c_int64), ("rows", c_int),
                 ("n", c_int), ("draw", c_int), ("split", c_int), ("wait_side", c_int), ("prefetch", c_int),
-                ("side", c_void_p), ("ev_main", c_void_p), ("ev_side", c_void_p), ("keys_next", c_void_p), ("z_next", c_void_p)]
+                ("side", c_void_p), ("ev_main", c_void_p), ("ev_side", c_void_p), ("keys_next", c_void_p), ("z_next", c_void_p),
+                ("count_in", c_void_p), ("count_out", c_void_p)]
 
 
 class _Tell(ctypes.Structure):
@@ -41,7 +42,7 @@ class _Tell(ctypes.Structure):
                 ("mean_o", c_void_p), ("ps_o", c_void_p), ("pc_o", c_void_p), ("scalars_o", c_void_p), ("C_o", c_void_p),
                 ("B_o", c_void_p), ("inv_o", c_void_p), ("b16_o", c_void_p), ("ctrl_vec_o", c_void_p), ("rec_o", c_void_p),
                 ("factor", c_int), ("ns_iters", c_int), ("ns_power", c_int), ("ns_safe", c_int), ("ns_symmetric", c_int),
-                ("ns_cond", c_int), ("ns_first_poly4", c_int), ("ns_tune", c_int)]
+                ("ns_cond", c_int), ("ns_first_poly4", c_int), ("ns_tune", c_int), ("rec_host", c_void_p)]
 
 
 _native.register_hip_api({
@@ -91,8 +92,9 @@ class Generation:
         except Exception:
             pass
 
-    def ask(self, key, s16, mean, sigma, rows: int, row_offset: int, prefetch: bool):
-        """``(population, next key)``.  With ``prefetch`` the split and the Gaussian draws of the NEXT generation
+    def ask(self, key, s16, mean, sigma, rows: int, row_offset: int, prefetch: bool, count=None):
+        """``(population, next key, count + 1 | None)`` — ``count``: the generation counter on the device (a 0-d fp32
+        tensor), advanced by the kernel that splits the key.  With ``prefetch`` the split and the Gaussian draws of the NEXT generation
         are started on a side stream once this generation's product has been issued; the next ``ask`` uses them when
         it is called with the key tensor returned here (any other key is split and drawn on the spot: same values)."""
         a, ws = self._ask, self.ws
@@ -111,6 +113,12 @@ class Generation:
         a.key, a.keys_out, a.z, a.s16 = key.data_ptr(), keys_out.data_ptr(), ws._Z[zi].data_ptr(), s16.data_ptr()
         a.mean, a.sigma, a.x = mean.data_ptr(), sigma.data_ptr(), out.data_ptr()
         a.rows, a.row_offset = rows, row_offset
+        count_out = None
+        if count is not None:
+            count_out = torch.empty((), dtype=torch.float32, device=dev)
+            a.count_in, a.count_out = count.data_ptr(), count_out.data_ptr()
+        else:
+            a.count_in = a.count_out = None
         next_key = keys_out[0]
         a.prefetch = 0
         if prefetch and not torch.cuda.is_current_stream_capturing():
@@ -124,7 +132,7 @@ class Generation:
             a.prefetch, a.keys_next, a.z_next = 1, keys_next.data_ptr(), ws._Z[zi ^ 1].data_ptr()
             self._ahead = (next_key, keys_next, zi ^ 1, (rows, row_offset))
         check(hip().evox_hip_cma_ask(ctypes.addressof(a), stream_of(mean)), "cma_ask")
-        return out, next_key
+        return out, next_key, count_out
 
     def tell(self, state, fitness, factor: bool, plan: dict | None):
         """Returns ``(mean, ps, pc, sigma, C, B, invsqrtC, b16, ctrl_vec, rec)``; the last five are ``None`` when the
@@ -151,6 +159,9 @@ class Generation:
             t.ctrl_vec_o, t.rec_o = ctrl_o.data_ptr(), rec_o.data_ptr()
             t.ns_iters, t.ns_power, t.ns_safe = plan["used"], plan["power"], int(plan["use_safe"])
             t.ns_symmetric, t.ns_cond = int(plan["symmetric"]), int(plan["cond"])
+            # the record of this call goes straight into a pinned slot of the iteration control (read two calls later)
+            slot = self.ns.pinned_slot() if not torch.cuda.is_current_stream_capturing() else None
+            t.rec_host = slot[2] if slot is not None else None
             if plan["symmetric"]:
                 b16 = ws.factor_buffer()
                 t.b16_o = b16.data_ptr()
@@ -162,7 +173,11 @@ class Generation:
                 t.lib_work, t.lib_eye = w.work.data_ptr(), w.eye.data_ptr()
                 t.ns_first_poly4, t.ns_tune = int(_blas._first_step_default() == "poly4"), _blas._tune()
                 t.b16_o = None
+        else:
+            slot = None
         check(hip().evox_hip_cma_tell(ctypes.addressof(t), stream_of(pop)), "cma_tell")
+        if slot is not None:
+            self.ns.adopt(rec_o, slot)
         sigma = scalars[0]
         if not factor:
             return mean_o, ps_o, pc_o, sigma, C_o, None, None, None, None, None
