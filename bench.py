@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--resync-every", type=int, default=0,
                     help="multi-GPU: broadcast rank 0's replicated algorithm state every k generations (0 = never; the "
                          "replicas are computed from identical all-reduced statistics and differ at rounding level at most)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="single process: run the row-sharded workflow anyway (its cost without any communication)")
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
                          "rehearses the multi-rank path on a single GPU")
@@ -97,7 +99,7 @@ def main():
                             eigh_method=args.eigh, decomposition=args.decomp)
     problem = {"ackley": problems.numerical.Ackley, "sphere": problems.numerical.Sphere,
                "rosenbrock": problems.numerical.Rosenbrock, "ellipsoid": problems.numerical.Ellipsoid}[args.problem]()
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from evox_amd.workflows import ShardedWorkflow
 
         wf = ShardedWorkflow(algo, problem, resync_every=args.resync_every)

@@ -89,7 +89,68 @@ __global__ void ctrl_out_kernel(const float* __restrict__ vec4, const float* __r
   }
 }
 
+// Row-sharded generation: the rank-mu term arrives summed over the ranks (gram = sum_r S_r^T S_r), so the covariance update
+// is one elementwise pass, out = alpha C + c1 pc pc^T + cmu gram.  `poison` (optional, one float): a positive value —
+// some rank had to drop selected rows — turns the result into NaNs on every rank alike.
+__global__ __launch_bounds__(256) void cov_from_gram_kernel(const float* __restrict__ C, const float* __restrict__ gram,
+                                                            const float* __restrict__ pc, const float* __restrict__ alpha,
+                                                            float c1, float cmu, const float* __restrict__ poison,
+                                                            float* __restrict__ out, int n) {
+  const float a = *alpha;
+  const bool bad = poison != nullptr && *poison > 0.f;
+  const int64_t total = (int64_t)n * n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / n), c = (int)(i - (int64_t)r * n);
+    const float v = fmaf(a, C[i], fmaf(c1, pc[r] * pc[c], cmu * gram[i]));
+    out[i] = bad ? __builtin_nanf("") : v;
+  }
+}
+
+// Row-sharded selection: of this rank's rows [lo, lo + local) those whose global rank is below mu are compacted, in row
+// order, into `keep` slots (row index relative to lo, and the square root of the recombination weight of its rank); the
+// unused slots get weight zero.  More than `keep` selected rows cannot be held: the count of such ranks is what
+// `overflow[0]` carries into the all-reduced message (overflow[1..3] are cleared).  One workgroup: per-thread counts, one block scan, ordered write-out.
+__global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __restrict__ ranking, int lo, int local, int mu,
+                                                            int keep, const float* __restrict__ sqrt_w_padded,
+                                                            int64_t* __restrict__ order_out, float* __restrict__ w_out,
+                                                            float* __restrict__ overflow) {
+  __shared__ int s_cnt[1024];
+  const int t = threadIdx.x;
+  const int per = (local + 1023) / 1024;
+  const int first = t * per, last = min(first + per, local);
+  int c = 0;
+  for (int i = first; i < last; ++i) c += ranking[lo + i] < mu;
+  s_cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {            // inclusive scan
+    const int v = t >= off ? s_cnt[t - off] : 0;
+    __syncthreads();
+    s_cnt[t] += v;
+    __syncthreads();
+  }
+  int pos = s_cnt[t] - c;
+  const int total = s_cnt[1023];
+  for (int i = first; i < last; ++i) {
+    const int64_t r = ranking[lo + i];
+    if (r < mu) {
+      if (pos < keep) { order_out[pos] = i; w_out[pos] = sqrt_w_padded[r]; }
+      ++pos;
+    }
+  }
+  for (int k = total + t; k < keep; k += 1024) { order_out[k] = 0; w_out[k] = 0.f; }
+  if (t < 4) overflow[t] = (t == 0 && total > keep) ? 1.f : 0.f;       // the message's four trailing floats
+}
+
 }  // namespace
+
+// ranking: global rank of every individual (int64, lam_total); sqrt_w_padded: lam_total floats (zero from mu on).
+EVOX_API int evox_hip_cma_select_local(const int64_t* ranking, int lo, int local, int mu, int keep, const float* sqrt_w_padded,
+                                       int64_t* order_out, float* w_out, float* overflow, void* stream) {
+  if (local <= 0 || keep <= 0 || keep > local || lo < 0 || mu <= 0) return (int)hipErrorInvalidValue;
+  select_local_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ranking, lo, local, mu, keep, sqrt_w_padded, order_out, w_out,
+                                                          overflow);
+  return last_launch_status();
+}
 
 // y = A x (A: n x n row-major fp32): the whitening product of the path update
 EVOX_API int evox_hip_matvec(const float* A, int n, const float* x, float* y, void* stream) {
@@ -212,23 +273,39 @@ struct CmaTell {
   int factor;                // 0: skip the factorisation (decomp_per_iter > 1)
   int ns_iters, ns_power, ns_safe, ns_symmetric, ns_cond, ns_first_poly4, ns_tune;
   float* rec_host;           // device-visible address of 7 pinned floats, or null
+  // row-sharded generation: the selected rows were reduced on every rank and summed over the ranks beforehand; `step`
+  // then is an INPUT (the summed mean shift) and `gram` the summed rank-mu term
+  int sharded;
+  const float* gram;         // n x n
+  const float* poison;       // one float (> 0: rows were dropped somewhere), or null
 };
 
 EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int n = t->n;
-  int e = evox_hip_rank_sort_sliced(t->fitness, t->lam, t->order, nullptr, t->sort_scratch, stream);
-  if (e) return e;
-  e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
-                            t->step, t->mu, n, t->lam, stream);
-  if (e) return e;
+  int e = 0;
+  if (!t->sharded) {
+    e = evox_hip_rank_sort_sliced(t->fitness, t->lam, t->order, nullptr, t->sort_scratch, stream);
+    if (e) return e;
+    e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
+                              t->step, t->mu, n, t->lam, stream);
+    if (e) return e;
+  } else if (t->gram == nullptr) {
+    return (int)hipErrorInvalidValue;
+  }
   e = matvec_with_control(t->invsqrtC, n, t->step, t->whitened, t->factor ? t->ctrl_vec : nullptr, t->vec4, st);
   if (e) return e;
   e = evox_hip_cma_paths(t->mean, t->step, t->whitened, t->ps, t->pc, t->sigma, t->iter_dev, t->consts, n, t->mean_o, t->ps_o,
                          t->pc_o, t->scalars_o, stream);
   if (e) return e;
-  e = evox_hip_bf16_cov(t->yt, t->ldmu, n, t->mu, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->C_o,
-                        t->cov_ws, t->cov_ws_floats, stream);
+  if (!t->sharded) {
+    e = evox_hip_bf16_cov(t->yt, t->ldmu, n, t->mu, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->C_o,
+                          t->cov_ws, t->cov_ws_floats, stream);
+  } else {
+    cov_from_gram_kernel<<<stream_grid((int64_t)n * n, 256), 256, 0, st>>>(t->C, t->gram, t->pc_o, t->scalars_o + 1,
+                                                                           t->consts[6], t->consts[7], t->poison, t->C_o, n);
+    e = last_launch_status();
+  }
   if (e || !t->factor) return e;
   if (t->ns_symmetric) {
     e = evox_hip_ns_sqrt_bf16(t->C_o, n, t->ldn, t->ns_planes, t->ns_iters, t->ns_power, t->ns_safe, t->planes, t->ns_f32,

@@ -262,9 +262,10 @@ class CMAES(Algorithm):
             return _b16.matvec(state.invsqrtC, delta)
         return state.invsqrtC @ delta
 
-    def _tell_native(self, state, fitness):
-        """``tell`` as one native call (same kernels and arithmetic as the op-by-op path below)."""
-        ws = self._workspace(self.pop_size, self.mu)
+    def _tell_native(self, state, fitness, reduced=None, ws=None):
+        """``tell`` as one native call (same kernels and arithmetic as the op-by-op path below).  ``reduced``: the
+        row-sharded form, entered after the all-reduce with ``(step_sum, gram, overflow)`` (``ops/cma_native.py``)."""
+        ws = self._workspace(self.pop_size, self.mu) if ws is None else ws
         gen = self._generation(ws)
         factor = state.count_iter % self.decomp_per_iter == 0
         ns = self._ns
@@ -273,8 +274,8 @@ class CMAES(Algorithm):
             capturing = torch.cuda.is_current_stream_capturing()
             ctrl = {k: getattr(state, k) for k in ns.CONTROL_FIELDS}
             plan = ns.plan(ctrl, capturing, True, True)
-        fitness = fitness.contiguous()
-        mean, ps, pc, sigma, C, B, inv, b16, vec_o, rec = gen.tell(state, fitness, factor and ns is not None, plan)
+        fitness = fitness.contiguous() if fitness is not None else None
+        mean, ps, pc, sigma, C, B, inv, b16, vec_o, rec = gen.tell(state, fitness, factor and ns is not None, plan, reduced)
         extra = {}
         if not factor:
             B, D, inv, count_eigen = state.B, state.D, state.invsqrtC, state.count_eigen
@@ -346,11 +347,17 @@ class CMAES(Algorithm):
         if self.pop_size % world:
             raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
         local = self.pop_size // world
-        key, sample_key = self._keys(state)
         consts = self._shard_consts(local, state.mean.device)
-        population = self._sample(state, key, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
+        if self._native_calls and self._bf16_kernels and state.mean.is_cuda:
+            ws = self._workspace(local, min(consts["keep"], local))
+            population, key, count = self._generation(ws).ask(state.key, self._factor_bf16(state, ws), state.mean, state.sigma,
+                                                              local, rank * local, False, count=state.count_iter_dev)
+        else:
+            key, sample_key = self._keys(state)
+            population = self._sample(state, key, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
+            count = state.count_iter_dev + 1
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
-                                         count_iter_dev=state.count_iter_dev + 1, key=key)
+                                         count_iter_dev=count, key=key)
 
     def _shard_consts(self, local: int, device):
         """Per-process constants of the sharded tell (built once): sqrt of the recombination weights
@@ -383,13 +390,17 @@ class CMAES(Algorithm):
             keep = min(consts["keep"], local)
             nn = self.dim * self.dim
             packed = torch.empty(nn + self.dim + 4, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
-            if keep < local:
-                # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the
-                # ranks, so that number is hypergeometric with a standard deviation of at most
-                # √local / 2: the local rows are put in rank order and the first `keep` (mean + 12
-                # standard deviations) go through the gather and the Gram product.  A count beyond
-                # `keep` would drop rows: every rank adds that fact to the message, and any overflow poisons the
-                # update on every rank in the same generation (and raises at the next periodic host check).
+            if self._native_calls and self._bf16_kernels:
+                # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the ranks, so that number
+                # is hypergeometric with a standard deviation of at most √local / 2: the selected rows are compacted
+                # into `keep` slots (mean + 12 standard deviations; one launch, ``ops/cma_native.py::select_local``) and
+                # only those go through the gather and the Gram product.  A count beyond `keep` would drop rows: every
+                # rank adds that fact to the message, and any overflow poisons the update on every rank in the same
+                # generation (and raises at the next periodic host check).
+                from ....ops import cma_native as _nat
+                local_order, sqrt_w_local = _nat.select_local(ranking, rank * local, local, self.mu, keep,
+                                                              consts["sqrt_w_padded"], packed[nn + self.dim:])
+            elif keep < local:
                 local_order = _sort.argsort(my_rank.to(torch.float32))[:keep]
                 packed[nn + self.dim:] = ((my_rank < self.mu).sum() > keep).to(torch.float32)
                 sqrt_w_local = consts["sqrt_w_padded"][my_rank[local_order]]
@@ -408,11 +419,15 @@ class CMAES(Algorithm):
                 _gemm.gram(S, out=gram_out)
             packed = dist.all_reduce_(packed)
             overflow = packed[nn + self.dim]
-            step_sum = torch.where(overflow > 0, torch.full_like(overflow, float("nan")), packed[nn:nn + self.dim])
-            gram = packed[:nn].view(self.dim, self.dim)
             consts["calls"] += 1
             if consts["calls"] % 64 == 0 and float(overflow) > 0:
                 raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(overflow)} rank(s)")
+            gram = packed[:nn].view(self.dim, self.dim)
+            if self._native_calls and self._bf16_kernels and ws is not None:
+                # everything after the all-reduce — whitening, paths, covariance, factorisation — in one native call;
+                # an overflow turns the covariance into NaNs there, on every rank alike
+                return self._tell_native(state, None, reduced=(packed[nn:nn + self.dim], gram, packed[nn + self.dim:]), ws=ws)
+            step_sum = torch.where(overflow > 0, torch.full_like(overflow, float("nan")), packed[nn:nn + self.dim])
             mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
                 state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
                 (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))

@@ -42,7 +42,8 @@ class _Tell(ctypes.Structure):
                 ("mean_o", c_void_p), ("ps_o", c_void_p), ("pc_o", c_void_p), ("scalars_o", c_void_p), ("C_o", c_void_p),
                 ("B_o", c_void_p), ("inv_o", c_void_p), ("b16_o", c_void_p), ("ctrl_vec_o", c_void_p), ("rec_o", c_void_p),
                 ("factor", c_int), ("ns_iters", c_int), ("ns_power", c_int), ("ns_safe", c_int), ("ns_symmetric", c_int),
-                ("ns_cond", c_int), ("ns_first_poly4", c_int), ("ns_tune", c_int), ("rec_host", c_void_p)]
+                ("ns_cond", c_int), ("ns_first_poly4", c_int), ("ns_tune", c_int), ("rec_host", c_void_p),
+                ("sharded", c_int), ("gram", c_void_p), ("poison", c_void_p)]
 
 
 _native.register_hip_api({
@@ -51,7 +52,23 @@ _native.register_hip_api({
     "evox_hip_event_create": (c_void_p, []),
     "evox_hip_event_destroy": (None, [P]),
     "evox_hip_cma_tell": (I, [P, P]),
+    "evox_hip_cma_select_local": (I, [P, I, I, I, I, P, P, P, P, P]),
 })
+
+
+def select_local(ranking: torch.Tensor, lo: int, local: int, mu: int, keep: int, sqrt_w_padded: torch.Tensor,
+                 overflow_out: torch.Tensor):
+    """Row-sharded selection in one launch: ``(order, sqrt_w)`` of ``keep`` slots — this rank's rows with a global rank
+    below ``mu`` (row index relative to ``lo``, in row order) and the square roots of their recombination weights, unused
+    slots weighing zero; ``overflow_out`` (four floats) becomes ``[1, 0, 0, 0]`` when more than ``keep`` rows were selected,
+    zeros otherwise."""
+    dev = ranking.device
+    order = torch.empty(keep, dtype=torch.int64, device=dev)
+    w = torch.empty(keep, dtype=torch.float32, device=dev)
+    check(hip().evox_hip_cma_select_local(ranking.data_ptr(), int(lo), int(local), int(mu), int(keep), sqrt_w_padded.data_ptr(),
+                                          order.data_ptr(), w.data_ptr(), overflow_out.data_ptr(), stream_of(ranking)),
+          "cma_select_local")
+    return order, w
 
 
 class Generation:
@@ -134,9 +151,12 @@ class Generation:
         check(hip().evox_hip_cma_ask(ctypes.addressof(a), stream_of(mean)), "cma_ask")
         return out, next_key, count_out
 
-    def tell(self, state, fitness, factor: bool, plan: dict | None):
+    def tell(self, state, fitness, factor: bool, plan: dict | None, reduced=None):
         """Returns ``(mean, ps, pc, sigma, C, B, invsqrtC, b16, ctrl_vec, rec)``; the last five are ``None`` when the
-        factorisation is skipped (``b16`` also when the fp32 library driver ran)."""
+        factorisation is skipped (``b16`` also when the fp32 library driver ran).
+
+        ``reduced = (step_sum, gram, poison | None)``: the row-sharded form — the selected rows have been reduced on every
+        rank and summed over the ranks already; the call then starts at the whitening product (``fitness`` is unused)."""
         ws, t = self.ws, self._tell
         n, dev = ws.n, ws.device
         small = torch.empty(3 * n + 4 + n + 2 * n + 8, dtype=torch.float32, device=dev)
@@ -146,7 +166,14 @@ class Generation:
         rec_o = small[6 * n + 4:6 * n + 11]
         C_o = torch.empty((n, n), dtype=torch.float32, device=dev)
         pop = state.population
-        t.fitness, t.pop, t.ldpop = fitness.data_ptr(), pop.data_ptr(), pop.stride(0)
+        if reduced is None:
+            t.sharded, t.gram, t.poison = 0, None, None
+            t.step = self.vecs.data_ptr()
+            t.fitness, t.pop, t.ldpop = fitness.data_ptr(), pop.data_ptr(), pop.stride(0)
+        else:
+            step_sum, gram, poison = reduced
+            t.sharded, t.gram, t.step = 1, gram.data_ptr(), step_sum.data_ptr()
+            t.poison = poison.data_ptr() if poison is not None else None
         t.mean, t.ps, t.pc, t.sigma = state.mean.data_ptr(), state.ps.data_ptr(), state.pc.data_ptr(), state.sigma.data_ptr()
         t.C, t.B, t.invsqrtC, t.iter_dev = state.C.data_ptr(), state.B.data_ptr(), state.invsqrtC.data_ptr(), state.count_iter_dev.data_ptr()
         t.mean_o, t.ps_o, t.pc_o, t.scalars_o, t.C_o = mean_o.data_ptr(), ps_o.data_ptr(), pc_o.data_ptr(), scalars.data_ptr(), C_o.data_ptr()
