@@ -110,7 +110,66 @@ __global__ __launch_bounds__(256) void cov_from_gram_kernel(const float* __restr
 // order, into `keep` slots (row index relative to lo, and the square root of the recombination weight of its rank); the
 // unused slots get weight zero.  More than `keep` selected rows cannot be held: the count of such ranks is what
 // `overflow[0]` carries into the all-reduced message (overflow[1..3] are cleared).  One workgroup: per-thread counts, one block scan, ordered write-out.
-__global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __restrict__ ranking, int lo, int local, int mu,
+// Order-preserving unsigned image of an fp32 key, the one the counting sort ranks by (-0 = +0, NaN after +inf).
+__device__ __forceinline__ uint32_t sortable_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFEu;
+  if (u == 0x80000000u) u = 0u;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Global ranks of this process's rows when every process has sorted its own fitness values before the all-gather.
+// msg: world x 2 x local floats — row 2q the fitness of process q's rows, row 2q + 1 the same values sorted.  The global
+// (stable: ties by global row index) rank of local row i is its rank among its own rows plus, for every other process,
+// the number of that process's values in front of it: one binary search per process, all of them advanced together so
+// that their loads are in flight at the same time.
+constexpr int kSearchGroup = 8;
+__global__ __launch_bounds__(256) void presorted_rank_kernel(const float* __restrict__ msg, int world, int me, int local,
+                                                             const int64_t* __restrict__ own_rank, int* __restrict__ ranks_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= local) return;
+  const uint32_t k = sortable_key(msg[(size_t)(2 * me) * local + i]);
+  int total = (int)own_rank[i];
+  int steps = 1;
+  while ((1 << steps) <= local) ++steps;                 // a range of `local` entries is empty after this many halvings
+  for (int q0 = 0; q0 < world; q0 += kSearchGroup) {
+    int lo[kSearchGroup], hi[kSearchGroup];
+#pragma unroll
+    for (int u = 0; u < kSearchGroup; ++u) {
+      const int q = q0 + u;
+      lo[u] = 0;
+      hi[u] = (q < world && q != me) ? local : 0;
+    }
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+      for (int u = 0; u < kSearchGroup; ++u) {
+        if (lo[u] < hi[u]) {
+          const int q = q0 + u;
+          const int mid = (lo[u] + hi[u]) >> 1;
+          const uint32_t v = sortable_key(msg[(size_t)(2 * q + 1) * local + mid]);
+          // values of a process in front of mine win ties (k <= 0xFFFFFFFE: k + 1 cannot wrap)
+          const bool before = v < k + (uint32_t)(q < me);
+          if (before) lo[u] = mid + 1; else hi[u] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSearchGroup; ++u) total += lo[u];
+  }
+  ranks_out[i] = total;
+}
+
+// The ranks come either from `ranking` (global rank of every individual) or, when `partial` is given, as the sum of
+// `slices` partial counts per local row (evox_hip_rank_window_count).
+__device__ __forceinline__ int local_rank(const int64_t* ranking, const int* partial, int slices, int lo, int local, int i) {
+  if (!partial) return (int)ranking[lo + i];
+  int r = 0;
+  for (int s = 0; s < slices; ++s) r += partial[(size_t)s * local + i];
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __restrict__ ranking, const int* __restrict__ partial,
+                                                            int slices, int lo, int local, int mu,
                                                             int keep, const float* __restrict__ sqrt_w_padded,
                                                             int64_t* __restrict__ order_out, float* __restrict__ w_out,
                                                             float* __restrict__ overflow) {
@@ -119,7 +178,7 @@ __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __res
   const int per = (local + 1023) / 1024;
   const int first = t * per, last = min(first + per, local);
   int c = 0;
-  for (int i = first; i < last; ++i) c += ranking[lo + i] < mu;
+  for (int i = first; i < last; ++i) c += local_rank(ranking, partial, slices, lo, local, i) < mu;
   s_cnt[t] = c;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {            // inclusive scan
@@ -131,7 +190,7 @@ __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __res
   int pos = s_cnt[t] - c;
   const int total = s_cnt[1023];
   for (int i = first; i < last; ++i) {
-    const int64_t r = ranking[lo + i];
+    const int r = local_rank(ranking, partial, slices, lo, local, i);
     if (r < mu) {
       if (pos < keep) { order_out[pos] = i; w_out[pos] = sqrt_w_padded[r]; }
       ++pos;
@@ -147,8 +206,36 @@ __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __res
 EVOX_API int evox_hip_cma_select_local(const int64_t* ranking, int lo, int local, int mu, int keep, const float* sqrt_w_padded,
                                        int64_t* order_out, float* w_out, float* overflow, void* stream) {
   if (local <= 0 || keep <= 0 || keep > local || lo < 0 || mu <= 0) return (int)hipErrorInvalidValue;
-  select_local_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ranking, lo, local, mu, keep, sqrt_w_padded, order_out, w_out,
-                                                          overflow);
+  select_local_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(ranking, nullptr, 0, lo, local, mu, keep, sqrt_w_padded, order_out,
+                                                          w_out, overflow);
+  return last_launch_status();
+}
+
+// The same from the fitness of the whole population (n_total keys): the local rows are ranked against all keys by
+// counting (evox_hip_rank_window_count; scratch: evox_hip_rank_window_slices() x local ints), then compacted.
+extern "C" int evox_hip_rank_window_count(const float* keys, int n, int row_lo, int rows_n, int* scratch, void* stream);
+
+EVOX_API int evox_hip_cma_rank_select_local(const float* fitness, int n_total, int lo, int local, int mu, int keep,
+                                            const float* sqrt_w_padded, int64_t* order_out, float* w_out, float* overflow,
+                                            int* scratch, void* stream) {
+  if (local <= 0 || keep <= 0 || keep > local || lo < 0 || mu <= 0 || lo + local > n_total) return (int)hipErrorInvalidValue;
+  const int slices = evox_hip_rank_window_count(fitness, n_total, lo, local, scratch, stream);
+  if (slices < 0) return -slices;
+  select_local_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(nullptr, scratch, slices, 0, local, mu, keep, sqrt_w_padded,
+                                                          order_out, w_out, overflow);
+  return last_launch_status();
+}
+
+// The same from the pre-sorted fitness message (see presorted_rank_kernel); own_rank: rank of every local row among the
+// local rows (int64), scratch: local ints.
+EVOX_API int evox_hip_cma_presorted_select_local(const float* msg, int world, int me, int local, const int64_t* own_rank,
+                                                 int mu, int keep, const float* sqrt_w_padded, int64_t* order_out,
+                                                 float* w_out, float* overflow, int* scratch, void* stream) {
+  if (local <= 0 || keep <= 0 || keep > local || world <= 0 || me < 0 || me >= world || mu <= 0)
+    return (int)hipErrorInvalidValue;
+  presorted_rank_kernel<<<(local + 255) / 256, 256, 0, (hipStream_t)stream>>>(msg, world, me, local, own_rank, scratch);
+  select_local_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(nullptr, scratch, 1, 0, local, mu, keep, sqrt_w_padded, order_out,
+                                                          w_out, overflow);
   return last_launch_status();
 }
 

@@ -91,15 +91,17 @@ __global__ __launch_bounds__(kThreads) void rank_sort_kernel(const float* __rest
 // and scatters the order.
 constexpr int kSlices = 4;      // upper bound; a launch uses as many as keep rows x slices within one round of blocks
 
+// Rows [row_lo, row_lo + rows_n) are ranked against all n keys (row_lo a multiple of 4; the whole vector: 0, n).
 __global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __restrict__ keys, int n, int* __restrict__ partial,
-                                                              int slices) {
+                                                              int slices, int row_lo, int rows_n) {
   __shared__ __attribute__((aligned(16))) uint32_t sk[kChunk];
   __shared__ int part[kWaves][kRows];
   const int il = threadIdx.x & 63;
   const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i0 = blockIdx.x * kRows;
+  const int i0 = row_lo + blockIdx.x * kRows;
   const int i = i0 + il;
-  const uint32_t ki = i < n ? sortable(keys[i]) : 0xFFFFFFFEu;
+  const bool valid = i < row_lo + rows_n;
+  const uint32_t ki = valid ? sortable(keys[i]) : 0xFFFFFFFEu;
   // this block's slice of the keys, in whole groups of four
   const int per = ((n + slices - 1) / slices + 3) / 4 * 4;
   const int j0 = blockIdx.y * per, j1 = min(n, j0 + per);
@@ -128,22 +130,24 @@ __global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __res
   }
   part[s][il] = cnt;
   __syncthreads();
-  if (s == 0 && i < n) {
+  if (s == 0 && valid) {
     int r = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) r += part[w][il];
-    partial[(size_t)blockIdx.y * n + i] = r;
+    partial[(size_t)blockIdx.y * rows_n + (i - row_lo)] = r;
   }
 }
 
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const int* __restrict__ partial, int n, int64_t* __restrict__ order,
-                                                           int64_t* __restrict__ rank_out, int slices) {
+                                                           int64_t* __restrict__ rank_out, int slices,
+                                                           const float* __restrict__ keys, float* __restrict__ sorted_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int r = 0;
   for (int sl = 0; sl < slices; ++sl) r += partial[(size_t)sl * n + i];
-  order[r] = i;
+  if (order) order[r] = i;
   if (rank_out) rank_out[i] = r;
+  if (sorted_out) sorted_out[r] = keys[i];
 }
 
 }  // namespace
@@ -165,9 +169,40 @@ EVOX_API int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order,
   const int rows = (n + kRows - 1) / kRows;
   int slices = 2 * evox::kNumCU / rows;
   slices = slices < 1 ? 1 : (slices > kSlices ? kSlices : slices);
-  rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices);
-  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices);
+  rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices, 0, n);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, nullptr, nullptr);
   return evox::last_launch_status();
+}
+
+// The sorted keys themselves (sorted_out[rank[i]] = keys[i]) next to the rank of every key; `order` may be null.
+EVOX_API int evox_hip_rank_sort_values(const float* keys, int n, int64_t* order, int64_t* rank_out, float* sorted_out,
+                                       int* scratch, void* stream) {
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int rows = (n + kRows - 1) / kRows;
+  int slices = 2 * evox::kNumCU / rows;
+  slices = slices < 1 ? 1 : (slices > kSlices ? kSlices : slices);
+  rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices, 0, n);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, keys, sorted_out);
+  return evox::last_launch_status();
+}
+
+// Partial rank counts of the rows [row_lo, row_lo + rows_n) against all n keys: scratch[s * rows_n + i] for s below the
+// returned number of slices (at most evox_hip_rank_window_slices()); the rank of row i is their sum.  What a process
+// that owns only those rows of a larger population needs: rows_n x n compares instead of a sort of all n keys.
+// Returns the number of slices, or a negative error.
+constexpr int kWindowSlices = 8;
+EVOX_API int evox_hip_rank_window_slices() { return kWindowSlices; }
+
+EVOX_API int evox_hip_rank_window_count(const float* keys, int n, int row_lo, int rows_n, int* scratch, void* stream) {
+  if (n <= 0 || rows_n <= 0 || row_lo < 0 || row_lo + rows_n > n || (row_lo & 3)) return -(int)hipErrorInvalidValue;
+  const int rows = (rows_n + kRows - 1) / kRows;
+  int slices = 4 * evox::kNumCU / rows;                       // about two rounds of blocks at most ...
+  slices = slices > n / 2048 ? n / 2048 : slices;            // ... of at least 2048 keys each
+  slices = slices < 1 ? 1 : (slices > kWindowSlices ? kWindowSlices : slices);
+  rank_count_kernel<<<dim3(rows, slices), kThreads, 0, (hipStream_t)stream>>>(keys, n, scratch, slices, row_lo, rows_n);
+  const int st = evox::last_launch_status();
+  return st ? -st : slices;
 }
 
 // Selection of the k smallest (or largest) of n fp32 keys without sorting them: one persistent workgroup

@@ -372,14 +372,23 @@ class CMAES(Algorithm):
                           "keep": keep, "calls": 0}
         return cache[key]
 
-    def tell_sharded(self, state, fitness, rank: int, world: int):
+    def tell_sharded(self, state, fitness, rank: int, world: int, presorted=None):
+        """``presorted`` — ``(message, own_rank)`` of :class:`~evox_amd.parallel.ShardedWorkflow`'s distributed ranking
+        (every process's fitness values next to the same values sorted, and the rank of this process's rows among
+        themselves) — spares the sort of the whole gathered fitness vector."""
         from ....core import distributed as dist
 
         local = self.pop_size // world
-        order, ranking = _sort.argsort_with_rank(fitness)
-        my_rank = ranking[rank * local:(rank + 1) * local]
         pop = state.population
         ws = None
+        native = (self._native_calls and self._bf16_kernels and pop.is_cuda and self._sqrt_w is not None)
+        presorted = presorted if native else None
+        # up to the size the counting sort takes in one pass, ranking the local rows against all keys is the whole sort
+        counted = (native and presorted is None and fitness.dtype == torch.float32 and fitness.is_contiguous()
+                   and (rank * local) % 4 == 0 and fitness.shape[0] <= 16384)
+        if not counted and presorted is None:
+            ranking = _sort.argsort_with_rank(fitness)[1]
+            my_rank = ranking[rank * local:(rank + 1) * local]
         if pop.is_cuda and self._sqrt_w is not None and (self._bf16_kernels or _cma.use_factor_form()):
             # local share of the sufficient statistics through the same kernels as the
             # single-process tell: S = sqrt(w_local)(X_local − m)/σ (zero rows for unselected
@@ -390,7 +399,7 @@ class CMAES(Algorithm):
             keep = min(consts["keep"], local)
             nn = self.dim * self.dim
             packed = torch.empty(nn + self.dim + 4, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
-            if self._native_calls and self._bf16_kernels:
+            if native:
                 # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the ranks, so that number
                 # is hypergeometric with a standard deviation of at most √local / 2: the selected rows are compacted
                 # into `keep` slots (mean + 12 standard deviations; one launch, ``ops/cma_native.py::select_local``) and
@@ -398,8 +407,16 @@ class CMAES(Algorithm):
                 # rank adds that fact to the message, and any overflow poisons the update on every rank in the same
                 # generation (and raises at the next periodic host check).
                 from ....ops import cma_native as _nat
-                local_order, sqrt_w_local = _nat.select_local(ranking, rank * local, local, self.mu, keep,
-                                                              consts["sqrt_w_padded"], packed[nn + self.dim:])
+                if presorted is not None:
+                    local_order, sqrt_w_local = _nat.presorted_select_local(presorted[0], world, rank, local, presorted[1],
+                                                                            self.mu, keep, consts["sqrt_w_padded"],
+                                                                            packed[nn + self.dim:])
+                elif counted:
+                    local_order, sqrt_w_local = _nat.rank_select_local(fitness, rank * local, local, self.mu, keep,
+                                                                       consts["sqrt_w_padded"], packed[nn + self.dim:])
+                else:
+                    local_order, sqrt_w_local = _nat.select_local(ranking, rank * local, local, self.mu, keep,
+                                                                  consts["sqrt_w_padded"], packed[nn + self.dim:])
             elif keep < local:
                 local_order = _sort.argsort(my_rank.to(torch.float32))[:keep]
                 packed[nn + self.dim:] = ((my_rank < self.mu).sum() > keep).to(torch.float32)
@@ -447,6 +464,8 @@ class CMAES(Algorithm):
             alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
             C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
         return self._finish_tell(state, mean, ps, pc, C, sigma, ws)
+
+    tell_sharded.accepts_presorted = True
 
 
 class SepCMAES(CMAES):

@@ -53,6 +53,9 @@ _native.register_hip_api({
     "evox_hip_event_destroy": (None, [P]),
     "evox_hip_cma_tell": (I, [P, P]),
     "evox_hip_cma_select_local": (I, [P, I, I, I, I, P, P, P, P, P]),
+    "evox_hip_cma_rank_select_local": (I, [P, I, I, I, I, I, P, P, P, P, P, P]),
+    "evox_hip_rank_window_slices": (I, []),
+    "evox_hip_cma_presorted_select_local": (I, [P, I, I, I, P, I, I, P, P, P, P, P, P]),
 })
 
 
@@ -68,6 +71,41 @@ def select_local(ranking: torch.Tensor, lo: int, local: int, mu: int, keep: int,
     check(hip().evox_hip_cma_select_local(ranking.data_ptr(), int(lo), int(local), int(mu), int(keep), sqrt_w_padded.data_ptr(),
                                           order.data_ptr(), w.data_ptr(), overflow_out.data_ptr(), stream_of(ranking)),
           "cma_select_local")
+    return order, w
+
+
+def presorted_select_local(msg: torch.Tensor, world: int, me: int, local: int, own_rank: torch.Tensor, mu: int, keep: int,
+                           sqrt_w_padded: torch.Tensor, overflow_out: torch.Tensor):
+    """:func:`select_local` from the pre-sorted fitness message of a row-sharded generation: ``msg`` is ``(2·world, local)``
+    fp32 — row ``2q`` the fitness of process ``q``'s rows, row ``2q + 1`` the same values in ascending order — and
+    ``own_rank`` the rank of every local row among the local rows.  The global rank of a local row is ``own_rank`` plus one
+    binary search per other process, so no process sorts more than its own rows."""
+    dev = msg.device
+    if msg.dtype != torch.float32 or not msg.is_contiguous() or tuple(msg.shape) != (2 * world, local):
+        raise ValueError(f"fitness message must be contiguous fp32 of shape {(2 * world, local)}, got {tuple(msg.shape)}")
+    order = torch.empty(keep, dtype=torch.int64, device=dev)
+    w = torch.empty(keep, dtype=torch.float32, device=dev)
+    scratch = torch.empty(local, dtype=torch.int32, device=dev)
+    check(hip().evox_hip_cma_presorted_select_local(msg.data_ptr(), int(world), int(me), int(local), own_rank.data_ptr(),
+                                                    int(mu), int(keep), sqrt_w_padded.data_ptr(), order.data_ptr(),
+                                                    w.data_ptr(), overflow_out.data_ptr(), scratch.data_ptr(),
+                                                    stream_of(msg)), "cma_presorted_select_local")
+    return order, w
+
+
+def rank_select_local(fitness: torch.Tensor, lo: int, local: int, mu: int, keep: int, sqrt_w_padded: torch.Tensor,
+                      overflow_out: torch.Tensor):
+    """:func:`select_local` straight from the fitness of the whole population (fp32, contiguous; ``lo`` a multiple of 4):
+    the ``local`` rows from ``lo`` on are ranked against all keys by counting — ``local x n`` compares, two launches in
+    all — instead of sorting the whole vector on every rank."""
+    dev = fitness.device
+    order = torch.empty(keep, dtype=torch.int64, device=dev)
+    w = torch.empty(keep, dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(hip().evox_hip_rank_window_slices()) * local, dtype=torch.int32, device=dev)
+    check(hip().evox_hip_cma_rank_select_local(fitness.data_ptr(), int(fitness.shape[0]), int(lo), int(local), int(mu), int(keep),
+                                               sqrt_w_padded.data_ptr(), order.data_ptr(), w.data_ptr(),
+                                               overflow_out.data_ptr(), scratch.data_ptr(), stream_of(fitness)),
+          "cma_rank_select_local")
     return order, w
 
 

@@ -12,7 +12,8 @@ from ._util import check, hip, stream_of
 P, I = _native.P, _native.I
 _native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]),
                           "evox_hip_rank_sort_scratch": (_native.I64, [I]),
-                          "evox_hip_rank_sort_sliced": (I, [P, I, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
+                          "evox_hip_rank_sort_sliced": (I, [P, I, P, P, P, P]),
+                          "evox_hip_rank_sort_values": (I, [P, I, P, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
                           "evox_hip_select_wide_ws": (_native.I64, [I]),
                           "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
@@ -85,6 +86,27 @@ def argsort(keys: torch.Tensor) -> torch.Tensor:
     if _rank_sortable(keys):
         return _rank_sort(keys, False)[0]
     return torch.argsort(keys, stable=True)
+
+
+def sort_with_rank(keys: torch.Tensor, out: torch.Tensor = None):
+    """``(sorted_keys, rank)``: the keys in ascending order (NaN last) and the stable rank of every key.  ``out``
+    (contiguous, same shape and dtype) receives the sorted keys."""
+    if _rank_sortable(keys) and (out is None or (out.is_contiguous() and out.dtype == keys.dtype and out.shape == keys.shape)):
+        n = keys.shape[0]
+        keys = keys.contiguous()
+        rank = torch.empty(n, dtype=torch.int64, device=keys.device)
+        out = torch.empty_like(keys) if out is None else out
+        scratch = torch.empty(int(hip().evox_hip_rank_sort_scratch(n)), dtype=torch.int32, device=keys.device)
+        check(hip().evox_hip_rank_sort_values(keys.data_ptr(), n, None, rank.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+                                              stream_of(keys)), "rank_sort_values")
+        return out, rank
+    values, order = torch.sort(keys, stable=True)
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(keys.shape[0], device=keys.device)
+    if out is not None:
+        out.copy_(values)
+        values = out
+    return values, rank
 
 
 def argsort_with_rank(keys: torch.Tensor):

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence
 
+import os
+
 import torch
 
 from ..core import distributed as dist
@@ -61,6 +63,38 @@ class ShardedWorkflow(StdWorkflow):
         self.global_fitness_transforms = list(global_fitness_transforms)
         if self.global_fitness_transforms:
             self.fitness_transforms = self.global_fitness_transforms + self.fitness_transforms
+        d = self.opt_direction
+        self._minimising = bool((d == 1).all()) if isinstance(d, torch.Tensor) else d == 1
+        self._presorted = None
+
+    # -- distributed ranking ---------------------------------------------------------------
+    # An algorithm whose ``tell_sharded`` carries ``accepts_presorted = True`` ranks the population without any process
+    # sorting more than its own rows: every process sorts its fitness values BEFORE the all-gather and sends them along
+    # (one message of 2 x local floats instead of local), and the global rank of a local row is its local rank plus one
+    # binary search per other process.  A full sort of the gathered vector on every rank — replicated work that grows
+    # with the number of processes — is what this replaces.  It needs the order of the raw fitness to be the order the
+    # algorithm sees: minimisation and no fitness transforms.
+    def _presort(self, fitness) -> bool:
+        if os.environ.get("EVOX_AMD_SHARDED_PRESORT", "1") == "0":
+            return False
+        fn = getattr(self.algorithm, "tell_sharded", None)
+        return (self.row_sharded and getattr(fn, "accepts_presorted", False) and self._minimising
+                and not self.fitness_transforms and isinstance(fitness, torch.Tensor) and fitness.is_cuda
+                and fitness.dim() == 1 and fitness.dtype == torch.float32)
+
+    def _gather_fitness(self, fitness, n_total=None, world=1):
+        self._presorted = None
+        if not self._presort(fitness):
+            return super()._gather_fitness(fitness, n_total, world)
+        from ..ops import sort as _sort
+
+        local = fitness.shape[0]
+        msg = torch.empty((2, local), dtype=torch.float32, device=fitness.device)
+        msg[0] = fitness
+        _, own_rank = _sort.sort_with_rank(fitness, out=msg[1])
+        full = dist.all_gather(msg, self.pmap_axis_name, axis=0, tiled=True) if world > 1 else msg
+        self._presorted = (full, own_rank)
+        return full.view(world, 2, local)[:, 0].reshape(-1)
 
     def _local_fields(self, alg_state) -> set:
         """Names of the row-local fields of the algorithm state: ``algorithm.sharded_fields`` plus every field whose
@@ -161,7 +195,9 @@ class ShardedWorkflow(StdWorkflow):
             tfitness = t(tfitness)
         for m in hooks["pre_tell"]:
             m.pre_tell(state, seen, tcands, fitness, tfitness)
-        state = use_state(self.algorithm.tell_sharded)(state, tfitness, rank, world)
+        extra = {} if self._presorted is None else {"presorted": self._presorted}
+        self._presorted = None
+        state = use_state(self.algorithm.tell_sharded)(state, tfitness, rank, world, **extra)
         if aux is not None:
             aux.update(cands=cands, tcands=tcands, fitness=fitness, tfitness=tfitness)
         for m in hooks["post_tell"]:

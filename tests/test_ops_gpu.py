@@ -1278,3 +1278,72 @@ def test_newton_schulz_fifth_order_step_alone(cuda):
     s, zi, s16 = b16.ns_sqrt(bad, ws, 1, prev=prev)
     assert float(scal[15]) == 1.0 and torch.equal(s, prev[0]) and torch.equal(zi, prev[1])
     assert torch.equal(s16[:, :n], prev[0].to(torch.bfloat16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lo,local,ties", [(40000, 10000, 10000, False), (80000, 70000, 10000, True), (8192, 4096, 4096, True),
+                                             (10000, 0, 10000, False)])
+def test_rank_select_local_matches_sort(n, lo, local, ties):
+    """Local rows ranked against the whole fitness vector by counting + compaction of the selected ones: the same set of
+    rows, each with the weight of its stable global rank, as a full sort gives."""
+    from evox_amd.ops import cma_native as nat
+
+    g = torch.Generator(device="cuda").manual_seed(n + lo)
+    fit = torch.randn(n, device="cuda", generator=g)
+    if ties:
+        fit = torch.round(fit * 50) / 50
+    mu = n // 2
+    w = torch.rand(mu, device="cuda", generator=g) + 0.1
+    padded = torch.cat([w, torch.zeros(n - mu, device="cuda")])
+    keep = local * 3 // 4
+    flags = torch.full((4,), 7.0, device="cuda")
+    order, sw = nat.rank_select_local(fit, lo, local, mu, keep, padded, flags)
+    ranking = torch.argsort(torch.argsort(fit, stable=True), stable=True)
+    mine = ranking[lo:lo + local]
+    sel = torch.nonzero(mine < mu).flatten()
+    assert sel.numel() <= keep and flags.tolist() == [0.0, 0.0, 0.0, 0.0]
+    assert torch.equal(order[:sel.numel()], sel)
+    assert torch.equal(sw[:sel.numel()], padded[mine[sel]])
+    assert float(sw[sel.numel():].abs().sum()) == 0.0
+    # from a ranking computed elsewhere: the same answer
+    order2, sw2 = nat.select_local(ranking, lo, local, mu, keep, padded, flags)
+    assert torch.equal(order2, order) and torch.equal(sw2, sw)
+    # too few slots: the overflow word is raised
+    small = max(1, sel.numel() // 2)
+    nat.rank_select_local(fit, lo, local, mu, small, padded, flags)
+    assert flags.tolist() == [1.0, 0.0, 0.0, 0.0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,local,ties", [(4, 10000, False), (8, 2500, True), (2, 4096, True), (1, 10000, False), (11, 700, True)])
+def test_presorted_select_local_matches_sort(world, local, ties):
+    """Distributed ranking: every process sorts its own fitness values, the global rank of a local row is its local rank
+    plus one binary search per other process — the same stable ranks as a sort of the whole vector."""
+    from evox_amd.ops import cma_native as nat, sort as _sort
+
+    n = world * local
+    g = torch.Generator(device="cuda").manual_seed(world * 100003 + local)
+    fit = torch.randn(n, device="cuda", generator=g)
+    if ties:
+        fit = torch.round(fit * 20) / 20
+        fit[::97] = float("inf")
+    msg = torch.empty(2 * world, local, device="cuda")
+    own = []
+    for q in range(world):
+        seg = fit[q * local:(q + 1) * local]
+        msg[2 * q] = seg
+        own.append(_sort.sort_with_rank(seg, out=msg[2 * q + 1])[1])
+        assert torch.equal(msg[2 * q + 1], torch.sort(seg).values)
+    ranking = torch.argsort(torch.argsort(fit, stable=True), stable=True)
+    mu = n // 2
+    w = torch.rand(mu, device="cuda", generator=g) + 0.1
+    padded = torch.cat([w, torch.zeros(n - mu, device="cuda")])
+    keep = local
+    flags = torch.zeros(4, device="cuda")
+    for me in range(world):
+        order, sw = nat.presorted_select_local(msg, world, me, local, own[me], mu, keep, padded, flags)
+        mine = ranking[me * local:(me + 1) * local]
+        sel = torch.nonzero(mine < mu).flatten()
+        assert torch.equal(order[:sel.numel()], sel), (world, me)
+        assert torch.equal(sw[:sel.numel()], padded[mine[sel]])
+        assert float(sw[sel.numel():].abs().sum()) == 0.0
