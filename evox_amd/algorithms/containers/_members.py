@@ -34,6 +34,37 @@ def member_tell(member, state, fitness, first):
     return use_state(fn)(state, fitness)
 
 
+def batch(base, times: int, concat: bool = True):
+    """``times`` copies of ``base`` as ONE algorithm whose state carries a leading block axis, or None when no batched
+    form of the algorithm exists.  Plain :class:`~evox_amd.algorithms.so.es_variants.cma_es.CMAES` (exact class, fp32,
+    eigendecomposition mode) has one: :class:`~evox_amd.algorithms.so.es_variants.batched_cma.BatchedCMAES`."""
+    from ..so.es_variants.batched_cma import BatchedCMAES
+    from ..so.es_variants.cma_es import CMAES
+
+    if type(base) is CMAES and base.decomposition == "eigh" and base.precision == "fp32":
+        return BatchedCMAES.of(base, times, concat)
+    return None
+
+
+def same_configuration(members) -> bool:
+    """True when all members are plain CMA-ES instances with identical settings (then one batched instance stands for
+    them all)."""
+    from ..so.es_variants.cma_es import CMAES
+    import torch
+
+    first = members[0]
+    if not all(type(m) is CMAES for m in members):
+        return False
+    for m in members[1:]:
+        if (m.dim, m.pop_size, m.mu, m.cm, m.decomp_per_iter, m.init_stdev, m.decomposition, m.precision) != \
+                (first.dim, first.pop_size, first.mu, first.cm, first.decomp_per_iter, first.init_stdev, first.decomposition,
+                 first.precision):
+            return False
+        if not (torch.equal(m.weights, first.weights) and torch.equal(m.center_init, first.center_init)):
+            return False
+    return True
+
+
 def widen(base, times: int):
     """One instance of ``base`` over ``times`` concatenated copies of its decision vector, or None when the algorithm
     does not declare itself separable.

