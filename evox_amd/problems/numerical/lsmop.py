@@ -17,10 +17,16 @@ from itertools import cycle
 
 import torch
 
+from ... import _native
 from ...core.problem import Problem
 from ...core.state import State
 from ...operators.sampling import UniformSampling
+from ...ops._util import check, hip, on_gpu, stream_of
 from .dtlz import _chain
+
+_native.register_hip_api({"evox_hip_mo_grouped": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.I, _native.I,
+                                                             _native.P, _native.P, _native.I, _native.I, _native.I, _native.P,
+                                                             _native.P])})
 
 
 def _sphere(x):
@@ -73,6 +79,27 @@ def grouped_g(x, m, sublen, nk, funcs):
     return torch.stack(cols, dim=1)
 
 
+_LANDSCAPE_ID = {_sphere: 0, _griewank: 1, _rosenbrock: 2, _ackley: 3, _schwefel: 4, _rastrigin: 5}
+FRONT_LINEAR, FRONT_CONCAVE, FRONT_DISCONNECTED, FRONT_INVERTED = 0, 1, 2, 3
+
+
+def fused_grouped(X, m, nk, sublen, funcs, nonlinear, front):
+    """Objectives of a grouped large-scale problem from the one-pass kernel (``csrc/mo_large.hip``: a wavefront per
+    individual, linkage, landscapes and front in one launch), or None when ``X`` is not an fp32 device matrix."""
+    import ctypes
+
+    if not on_gpu(X) or X.dtype != torch.float32 or X.dim() != 2 or m > 16 or X.shape[0] == 0 or len(funcs) > 2:
+        return None
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    out = torch.empty((X.shape[0], m), dtype=torch.float32, device=X.device)
+    lens = (ctypes.c_int * m)(*sublen)
+    ids = (ctypes.c_int * len(funcs))(*[_LANDSCAPE_ID[f] for f in funcs])
+    check(hip().evox_hip_mo_grouped(X.data_ptr(), X.stride(0), X.shape[0], X.shape[1], m, nk, lens, ids, len(funcs),
+                                    int(bool(nonlinear)), front, out.data_ptr(), stream_of(X)), "mo_grouped")
+    return out
+
+
 def _dtlz7_front(n, m, dtype=torch.float32):
     lo1, hi1, lo2, hi2 = 0.0, 0.251412, 0.631627, 0.859401
     median = (hi1 - lo1) / (hi2 - lo2 + hi1 - lo1)
@@ -112,7 +139,16 @@ class LSMOP(Problem):
     def _g(self, X):
         return grouped_g(X, self.m, self.sublen, self.nk, self.funcs)
 
+    def _fused(self, X, front):
+        # only the stock classes: a subclass may override the linkage or the landscapes
+        if type(self) not in _STOCK or X.shape[1] != self.d:
+            return None
+        return fused_grouped(X, self.m, self.nk, self.sublen, self.funcs, self.nonlinear_linkage, front)
+
     def evaluate(self, state, X):
+        f = self._fused(X, FRONT_CONCAVE if self.nonlinear_linkage else FRONT_LINEAR)
+        if f is not None:
+            return f, state
         X = self._link(X)
         g = self._g(X)
         pos = X[:, : self.m - 1]
@@ -174,6 +210,9 @@ class LSMOP9(LSMOP):
     nonlinear_linkage = True
 
     def evaluate(self, state, X):
+        f = self._fused(X, FRONT_DISCONNECTED)
+        if f is not None:
+            return f, state
         m = self.m
         X = self._link(X)
         g = 1 + self._g(X).sum(1, keepdim=True)
@@ -183,3 +222,6 @@ class LSMOP9(LSMOP):
 
     def pf(self):
         return _dtlz7_front(self.ref_num * self.m, self.m)
+
+
+_STOCK = {LSMOP1, LSMOP2, LSMOP3, LSMOP4, LSMOP5, LSMOP6, LSMOP7, LSMOP8, LSMOP9}

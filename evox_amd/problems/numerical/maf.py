@@ -14,13 +14,35 @@ import math
 
 import torch
 
+from ... import _native
 from ...core.problem import Problem
 from ...core.state import State
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...ops.distance import cdist as _cdist
+from ...ops._util import check, hip, on_gpu, stream_of
 from .dtlz import _chain, _multimodal_g
-from .lsmop import _dtlz7_front, _griewank, _rastrigin, _rosenbrock, _sphere, chaotic_group_sizes, grouped_g
+from .lsmop import (FRONT_INVERTED, FRONT_LINEAR, _dtlz7_front, _griewank, _rastrigin, _rosenbrock, _sphere,
+                    chaotic_group_sizes, fused_grouped, grouped_g)
+
+_native.register_hip_api({"evox_hip_maf": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.I, _native.I,
+                                                      _native.P, _native.P])})
+_KIND = {}        # stock class -> variant of the one-pass kernel (``csrc/mo_large.hip``); filled at the end of the module
+
+
+def _fused(problem, X):
+    """Objectives of MaF1-7 / MaF13 from the one-pass kernel when ``problem`` is a stock class and ``X`` an fp32 device
+    matrix; None otherwise (subclasses that override pieces use the tensor formulation)."""
+    kind = _KIND.get(type(problem))
+    if kind is None or not on_gpu(X) or X.dtype != torch.float32 or X.dim() != 2 or problem.m > 16 \
+            or X.shape[1] < max(problem.m, 2) or X.shape[0] == 0:
+        return None
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    out = torch.empty((X.shape[0], problem.m), dtype=torch.float32, device=X.device)
+    check(hip().evox_hip_maf(X.data_ptr(), X.stride(0), X.shape[0], X.shape[1], problem.m, kind, out.data_ptr(),
+                             stream_of(X)), "maf")
+    return out
 
 
 # ------------------------------------------------------------------ polygon helpers (MaF8/9)
@@ -142,6 +164,9 @@ class MaF1(MaF):
     """Inverted linear front."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = ((X[:, m - 1:] - 0.5) ** 2).sum(1, keepdim=True)
         pos = X[:, : m - 1]
@@ -152,6 +177,9 @@ class MaF2(MaF):
     """DTLZ2BZ: concave front restricted to the central part, one distance function per objective."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m, d = self.m, X.shape[1]
         step = (d - m + 1) // m
         cols = []
@@ -182,6 +210,9 @@ class MaF3(MaF):
     """Convex DTLZ3."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = _multimodal_g(X[:, m - 1:])
         ang = X[:, : m - 1] * (math.pi / 2)
@@ -198,6 +229,9 @@ class MaF4(MaF):
     """Inverted, badly scaled DTLZ3."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = _multimodal_g(X[:, m - 1:])
         ang = X[:, : m - 1] * (math.pi / 2)
@@ -214,6 +248,9 @@ class MaF5(MaF):
     """Badly scaled DTLZ4 (bias α = 100)."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = ((X[:, m - 1:] - 0.5) ** 2).sum(1, keepdim=True)
         ang = X[:, : m - 1] ** 100 * (math.pi / 2)
@@ -230,6 +267,9 @@ class MaF6(MaF):
     """DTLZ5(I, M) with I = 2: a degenerate curve front."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m, i = self.m, 2
         g = ((X[:, m - 1:] - 0.5) ** 2).sum(1, keepdim=True)
         pos = X[:, : m - 1].clone()
@@ -257,6 +297,9 @@ class MaF7(MaF):
             self.d = self.m + 19
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         g = 1 + 9 * X[:, m - 1:].mean(1, keepdim=True)
         head = X[:, : m - 1]
@@ -429,6 +472,9 @@ class MaF13(MaF):
         self.m = max(self.m, 3)
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         n, d = X.shape
         j = torch.arange(1, d + 1, device=X.device, dtype=X.dtype)
         Y = X - 2 * X[:, 1:2] * torch.sin(2 * math.pi * X[:, :1] + j * math.pi / d)
@@ -464,6 +510,10 @@ class MaF14(_LargeScaleMaF):
     """LSMOP3: linear front, linear linkage, Rastrigin / Rosenbrock group landscapes."""
 
     def evaluate(self, state, X):
+        if type(self) is MaF14:
+            f = fused_grouped(X, self.m, self.nk, self.sublen, (_rastrigin, _rosenbrock), False, FRONT_LINEAR)
+            if f is not None:
+                return f, state
         m, d = self.m, X.shape[1]
         w = 1 + torch.arange(m, d + 1, device=X.device, dtype=X.dtype) / d
         X = torch.cat([X[:, : m - 1], w * X[:, m - 1:] - X[:, :1] * 10], dim=1)
@@ -479,6 +529,10 @@ class MaF15(_LargeScaleMaF):
     """Inverted LSMOP8: convex front, non-linear linkage, Griewank / sphere landscapes."""
 
     def evaluate(self, state, X):
+        if type(self) is MaF15:
+            f = fused_grouped(X, self.m, self.nk, self.sublen, (_griewank, _sphere), True, FRONT_INVERTED)
+            if f is not None:
+                return f, state
         m, d = self.m, X.shape[1]
         w = 1 + torch.cos(torch.arange(m, d + 1, device=X.device, dtype=X.dtype) / d * (math.pi / 2))
         X = torch.cat([X[:, : m - 1], w * X[:, m - 1:] - X[:, :1] * 10], dim=1)
@@ -490,3 +544,6 @@ class MaF15(_LargeScaleMaF):
     def pf(self):
         r = self._simplex()
         return 1 - r / torch.linalg.vector_norm(r, dim=1, keepdim=True)
+
+
+_KIND.update({MaF1: 1, MaF2: 2, MaF3: 3, MaF4: 4, MaF5: 5, MaF6: 6, MaF7: 7, MaF13: 13})

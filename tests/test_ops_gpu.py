@@ -1347,3 +1347,32 @@ def test_presorted_select_local_matches_sort(world, local, ties):
         assert torch.equal(order[:sel.numel()], sel), (world, me)
         assert torch.equal(sw[:sel.numel()], padded[mine[sel]])
         assert float(sw[sel.numel():].abs().sum()) == 0.0
+
+
+_GROUPED = ["LSMOP%d" % k for k in range(1, 10)] + ["MaF14", "MaF15"]
+_MAF_FUSED = ["MaF1", "MaF2", "MaF3", "MaF4", "MaF5", "MaF6", "MaF7", "MaF13"]
+
+
+@pytest.mark.parametrize("name", _GROUPED + _MAF_FUSED)
+@pytest.mark.parametrize("m", [2, 3, 5])
+def test_fused_maf_lsmop_kernels_match_tensor_formulation(cuda, name, m):
+    """One-pass evaluators (a wavefront per individual for the grouped problems) against the tensor formulation in
+    double precision, which the kernels never see: an fp64 input takes the tensor path."""
+    from evox_amd import problems
+
+    if name == "MaF13" and m < 3:
+        pytest.skip("MaF13 has at least three objectives")
+    prob = getattr(problems.numerical, name)(m=m)
+    g = torch.Generator(device="cuda").manual_seed(m * 31 + len(name))
+    x = torch.rand(517, prob.d, device=cuda, generator=g)
+    pstate = prob.setup(rnd.PRNGKey(0))
+    got, _ = prob.evaluate(pstate, x)
+    ref, _ = prob.evaluate(pstate, x.double())
+    assert got.dtype == torch.float32 and got.shape == (517, prob.m) and ref.dtype == torch.float64
+    err = (got.double() - ref).abs()
+    assert bool((err <= 5e-4 * ref.abs() + 1e-4 * float(ref.abs().max())).all()), (name, m, float(err.max()), float(ref.abs().max()))
+    # a strided view of a wider matrix is read in place
+    wide = torch.rand(517, prob.d + 3, device=cuda, generator=g)
+    got2, _ = prob.evaluate(pstate, wide[:, :prob.d])
+    ref2, _ = prob.evaluate(pstate, wide[:, :prob.d].double())
+    assert torch.allclose(got2.double(), ref2, rtol=5e-4, atol=1e-4 * float(ref2.abs().max()))
