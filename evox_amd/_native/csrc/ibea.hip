@@ -189,6 +189,58 @@ __global__ __launch_bounds__(256) void sra_indicators_kernel(const float* __rest
   }
 }
 
+// BiGE's crowding degree from the normalised objective vectors, without the n x n distance and sharing matrices:
+//   cd_j = sqrt( Σ_{i ≠ j, d_ij < r} ( 0.5 · (1 + [pr_j >= pr_i] + [pr_j > pr_i]) · (1 − d_ij / r) )² ),
+// d_ij the Euclidean distance, pr the proximity (sum of the normalised objectives), r the niche radius (read from the
+// device: it depends on the size of the front being ranked).
+template <int M>
+__global__ __launch_bounds__(256) void bige_crowding_kernel(const float* __restrict__ f, const float* __restrict__ pr, int n,
+                                                            const float* __restrict__ radius, float* __restrict__ cd) {
+  __shared__ float tile[M + 1][256];
+  __shared__ float part[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + r;
+  const float rad = *radius, inv_rad = 1.f / rad;
+  float mine[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) mine[k] = j < n ? f[(int64_t)j * M + k] : 0.f;
+  const float pj = j < n ? pr[j] : 0.f;
+  float acc = 0.f;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? f[(int64_t)ii * M + k] : 0.f;
+    tile[M][threadIdx.x] = ii < n ? pr[ii] : 0.f;
+    __syncthreads();
+    const int lim = min(64, n - i0 - s * 64);
+    for (int q = 0; q < lim; ++q) {
+      const int c = s * 64 + q;
+      float d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const float d = tile[k][c] - mine[k];
+        d2 = fmaf(d, d, d2);
+      }
+      const float d = sqrtf(d2);
+      if (d < rad && i0 + c != j) {
+        const float pi = tile[M][c];
+        const float w = 0.5f * (1.f + (float)(pj >= pi) + (float)(pj > pi)) * (1.f - d * inv_rad);
+        acc = fmaf(w, w, acc);
+      }
+    }
+  }
+  part[s][r] = acc;
+  __syncthreads();
+  if (s == 0 && j < n) cd[j] = sqrtf(fmaxf(acc + part[1][r] + part[2][r] + part[3][r], 0.f));
+}
+
+template <int M>
+int launch_bige(const float* f, const float* pr, int n, const float* radius, float* cd, hipStream_t st) {
+  bige_crowding_kernel<M><<<(n + 63) / 64, 256, 0, st>>>(f, pr, n, radius, cd);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_sra(const float* obj, int n, int lower, float* I1, float* I2, hipStream_t st) {
   const int blocks = (n + 63) / 64;
@@ -253,6 +305,12 @@ EVOX_API int evox_hip_ibea_fitness(const float* obj, int n, int m, float kappa, 
 EVOX_API int evox_hip_sra_indicators(const float* obj, int n, int m, int lower, float* I1, float* I2, void* stream) {
   if (n <= 0) return 0;
   EVOX_IBEA_DISPATCH(launch_sra, obj, n, lower, I1, I2, (hipStream_t)stream)
+}
+
+// f: (n, m) normalised objectives, pr: (n) proximity, radius: one float on the device.  cd: out (n).
+EVOX_API int evox_hip_bige_crowding(const float* f, const float* pr, int n, int m, const float* radius, float* cd, void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_bige, f, pr, n, radius, cd, (hipStream_t)stream)
 }
 
 // Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix

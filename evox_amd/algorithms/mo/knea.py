@@ -9,6 +9,7 @@ from ...core.state import State
 from ...operators import selection
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
+from ...ops import moselect as _sel
 from ...ops.distance import cdist as _cdist
 from ...ops.linalg_small import solve_small
 from ...utils.common import cos_dist
@@ -18,7 +19,7 @@ from .common import MOAlgorithm
 def calc_DW(fit, k):
     """Weighted distance to the k nearest neighbours (KnEA's density estimate)."""
     dis = _cdist(fit, fit)
-    nb = torch.sort(dis, dim=1).values[:, 1:k + 1]
+    nb = torch.topk(dis, k + 1, dim=1, largest=False, sorted=True).values[:, 1:]        # the k nearest, self excluded
     avg = nb.sum(1) / k
     r = 1 / (nb - avg[:, None]).abs().clamp_min(1e-12)
     w = r / r.sum(1, keepdim=True)
@@ -120,11 +121,7 @@ def bige_estimate(fit, mask):
     normed = (fit - f_min) / (f_max - f_min).clamp_min(1e-6)
     normed = torch.where(mask[:, None], normed, torch.full_like(normed, float(m)))
     pr = normed.sum(1)
-    dis = _cdist(normed, normed)
-    ge = (pr[:, None] >= pr[None, :]).to(torch.float32)
-    gt = (pr[:, None] > pr[None, :]).to(torch.float32)
-    sh = ((dis < r) * 0.5 * ((1 + ge + gt) * (1 - dis / r))) ** 2
-    cd = torch.sqrt((sh.sum(1) - torch.diagonal(sh)).clamp_min(0))
+    cd = _sel.bige_crowding(normed, pr, r)             # streaming kernel on the GPU: no n × n matrices
     bi = torch.stack([pr, cd], dim=1)
     return torch.where(mask[:, None], bi, torch.full_like(bi, float("inf")))
 

@@ -66,6 +66,9 @@ class SRA(MOAlgorithm):
 def sde_fitness(obj):
     f_min, f_max = obj.amin(0), obj.amax(0)
     f = (obj - f_min) / (f_max - f_min)
+    if f.is_cuda and 2 <= f.shape[1] <= 8 and f.dtype == torch.float32:
+        # the shift-based density is SRA's second indicator: streamed from the objective vectors, no n × n matrix
+        return _sel.sra_indicators(f, lower_only=False)[1]
     d = shifted_distance_matrix(f)
     d = d.masked_fill(torch.eye(f.shape[0], dtype=torch.bool, device=f.device), float("inf"))
     return d.amin(1)

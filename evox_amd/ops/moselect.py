@@ -28,6 +28,7 @@ _native.register_hip_api({
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
     "evox_hip_ibea_remove_obj_max": (I64, [I]),
     "evox_hip_sra_indicators": (I, [P, I, I, I, P, P, P]),
+    "evox_hip_bige_crowding": (I, [P, P, I, I, P, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
 })
 
@@ -224,6 +225,26 @@ def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
     else:
         _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
     return rank
+
+
+def bige_crowding(normed: torch.Tensor, pr: torch.Tensor, radius: torch.Tensor) -> torch.Tensor:
+    """BiGE's crowding degree (sharing function over a niche of radius ``radius``, a 0-d tensor) from the normalised
+    objectives ``normed`` (n, m) and the proximity ``pr`` (n), without the n × n distance and sharing matrices
+    (``csrc/ibea.hip``).  Reference: ``algorithms/mo/bige.py:26-60``."""
+    n, m = normed.shape
+    if on_gpu(normed) and 2 <= m <= 8 and normed.dtype == torch.float32:
+        f, p = normed.contiguous(), pr.contiguous().to(torch.float32)
+        rad = radius.reshape(1).to(torch.float32).contiguous()
+        cd = torch.empty(n, dtype=torch.float32, device=normed.device)
+        check(hip().evox_hip_bige_crowding(f.data_ptr(), p.data_ptr(), n, m, rad.data_ptr(), cd.data_ptr(), stream_of(f)),
+              "bige_crowding")
+        return cd
+    from .distance import cdist as _cdist
+    dis = _cdist(normed, normed)
+    ge = (pr[:, None] >= pr[None, :]).to(torch.float32)
+    gt = (pr[:, None] > pr[None, :]).to(torch.float32)
+    sh = ((dis < radius) * 0.5 * ((1 + ge + gt) * (1 - dis / radius))) ** 2
+    return torch.sqrt((sh.sum(1) - torch.diagonal(sh)).clamp_min(0))
 
 
 def sra_indicators(obj: torch.Tensor, lower_only: bool = False):

@@ -1376,3 +1376,33 @@ def test_fused_maf_lsmop_kernels_match_tensor_formulation(cuda, name, m):
     got2, _ = prob.evaluate(pstate, wide[:, :prob.d])
     ref2, _ = prob.evaluate(pstate, wide[:, :prob.d].double())
     assert torch.allclose(got2.double(), ref2, rtol=5e-4, atol=1e-4 * float(ref2.abs().max()))
+
+
+@pytest.mark.parametrize("n,m", [(1500, 3), (333, 2), (2048, 5)])
+def test_bige_crowding_kernel_matches_matrix_formulation(cuda, n, m):
+    from evox_amd.ops import moselect as sel
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    f = torch.rand(n, m, device=cuda, generator=g)
+    f[::7] = f[1::7][: f[::7].shape[0]]                         # duplicates: distance zero, equal proximity
+    pr = f.sum(1)
+    radius = torch.tensor(1.0 / n ** (1.0 / m), device=cuda) * 3
+    got = sel.bige_crowding(f, pr, radius)
+    fd, pd, rd = f.double(), pr.double(), radius.double()
+    dis = torch.cdist(fd, fd)
+    dis = torch.where(dis < 1e-12, torch.zeros_like(dis), dis)
+    ge, gt = (pd[:, None] >= pd[None, :]).double(), (pd[:, None] > pd[None, :]).double()
+    sh = ((dis < rd) * 0.5 * ((1 + ge + gt) * (1 - dis / rd))) ** 2
+    ref = torch.sqrt((sh.sum(1) - torch.diagonal(sh)).clamp_min(0))
+    assert torch.allclose(got.double(), ref, rtol=1e-3, atol=1e-3), float((got.double() - ref).abs().max())
+
+
+def test_lmocso_density_streams_the_shifted_distances(cuda):
+    from evox_amd.algorithms.mo.sra import sde_fitness, shifted_distance_matrix
+
+    obj = torch.rand(700, 3, device=cuda) * torch.tensor([1.0, 5.0, 0.2], device=cuda)
+    got = sde_fitness(obj)
+    f = (obj - obj.amin(0)) / (obj.amax(0) - obj.amin(0))
+    d = shifted_distance_matrix(f.cpu())
+    d.fill_diagonal_(float("inf"))
+    assert torch.allclose(got.cpu(), d.amin(1), rtol=1e-5, atol=1e-6)
