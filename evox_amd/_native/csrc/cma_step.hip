@@ -106,10 +106,6 @@ __global__ __launch_bounds__(256) void cov_from_gram_kernel(const float* __restr
   }
 }
 
-// Row-sharded selection: of this rank's rows [lo, lo + local) those whose global rank is below mu are compacted, in row
-// order, into `keep` slots (row index relative to lo, and the square root of the recombination weight of its rank); the
-// unused slots get weight zero.  More than `keep` selected rows cannot be held: the count of such ranks is what
-// `overflow[0]` carries into the all-reduced message (overflow[1..3] are cleared).  One workgroup: per-thread counts, one block scan, ordered write-out.
 // Order-preserving unsigned image of an fp32 key, the one the counting sort ranks by (-0 = +0, NaN after +inf).
 __device__ __forceinline__ uint32_t sortable_key(float f) {
   uint32_t u = __float_as_uint(f);
@@ -168,36 +164,45 @@ __device__ __forceinline__ int local_rank(const int64_t* ranking, const int* par
   return r;
 }
 
+// Row-sharded selection: of this rank's rows [lo, lo + local) those whose global rank is below mu are compacted, in row
+// order, into `keep` slots (row index relative to lo, and the square root of the recombination weight of its rank); the
+// unused slots get weight zero.  More than `keep` selected rows cannot be held: the count of such ranks is what
+// `overflow[0]` carries into the all-reduced message (overflow[1..3] are cleared).
 __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __restrict__ ranking, const int* __restrict__ partial,
                                                             int slices, int lo, int local, int mu,
                                                             int keep, const float* __restrict__ sqrt_w_padded,
                                                             int64_t* __restrict__ order_out, float* __restrict__ w_out,
                                                             float* __restrict__ overflow) {
-  __shared__ int s_cnt[1024];
-  const int t = threadIdx.x;
-  const int per = (local + 1023) / 1024;
-  const int first = t * per, last = min(first + per, local);
-  int c = 0;
-  for (int i = first; i < last; ++i) c += local_rank(ranking, partial, slices, lo, local, i) < mu;
-  s_cnt[t] = c;
+  // wavefront w owns the rows [w·per, (w+1)·per): 64 consecutive rows per step (coalesced), selected rows counted and
+  // placed with ballots; one barrier for the offsets of the sixteen wavefronts
+  __shared__ int s_tot[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = ((local + 15) / 16 + 63) / 64 * 64;
+  const int first = min(w * per, local), last = min(first + per, local);
+  int cnt = 0;
+  for (int i0 = first; i0 < last; i0 += 64) {
+    const int i = i0 + lane;
+    const bool sel = i < last && local_rank(ranking, partial, slices, lo, local, i) < mu;
+    cnt += __popcll(__ballot(sel));
+  }
+  if (lane == 0) s_tot[w] = cnt;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {            // inclusive scan
-    const int v = t >= off ? s_cnt[t - off] : 0;
-    __syncthreads();
-    s_cnt[t] += v;
-    __syncthreads();
+  int pos = 0, total = 0;
+  for (int q = 0; q < 16; ++q) {
+    if (q < w) pos += s_tot[q];
+    total += s_tot[q];
   }
-  int pos = s_cnt[t] - c;
-  const int total = s_cnt[1023];
-  for (int i = first; i < last; ++i) {
-    const int r = local_rank(ranking, partial, slices, lo, local, i);
-    if (r < mu) {
-      if (pos < keep) { order_out[pos] = i; w_out[pos] = sqrt_w_padded[r]; }
-      ++pos;
-    }
+  for (int i0 = first; i0 < last; i0 += 64) {
+    const int i = i0 + lane;
+    const int r = i < last ? local_rank(ranking, partial, slices, lo, local, i) : mu;
+    const bool sel = r < mu;
+    const unsigned long long m = __ballot(sel);
+    const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+    if (sel && at < keep) { order_out[at] = i; w_out[at] = sqrt_w_padded[r]; }
+    pos += __popcll(m);
   }
-  for (int k = total + t; k < keep; k += 1024) { order_out[k] = 0; w_out[k] = 0.f; }
-  if (t < 4) overflow[t] = (t == 0 && total > keep) ? 1.f : 0.f;       // the message's four trailing floats
+  for (int k = total + (int)threadIdx.x; k < keep; k += 1024) { order_out[k] = 0; w_out[k] = 0.f; }
+  if (threadIdx.x < 4) overflow[threadIdx.x] = (threadIdx.x == 0 && total > keep) ? 1.f : 0.f;   // the message's four trailing floats
 }
 
 }  // namespace

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(kThreads) void rank_count_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const int* __restrict__ partial, int n, int64_t* __restrict__ order,
                                                            int64_t* __restrict__ rank_out, int slices,
-                                                           const float* __restrict__ keys, float* __restrict__ sorted_out) {
+                                                           const float* __restrict__ keys, float* __restrict__ sorted_out,
+                                                           float* __restrict__ keys_copy) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   int r = 0;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const int* __restrict
   if (order) order[r] = i;
   if (rank_out) rank_out[i] = r;
   if (sorted_out) sorted_out[r] = keys[i];
+  if (keys_copy) keys_copy[i] = keys[i];
 }
 
 }  // namespace
@@ -170,20 +172,21 @@ EVOX_API int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order,
   int slices = 2 * evox::kNumCU / rows;
   slices = slices < 1 ? 1 : (slices > kSlices ? kSlices : slices);
   rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices, 0, n);
-  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, nullptr, nullptr);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, nullptr, nullptr, nullptr);
   return evox::last_launch_status();
 }
 
-// The sorted keys themselves (sorted_out[rank[i]] = keys[i]) next to the rank of every key; `order` may be null.
+// The sorted keys themselves (sorted_out[rank[i]] = keys[i]) next to the rank of every key; `order` and `keys_copy`
+// (an unsorted copy of the keys, e.g. the other half of a message) may be null.
 EVOX_API int evox_hip_rank_sort_values(const float* keys, int n, int64_t* order, int64_t* rank_out, float* sorted_out,
-                                       int* scratch, void* stream) {
+                                       float* keys_copy, int* scratch, void* stream) {
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const int rows = (n + kRows - 1) / kRows;
   int slices = 2 * evox::kNumCU / rows;
   slices = slices < 1 ? 1 : (slices > kSlices ? kSlices : slices);
   rank_count_kernel<<<dim3(rows, slices), kThreads, 0, st>>>(keys, n, scratch, slices, 0, n);
-  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, keys, sorted_out);
+  rank_scatter_kernel<<<(n + 255) / 256, 256, 0, st>>>(scratch, n, order, rank_out, slices, keys, sorted_out, keys_copy);
   return evox::last_launch_status();
 }
 

@@ -428,7 +428,7 @@ class CMAES(Algorithm):
             gram_out = packed[:nn].view(self.dim, self.dim)
             if self._bf16_kernels:
                 ws = self._workspace(local, keep)
-                packed[nn:nn + self.dim] = _b16.elite_factor_t(pop, local_order, state.mean, state.sigma, sqrt_w_local, ws)
+                _b16.elite_factor_t(pop, local_order, state.mean, state.sigma, sqrt_w_local, ws, out=packed[nn:nn + self.dim])
                 _b16.gram(ws, gram_out)
             else:
                 S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)

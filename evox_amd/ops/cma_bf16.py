@@ -161,9 +161,10 @@ def sample(key, mean, sigma, S_bf16, pop_size: int, ws: Workspace, row_offset: i
     return out
 
 
-def elite_factor_t(pop, order, mean, sigma, rowscale, ws: Workspace):
+def elite_factor_t(pop, order, mean, sigma, rowscale, ws: Workspace, out=None):
     """Writes ``ws.Yt[c, i] = rowscale[i]·(pop[order[i], c] − mean[c])/σ`` for ``i < len(rowscale)`` and returns the
-    weighted mean shift ``Σ rowscale[i]²·(pop[order[i]] − mean)`` (fp32, fixed summation order)."""
+    weighted mean shift ``Σ rowscale[i]²·(pop[order[i]] − mean)`` (fp32, fixed summation order; into ``out``, a
+    contiguous fp32 vector of n elements, when given)."""
     mu, n = rowscale.shape[0], mean.shape[0]
     if mu != ws.mu or n != ws.n:
         raise ValueError("elite_factor_t: operands do not match the workspace")
@@ -174,7 +175,9 @@ def elite_factor_t(pop, order, mean, sigma, rowscale, ws: Workspace):
     if order.shape[0] < mu:
         raise ValueError("order is shorter than the number of selected rows")
     sig = sigma.reshape(1) if isinstance(sigma, torch.Tensor) else torch.tensor([float(sigma)], device=mean.device)
-    step = torch.empty(n, dtype=torch.float32, device=mean.device)
+    if out is not None and not (out.dtype == torch.float32 and out.is_contiguous() and out.shape == (n,)):
+        raise ValueError("elite_factor_t: out must be a contiguous fp32 vector of n elements")
+    step = torch.empty(n, dtype=torch.float32, device=mean.device) if out is None else out
     check(hip().evox_hip_cma_gather_t(pop.data_ptr(), pop.stride(0), order.contiguous().data_ptr(), mean.contiguous().data_ptr(),
                                       rowscale.contiguous().data_ptr(), sig.data_ptr(), ws.Yt.data_ptr(), ws.ldmu,
                                       ws.colsum.data_ptr(), ws.rb, step.data_ptr(), mu, n, pop.shape[0], stream_of(pop)),

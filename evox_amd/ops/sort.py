@@ -13,7 +13,7 @@ P, I = _native.P, _native.I
 _native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]),
                           "evox_hip_rank_sort_scratch": (_native.I64, [I]),
                           "evox_hip_rank_sort_sliced": (I, [P, I, P, P, P, P]),
-                          "evox_hip_rank_sort_values": (I, [P, I, P, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
+                          "evox_hip_rank_sort_values": (I, [P, I, P, P, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
                           "evox_hip_select_wide_ws": (_native.I64, [I]),
                           "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
@@ -88,16 +88,20 @@ def argsort(keys: torch.Tensor) -> torch.Tensor:
     return torch.argsort(keys, stable=True)
 
 
-def sort_with_rank(keys: torch.Tensor, out: torch.Tensor = None):
+def sort_with_rank(keys: torch.Tensor, out: torch.Tensor = None, copy_out: torch.Tensor = None):
     """``(sorted_keys, rank)``: the keys in ascending order (NaN last) and the stable rank of every key.  ``out``
-    (contiguous, same shape and dtype) receives the sorted keys."""
-    if _rank_sortable(keys) and (out is None or (out.is_contiguous() and out.dtype == keys.dtype and out.shape == keys.shape)):
+    (contiguous, same shape and dtype) receives the sorted keys, ``copy_out`` (likewise) an unsorted copy of the keys."""
+    def fits(t):
+        return t is None or (t.is_contiguous() and t.dtype == keys.dtype and t.shape == keys.shape)
+
+    if _rank_sortable(keys) and fits(out) and fits(copy_out):
         n = keys.shape[0]
         keys = keys.contiguous()
         rank = torch.empty(n, dtype=torch.int64, device=keys.device)
         out = torch.empty_like(keys) if out is None else out
         scratch = torch.empty(int(hip().evox_hip_rank_sort_scratch(n)), dtype=torch.int32, device=keys.device)
-        check(hip().evox_hip_rank_sort_values(keys.data_ptr(), n, None, rank.data_ptr(), out.data_ptr(), scratch.data_ptr(),
+        check(hip().evox_hip_rank_sort_values(keys.data_ptr(), n, None, rank.data_ptr(), out.data_ptr(),
+                                              copy_out.data_ptr() if copy_out is not None else None, scratch.data_ptr(),
                                               stream_of(keys)), "rank_sort_values")
         return out, rank
     values, order = torch.sort(keys, stable=True)
@@ -106,6 +110,8 @@ def sort_with_rank(keys: torch.Tensor, out: torch.Tensor = None):
     if out is not None:
         out.copy_(values)
         values = out
+    if copy_out is not None:
+        copy_out.copy_(keys)
     return values, rank
 
 

@@ -90,8 +90,7 @@ class ShardedWorkflow(StdWorkflow):
 
         local = fitness.shape[0]
         msg = torch.empty((2, local), dtype=torch.float32, device=fitness.device)
-        msg[0] = fitness
-        _, own_rank = _sort.sort_with_rank(fitness, out=msg[1])
+        _, own_rank = _sort.sort_with_rank(fitness, out=msg[1], copy_out=msg[0])
         full = dist.all_gather(msg, self.pmap_axis_name, axis=0, tiled=True) if world > 1 else msg
         self._presorted = (full, own_rank)
         return full.view(world, 2, local)[:, 0].reshape(-1)

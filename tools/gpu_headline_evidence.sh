@@ -9,12 +9,17 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 200 python bench.py --steps 1000 --warmup 50 > $out/bench_1000.json
 timeout -k 10 200 python bench.py > $out/bench_default.json
 timeout -k 10 200 python bench.py --precision fp32 > $out/bench_fp32.json
+timeout -k 10 200 python bench.py --force-sharded --steps 1000 --warmup 50 > $out/bench_sharded_world1.json
 [ -x tools/bin/gemm_check ] && timeout -k 10 120 tools/bin/gemm_check > $out/gemm_check.txt 2>&1 || true
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 20 > $out/stats_stdout.log 2>&1
 f=$(find $out/stats -name '*kernel_stats.csv' | head -1)
 head -40 "$f" > $out/kernel_stats_bf16.csv
 find $out/stats -name '*kernel_trace.csv' -delete
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_sharded -- python3 $GRAFT_REPO_ROOT/bench.py --force-sharded --steps 200 --warmup 20 > $out/stats_sharded_stdout.log 2>&1
+f=$(find $out/stats_sharded -name '*kernel_stats.csv' | head -1)
+head -40 "$f" > $out/kernel_stats_bf16_sharded_world1.csv
+find $out/stats_sharded -name '*kernel_trace.csv' -delete
 pmc() {
   name=$1; shift
   mkdir -p $out/pmc_$name
