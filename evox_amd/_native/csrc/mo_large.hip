@@ -1,5 +1,5 @@
-// One-pass evaluators of the grouped large-scale problems (LSMOP1-9, MaF14, MaF15) and of the DTLZ-shaped MaF problems
-// (MaF1-7, MaF13).
+// One-pass evaluators of the grouped large-scale problems (LSMOP1-9, MaF14, MaF15), of the DTLZ-shaped MaF problems
+// (MaF1-7, MaF13), of the WFG-based ones (MaF10-12) and of the line-distance problem MaF9.
 //
 // Grouped problems: the decision vector is m-1 position variables followed by m groups of nk sub-components; every
 // distance variable is linked to x_0 (z = w(col)·x − 10·x_0), every sub-component is put through a landscape function
@@ -242,6 +242,109 @@ __global__ __launch_bounds__(256) void maf_kernel(const float* __restrict__ x, i
   }
 }
 
+// MaF10-12 = WFG1, WFG2, WFG9 with k = m-1 position parameters: the transformation chain of the WFG toolkit
+// (shift / bias / reduction), then the shape functions; one lane per individual, the transformed vector in private
+// memory (d <= kMaxWfgDim).  kind: 10, 11, 12.
+constexpr int kMaxWfgDim = 64;
+
+__device__ __forceinline__ float s_linear(float y, float a) { return fabsf(y - a) / fabsf(floorf(a - y) + a); }
+__device__ __forceinline__ float b_flat(float y, float a, float b, float c) {
+  const float v = a + fminf(floorf(y - b), 0.f) * a * (b - y) / b - fminf(floorf(c - y), 0.f) * (1.f - a) * (y - c) / (1.f - c);
+  return rintf(v * 1e4f) / 1e4f;
+}
+__device__ __forceinline__ float s_decept(float y, float a, float b, float c) {
+  return 1.f + (fabsf(y - a) - b) * (floorf(y - a + b) * (1.f - c + (a - b) / b) / (a - b) +
+                                     floorf(a + b - y) * (1.f - c + (1.f - a - b) / b) / (1.f - a - b) + 1.f / b);
+}
+__device__ __forceinline__ float s_multi(float y, float a, float b, float c) {
+  const float t = fabsf(y - c) / 2.f / (floorf(c - y) + c);
+  return (1.f + cosf((4.f * a + 2.f) * kPi * (0.5f - t)) + 4.f * b * t * t) / (b + 2.f);
+}
+
+__global__ __launch_bounds__(256) void maf_wfg_kernel(const float* __restrict__ x, int64_t ldx, int n, int d, int m, int kind,
+                                                      float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float* r = x + (int64_t)i * ldx;
+  const int k = m - 1, l = d - k;
+  float t[kMaxWfgDim];
+  for (int j = 0; j < d; ++j) t[j] = r[j] / (float)(2 * (j + 1));
+  float red[kMaxObj];                                   // the m reduced parameters
+  if (kind == 10) {
+    for (int j = k; j < d; ++j) t[j] = b_flat(s_linear(t[j], 0.35f), 0.8f, 0.75f, 0.85f);
+    for (int j = 0; j < d; ++j) t[j] = powf(fmaxf(t[j], 0.f), 0.02f);
+    for (int j = 0; j < k; ++j) red[j] = t[j];          // one weighted element each: the weight cancels
+    float num = 0.f, den = 0.f;
+    for (int j = k; j < d; ++j) {
+      const float w = (float)(2 * (j + 1));
+      num += t[j] * w;
+      den += w;
+    }
+    red[k] = num / den;
+  } else if (kind == 11) {
+    for (int j = k; j < d; ++j) t[j] = s_linear(t[j], 0.35f);
+    const int pairs = l / 2;
+    float acc = 0.f;
+    for (int q = 0; q < pairs; ++q) {
+      const float a = t[k + 2 * q], b = t[k + 2 * q + 1];
+      acc += (a + b + 2.f * fabsf(a - b)) / 3.f;
+    }
+    for (int j = 0; j < k; ++j) red[j] = t[j];
+    red[k] = acc / (float)pairs;
+  } else {
+    // bias of every variable but the last by the mean of the variables behind it
+    float tail = 0.f;
+    for (int j = d - 1; j >= 0; --j) {
+      const float z = t[j];
+      if (j < d - 1) {
+        const float y = tail / (float)(d - 1 - j);
+        const float e = 0.02f + 49.98f * (0.98f / 49.98f - (1.f - 2.f * y) * fabsf(floorf(0.5f - y) + 0.98f / 49.98f));
+        t[j] = powf(fmaxf(z, 0.f), e);
+      }
+      tail += z;
+    }
+    for (int j = 0; j < k; ++j) red[j] = s_decept(t[j], 0.35f, 0.001f, 0.05f);
+    float sum = 0.f, pair = 0.f;
+    for (int j = k; j < d; ++j) {
+      t[j] = s_multi(t[j], 30.f, 95.f, 0.35f);
+      sum += t[j];
+    }
+    for (int a = k; a < d; ++a)
+      for (int b = a + 1; b < d; ++b) pair += fabsf(t[a] - t[b]);
+    const int half = (l + 1) / 2;
+    red[k] = (sum + 2.f * pair) / (float)half / (float)(1 + 2 * l - 2 * half);
+  }
+  // position parameters (degeneracy constants 1), shape functions, objective scales 2, 4, ...
+  float pos[kMaxObj], head[kMaxObj], tail_f[kMaxObj], scale[kMaxObj], h[kMaxObj];
+  const float last = red[k];
+  for (int j = 0; j < k; ++j) pos[j] = fmaxf(last, 1.f) * (red[j] - 0.5f) + 0.5f;
+  for (int j = 0; j < k; ++j) {
+    const float a = pos[j] * kHalfPi;
+    if (kind == 12) { head[j] = sinf(a); tail_f[j] = cosf(a); }
+    else { head[j] = 1.f - cosf(a); tail_f[j] = 1.f - sinf(a); }
+  }
+  for (int j = 0; j < m; ++j) scale[j] = 1.f;
+  chain_out(head, tail_f, scale, m, false, h);
+  if (kind == 10) h[m - 1] = 1.f - pos[0] - cosf(10.f * kPi * pos[0] + kHalfPi) / (10.f * kPi);
+  if (kind == 11) { const float c = cosf(5.f * kPi * pos[0]); h[m - 1] = 1.f - pos[0] * c * c; }
+  float* o = out + (int64_t)i * m;
+  for (int j = 0; j < m; ++j) o[j] = last + (float)(2 * (j + 1)) * h[j];
+}
+
+// MaF9: objective j = distance of the point (x_0, x_1) to the line through the polygon vertices j and j+1.
+__global__ __launch_bounds__(256) void maf9_kernel(const float* __restrict__ x, int64_t ldx, int n, int m,
+                                                   const float* __restrict__ points, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = x[(int64_t)i * ldx], py = x[(int64_t)i * ldx + 1];
+  for (int j = 0; j < m; ++j) {
+    const int jn = j + 1 < m ? j + 1 : 0;
+    const float ax = points[2 * j], ay = points[2 * j + 1], bx = points[2 * jn], by = points[2 * jn + 1];
+    const float num = fabsf((ax - px) * (by - py) - (bx - px) * (ay - py));
+    out[(int64_t)i * m + j] = num / sqrtf((ax - bx) * (ax - bx) + (ay - by) * (ay - by));
+  }
+}
+
 }  // namespace
 
 // sublen: m ints (sub-component length of every group); funcs: nfuncs (1 or 2) landscape ids, group i uses funcs[i % nfuncs]
@@ -266,7 +369,21 @@ EVOX_API int evox_hip_mo_grouped(const float* x, int64_t ldx, int n, int d, int 
   return evox::last_launch_status();
 }
 
+// MaF9: points = m x 2 polygon vertices (device).
+EVOX_API int evox_hip_maf9(const float* x, int64_t ldx, int n, int m, const float* points, float* out, void* stream) {
+  if (n <= 0 || m < 2 || m > 64) return (int)hipErrorInvalidValue;
+  maf9_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, ldx, n, m, points, out);
+  return evox::last_launch_status();
+}
+
 EVOX_API int evox_hip_maf(const float* x, int64_t ldx, int n, int d, int m, int kind, float* out, void* stream) {
+  if (kind >= 10 && kind <= 12) {
+    // k = m-1 position parameters and at least one (WFG2: an even number of) distance parameters
+    if (n <= 0 || m < 2 || m > kMaxObj || d > kMaxWfgDim || d < m || (kind == 11 && ((d - m + 1) & 1)))
+      return (int)hipErrorInvalidValue;
+    maf_wfg_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, ldx, n, d, m, kind, out);
+    return evox::last_launch_status();
+  }
   const bool known = (kind >= 1 && kind <= 7) || kind == 13;
   if (n <= 0 || !known || m < (kind == 13 ? 3 : 2) || m > kMaxObj || d < m || (kind == 13 && d < 2))
     return (int)hipErrorInvalidValue;

@@ -27,6 +27,8 @@ from .lsmop import (FRONT_INVERTED, FRONT_LINEAR, _dtlz7_front, _griewank, _rast
 
 _native.register_hip_api({"evox_hip_maf": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.I, _native.I,
                                                       _native.P, _native.P])})
+_native.register_hip_api({"evox_hip_maf9": (_native.I, [_native.P, _native.I64, _native.I, _native.I, _native.P, _native.P,
+                                                       _native.P])})
 _KIND = {}        # stock class -> variant of the one-pass kernel (``csrc/mo_large.hip``); filled at the end of the module
 
 
@@ -36,6 +38,8 @@ def _fused(problem, X):
     kind = _KIND.get(type(problem))
     if kind is None or not on_gpu(X) or X.dtype != torch.float32 or X.dim() != 2 or problem.m > 16 \
             or X.shape[1] < max(problem.m, 2) or X.shape[0] == 0:
+        return None
+    if kind in (10, 11, 12) and (X.shape[1] > 64 or (kind == 11 and (X.shape[1] - problem.m + 1) % 2)):
         return None
     if X.stride(1) != 1:
         X = X.contiguous()
@@ -344,6 +348,13 @@ class MaF9(MaF8):
         return num / torch.linalg.vector_norm(a - b, dim=1)
 
     def evaluate(self, state, X):
+        if type(self) is MaF9 and on_gpu(X) and X.dtype == torch.float32 and X.dim() == 2 and X.shape[0] > 0:
+            Xc = X if X.stride(1) == 1 else X.contiguous()
+            pts = self.points.to(X.device, torch.float32).contiguous()
+            out = torch.empty((X.shape[0], self.m), dtype=torch.float32, device=X.device)
+            check(hip().evox_hip_maf9(Xc.data_ptr(), Xc.stride(0), Xc.shape[0], self.m, pts.data_ptr(), out.data_ptr(),
+                                      stream_of(Xc)), "maf9")
+            return out, state
         return self._lines(X), state
 
     def pf(self):
@@ -391,6 +402,9 @@ class MaF10(_WFG):
     """WFG1: polynomial bias and flat region, mixed convex front."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         z, k, l = self._split(X)
         t = torch.cat([z[:, :k], s_linear(z[:, k:], 0.35)], dim=1)
@@ -416,6 +430,9 @@ class MaF11(_WFG):
         self.d = int(math.ceil((self.d - self.m + 1) / 2) * 2 + self.m - 1)
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         z, k, l = self._split(X)
         t = torch.cat([z[:, :k], s_linear(z[:, k:], 0.35)], dim=1)
@@ -440,6 +457,9 @@ class MaF12(_WFG):
     reductions, concave front."""
 
     def evaluate(self, state, X):
+        f = _fused(self, X)
+        if f is not None:
+            return f, state
         m = self.m
         z, k, l = self._split(X)
         n_var = k + l
@@ -546,4 +566,4 @@ class MaF15(_LargeScaleMaF):
         return 1 - r / torch.linalg.vector_norm(r, dim=1, keepdim=True)
 
 
-_KIND.update({MaF1: 1, MaF2: 2, MaF3: 3, MaF4: 4, MaF5: 5, MaF6: 6, MaF7: 7, MaF13: 13})
+_KIND.update({MaF1: 1, MaF2: 2, MaF3: 3, MaF4: 4, MaF5: 5, MaF6: 6, MaF7: 7, MaF10: 10, MaF11: 11, MaF12: 12, MaF13: 13})

@@ -1350,7 +1350,7 @@ def test_presorted_select_local_matches_sort(world, local, ties):
 
 
 _GROUPED = ["LSMOP%d" % k for k in range(1, 10)] + ["MaF14", "MaF15"]
-_MAF_FUSED = ["MaF1", "MaF2", "MaF3", "MaF4", "MaF5", "MaF6", "MaF7", "MaF13"]
+_MAF_FUSED = ["MaF1", "MaF2", "MaF3", "MaF4", "MaF5", "MaF6", "MaF7", "MaF9", "MaF10", "MaF11", "MaF12", "MaF13"]
 
 
 @pytest.mark.parametrize("name", _GROUPED + _MAF_FUSED)
@@ -1365,17 +1365,35 @@ def test_fused_maf_lsmop_kernels_match_tensor_formulation(cuda, name, m):
     prob = getattr(problems.numerical, name)(m=m)
     g = torch.Generator(device="cuda").manual_seed(m * 31 + len(name))
     x = torch.rand(517, prob.d, device=cuda, generator=g)
+    if name in ("MaF10", "MaF11", "MaF12"):
+        x = x * torch.arange(2, 2 * prob.d + 1, 2, device=cuda)          # variable i lives in [0, 2i]
+    if name == "MaF9":
+        x = x * 4 - 2
     pstate = prob.setup(rnd.PRNGKey(0))
     got, _ = prob.evaluate(pstate, x)
     ref, _ = prob.evaluate(pstate, x.double())
-    assert got.dtype == torch.float32 and got.shape == (517, prob.m) and ref.dtype == torch.float64
+    assert got.dtype == torch.float32 and got.shape == (517, prob.m)
+    assert ref.dtype == torch.float64 or name == "MaF9"          # MaF9's tensor formulation works in fp32 throughout
+    ref = ref.double()
     err = (got.double() - ref).abs()
-    assert bool((err <= 5e-4 * ref.abs() + 1e-4 * float(ref.abs().max())).all()), (name, m, float(err.max()), float(ref.abs().max()))
+    tol = 5e-4 * ref.abs() + 1e-4 * float(ref.abs().max())
+    if name == "MaF12":
+        # WFG9 raises to powers up to 50 and takes cosines of arguments up to 122 pi: single precision itself is worth a few
+        # 1e-3 here.  The kernel may not be worse than the tensor formulation evaluated in fp32.
+        import evox_amd.problems.numerical.maf as maf_mod
+        kinds = dict(maf_mod._KIND)
+        maf_mod._KIND.clear()
+        try:
+            plain, _ = prob.evaluate(pstate, x)
+        finally:
+            maf_mod._KIND.update(kinds)
+        tol = torch.maximum(tol, 3 * (plain.double() - ref).abs().max())
+    assert bool((err <= tol).all()), (name, m, float(err.max()), float(ref.abs().max()))
     # a strided view of a wider matrix is read in place
-    wide = torch.rand(517, prob.d + 3, device=cuda, generator=g)
+    wide = torch.rand(517, prob.d + 3, device=cuda, generator=g) * (2.0 if name in ("MaF10", "MaF11", "MaF12") else 1.0)
     got2, _ = prob.evaluate(pstate, wide[:, :prob.d])
     ref2, _ = prob.evaluate(pstate, wide[:, :prob.d].double())
-    assert torch.allclose(got2.double(), ref2, rtol=5e-4, atol=1e-4 * float(ref2.abs().max()))
+    assert torch.allclose(got2.double(), ref2.double(), rtol=5e-3 if name == "MaF12" else 5e-4, atol=1e-4 * float(ref2.abs().max()))
 
 
 @pytest.mark.parametrize("n,m", [(1500, 3), (333, 2), (2048, 5)])
