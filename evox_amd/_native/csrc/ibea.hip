@@ -235,6 +235,127 @@ __global__ __launch_bounds__(256) void bige_crowding_kernel(const float* __restr
   if (s == 0 && j < n) cd[j] = sqrtf(fmaxf(acc + part[1][r] + part[2][r] + part[3][r], 0.f));
 }
 
+// KnEA's density estimate needs the K nearest neighbours of every point: K smallest distances (self excluded) streamed
+// from the objective vectors; four lanes share a point, each keeps the K smallest of its quarter of the tiles in
+// registers, lane group 0 merges.  out: n x K ascending distances.
+template <int M, int K>
+__global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__ f, int n, float* __restrict__ out) {
+  __shared__ float tile[M][256];
+  __shared__ float part[3][64][K];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + r;
+  float mine[M], best[K];
+#pragma unroll
+  for (int k = 0; k < M; ++k) mine[k] = j < n ? f[(int64_t)j * M + k] : 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) best[k] = INFINITY;
+  auto insert = [&](float d2) {
+    if (d2 < best[K - 1]) {
+      best[K - 1] = d2;
+#pragma unroll
+      for (int k = K - 1; k > 0; --k)
+        if (best[k] < best[k - 1]) { const float t = best[k]; best[k] = best[k - 1]; best[k - 1] = t; }
+    }
+  };
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? f[(int64_t)ii * M + k] : 0.f;
+    __syncthreads();
+    const int lim = min(64, n - i0 - s * 64);
+    for (int q = 0; q < lim; ++q) {
+      const int c = s * 64 + q;
+      float d2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) {
+        const float d = tile[k][c] - mine[k];
+        d2 = fmaf(d, d, d2);
+      }
+      if (i0 + c != j) insert(d2);
+    }
+  }
+  if (s > 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) part[s - 1][r][k] = best[k];
+  }
+  __syncthreads();
+  if (s == 0 && j < n) {
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int k = 0; k < K; ++k) insert(part[w][r][k]);
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[(int64_t)j * K + k] = sqrtf(best[k]);
+  }
+}
+
+template <int M>
+int launch_knn(const float* f, int n, int k, float* out, hipStream_t st) {
+  const int blocks = (n + 63) / 64;
+  switch (k) {
+    case 1: knn_dist_kernel<M, 1><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 2: knn_dist_kernel<M, 2><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 3: knn_dist_kernel<M, 3><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 4: knn_dist_kernel<M, 4><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 5: knn_dist_kernel<M, 5><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 6: knn_dist_kernel<M, 6><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 7: knn_dist_kernel<M, 7><<<blocks, 256, 0, st>>>(f, n, out); break;
+    case 8: knn_dist_kernel<M, 8><<<blocks, 256, 0, st>>>(f, n, out); break;
+    default: return (int)hipErrorInvalidValue;
+  }
+  return last_launch_status();
+}
+
+// One round of KnEA's knee suppression as a fixed-point iteration.  The points are given in walking order (the point
+// closest to the ideal side of the hyperplane first); a point stays a knee candidate unless an EARLIER point that is
+// itself still selected lies in its neighbourhood (|f_p - f_q| < R in every objective):
+//   keep_out[q] = not exists p < q : keep_in[p] and close(p, q).
+// Iterated from all-ones this converges to the result of the sequential walk (position q is final after q rounds at
+// the latest; in practice after a handful).  Tiles of earlier points only: half the pair tests.
+template <int M>
+__global__ __launch_bounds__(256) void knee_round_kernel(const float* __restrict__ f, const float* __restrict__ R, int n,
+                                                         const uint8_t* __restrict__ keep_in, uint8_t* __restrict__ keep_out) {
+  __shared__ float tile[M][256];
+  __shared__ uint8_t tkeep[256];
+  __shared__ int hit[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int q = blockIdx.x * 64 + r;
+  float mine[M], rad[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    mine[k] = q < n ? f[(int64_t)q * M + k] : 0.f;
+    rad[k] = R[k];
+  }
+  int found = 0;
+  const int end = min(n, blockIdx.x * 64 + 64);            // points at or after this block's last row cannot precede it
+  for (int i0 = 0; i0 < end; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? f[(int64_t)ii * M + k] : 0.f;
+    tkeep[threadIdx.x] = ii < n ? keep_in[ii] : 0;
+    __syncthreads();
+    const int lim = min(64, end - i0 - s * 64);
+    for (int t = 0; t < lim; ++t) {
+      const int c = s * 64 + t;
+      const int p = i0 + c;
+      bool close = tkeep[c] && p < q;
+#pragma unroll
+      for (int k = 0; k < M; ++k) close = close && fabsf(tile[k][c] - mine[k]) < rad[k];
+      found |= (int)close;
+    }
+  }
+  hit[s][r] = found;
+  __syncthreads();
+  if (s == 0 && q < n) keep_out[q] = !(hit[0][r] | hit[1][r] | hit[2][r] | hit[3][r]);
+}
+
+template <int M>
+int launch_knee(const float* f, const float* R, int n, const uint8_t* keep_in, uint8_t* keep_out, hipStream_t st) {
+  knee_round_kernel<M><<<(n + 63) / 64, 256, 0, st>>>(f, R, n, keep_in, keep_out);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_bige(const float* f, const float* pr, int n, const float* radius, float* cd, hipStream_t st) {
   bige_crowding_kernel<M><<<(n + 63) / 64, 256, 0, st>>>(f, pr, n, radius, cd);
@@ -311,6 +432,19 @@ EVOX_API int evox_hip_sra_indicators(const float* obj, int n, int m, int lower, 
 EVOX_API int evox_hip_bige_crowding(const float* f, const float* pr, int n, int m, const float* radius, float* cd, void* stream) {
   if (n <= 0) return 0;
   EVOX_IBEA_DISPATCH(launch_bige, f, pr, n, radius, cd, (hipStream_t)stream)
+}
+
+// f: (n, m); out: (n, k) ascending Euclidean distances to the k nearest other points, 1 <= k <= 8.
+EVOX_API int evox_hip_knn_dist(const float* f, int n, int m, int k, float* out, void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_knn, f, n, k, out, (hipStream_t)stream)
+}
+
+// f: (n, m) in walking order, R: (m) neighbourhood half-widths on the device, keep_in / keep_out: (n) bytes.
+EVOX_API int evox_hip_knee_round(const float* f, const float* R, int n, int m, const uint8_t* keep_in, uint8_t* keep_out,
+                                 void* stream) {
+  if (n <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_knee, f, R, n, keep_in, keep_out, (hipStream_t)stream)
 }
 
 // Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix

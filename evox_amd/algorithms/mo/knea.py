@@ -10,7 +10,6 @@ from ...operators import selection
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...ops import moselect as _sel
-from ...ops.distance import cdist as _cdist
 from ...ops.linalg_small import solve_small
 from ...utils.common import cos_dist
 from .common import MOAlgorithm
@@ -18,31 +17,11 @@ from .common import MOAlgorithm
 
 def calc_DW(fit, k):
     """Weighted distance to the k nearest neighbours (KnEA's density estimate)."""
-    dis = _cdist(fit, fit)
-    nb = torch.topk(dis, k + 1, dim=1, largest=False, sorted=True).values[:, 1:]        # the k nearest, self excluded
+    nb = _sel.knn_distances(fit, k)
     avg = nb.sum(1) / k
     r = 1 / (nb - avg[:, None]).abs().clamp_min(1e-12)
     w = r / r.sum(1, keepdim=True)
     return (nb * w).sum(1)
-
-
-def _greedy_suppress(order, neighbour):
-    """Walk ``order``; an element that is still selected deselects all its neighbours.  Solved
-    as the fixed point k_q = ¬∃ p before q: neighbour[p, q] ∧ k_p (a few parallel rounds instead
-    of one step per element)."""
-    n = order.shape[0]
-    pos = torch.empty(n, dtype=torch.int64, device=order.device)
-    pos[order] = torch.arange(n, device=order.device)
-    before = (pos[:, None] < pos[None, :]) & neighbour                     # p suppresses q
-    bf = before.to(torch.float32)
-    keep = torch.ones(n, dtype=torch.bool, device=order.device)
-    for rounds in range(1, n + 1):
-        new = ~((keep.to(torch.float32) @ bf) > 0)
-        # extra rounds past the fixed point change nothing, so the (host-synchronising) test runs every fourth round
-        if rounds % 4 == 0 and torch.equal(new, keep):
-            break
-        keep = new
-    return keep
 
 
 class KnEA(MOAlgorithm):
@@ -88,9 +67,7 @@ class KnEA(MOAlgorithm):
             far_first = torch.argsort(plane @ f.T, stable=True)              # closest to the ideal side first
             r = r * torch.exp(-(1 - t / self.knee_rate) / self.n_objs)
             R = (f.amax(0) - f.amin(0)) * r
-            close = ((f[:, None, :] - f[None, :, :]).abs() < R).all(-1)
-            close = close & ~torch.eye(f.shape[0], dtype=torch.bool, device=f.device)
-            k_i = _greedy_suppress(far_first, close)
+            k_i = _sel.knee_suppress(f, far_first, R)
             knee[members] = k_i
             t = k_i.sum() / f.shape[0]
         selected = (rank < last_rank) | knee

@@ -29,6 +29,8 @@ _native.register_hip_api({
     "evox_hip_ibea_remove_obj_max": (I64, [I]),
     "evox_hip_sra_indicators": (I, [P, I, I, I, P, P, P]),
     "evox_hip_bige_crowding": (I, [P, P, I, I, P, P, P]),
+    "evox_hip_knn_dist": (I, [P, I, I, I, P, P]),
+    "evox_hip_knee_round": (I, [P, P, I, I, P, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
 })
 
@@ -225,6 +227,57 @@ def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
     else:
         _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
     return rank
+
+
+def knn_distances(f: torch.Tensor, k: int) -> torch.Tensor:
+    """(n, k) ascending Euclidean distances from every row of ``f`` (n, m) to its k nearest other rows; streamed from
+    the objective vectors on the GPU (``csrc/ibea.hip::knn_dist_kernel``), no n × n distance matrix."""
+    n, m = f.shape
+    if on_gpu(f) and 2 <= m <= 8 and 1 <= k <= 8 and f.dtype == torch.float32 and n > k:
+        out = torch.empty((n, k), dtype=torch.float32, device=f.device)
+        fc = f.contiguous()
+        check(hip().evox_hip_knn_dist(fc.data_ptr(), n, m, k, out.data_ptr(), stream_of(fc)), "knn_dist")
+        return out
+    from .distance import cdist as _cdist
+    dis = _cdist(f, f)
+    return torch.topk(dis, k + 1, dim=1, largest=False, sorted=True).values[:, 1:]
+
+
+def knee_suppress(f: torch.Tensor, order: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+    """KnEA's knee selection on one front: walk the points in ``order``; a point that is still selected deselects every
+    later point within ``R`` of it in every objective.  Returns the boolean selection in the row order of ``f``.
+
+    Solved as the fixed point ``keep[q] = ¬∃ p before q: close(p, q) ∧ keep[p]`` — a few fully parallel rounds instead of
+    one step per point (reference: the nested loops of ``algorithms/mo/knea.py:90-123``).  On the GPU a round is one
+    streaming launch over the objective vectors; the tensor formulation builds the n × n neighbourhood matrix."""
+    n, m = f.shape
+    if on_gpu(f) and 2 <= m <= 8 and f.dtype == torch.float32:
+        fs = f[order].contiguous()
+        Rc = R.to(torch.float32).contiguous()
+        a = torch.ones(n, dtype=torch.uint8, device=f.device)
+        b = torch.empty_like(a)
+        for rounds in range(1, n + 1):
+            check(hip().evox_hip_knee_round(fs.data_ptr(), Rc.data_ptr(), n, m, a.data_ptr(), b.data_ptr(), stream_of(fs)),
+                  "knee_round")
+            # rounds past the fixed point change nothing: the (host-synchronising) test runs every fourth round
+            if rounds % 4 == 0 and torch.equal(a, b):
+                break
+            a, b = b, a
+        keep = torch.empty(n, dtype=torch.bool, device=f.device)
+        keep[order] = a.to(torch.bool)
+        return keep
+    close = ((f[:, None, :] - f[None, :, :]).abs() < R).all(-1)
+    close = close & ~torch.eye(n, dtype=torch.bool, device=f.device)
+    pos = torch.empty(n, dtype=torch.int64, device=f.device)
+    pos[order] = torch.arange(n, device=f.device)
+    before = ((pos[:, None] < pos[None, :]) & close).to(torch.float32)        # p suppresses q
+    keep = torch.ones(n, dtype=torch.bool, device=f.device)
+    for rounds in range(1, n + 1):
+        new = ~((keep.to(torch.float32) @ before) > 0)
+        if rounds % 4 == 0 and torch.equal(new, keep):
+            break
+        keep = new
+    return keep
 
 
 def bige_crowding(normed: torch.Tensor, pr: torch.Tensor, radius: torch.Tensor) -> torch.Tensor:

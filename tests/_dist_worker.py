@@ -99,7 +99,8 @@ def main():
         cands, _ = wf.algorithm.init_ask(state.get_child_state("algorithm"))
         for _ in range(60):
             state = wf.step(state)
-        result = {"members": len(algo.members), "cand_shape": list(cands.shape), "best": float(mon.get_best_fitness()),
+        result = {"members": len(algo.members), "blocks": algo.members[0].num_blocks, "cand_shape": list(cands.shape),
+                  "best": float(mon.get_best_fitness()),
                   "cands": cands.reshape(-1)[:40].tolist()}
     elif case == "std_multi_device":
         wf = workflows.StdWorkflow(A.PSO(lb, ub, 16), problems.numerical.Sphere())

@@ -112,10 +112,10 @@ def test_enable_multi_devices(tmp_path):
 
 
 def test_clustered_algorithm_blocks_dealt_out_over_ranks(tmp_path):
-    """Cross-process decomposition: 4 blocks on 2 ranks, two member algorithms per rank, identical full candidates on
-    both ranks, and the optimisation converges."""
+    """Cross-process decomposition: 4 blocks on 2 ranks, two blocks per rank (as one batched CMA-ES instance), identical
+    full candidates on both ranks, and the optimisation converges."""
     res = launch("clustered_dist", 2, tmp_path)
-    assert all(r["members"] == 2 and r["cand_shape"] == [16, 20] for r in res)
+    assert all(r["members"] == 1 and r["blocks"] == 2 and r["cand_shape"] == [16, 20] for r in res)
     assert res[0]["cands"] == res[1]["cands"]
     assert all(r["best"] < 1.0 for r in res)
 

@@ -1424,3 +1424,40 @@ def test_lmocso_density_streams_the_shifted_distances(cuda):
     d = shifted_distance_matrix(f.cpu())
     d.fill_diagonal_(float("inf"))
     assert torch.allclose(got.cpu(), d.amin(1), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,m,k", [(1000, 3, 3), (257, 2, 1), (3000, 5, 8)])
+def test_knn_distance_kernel_matches_sorted_distance_matrix(cuda, n, m, k):
+    from evox_amd.ops import moselect as sel
+
+    f = torch.rand(n, m, device=cuda)
+    f[5] = f[9]                                                     # a duplicate: its nearest neighbour is at distance 0
+    got = sel.knn_distances(f, k)
+    d = torch.cdist(f.double(), f.double())
+    d.fill_diagonal_(float("inf"))
+    ref = torch.sort(d, dim=1).values[:, :k]
+    assert got.shape == (n, k) and torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-6)
+    assert float(got[5, 0]) == 0.0
+
+
+@pytest.mark.parametrize("n,m", [(700, 3), (64, 2), (2500, 4)])
+def test_knee_suppression_rounds_match_sequential_walk(cuda, n, m):
+    """The fixed-point rounds (one streaming launch each) select exactly what the sequential walk selects."""
+    from evox_amd.ops import moselect as sel
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    f = torch.rand(n, m, device=cuda, generator=g)
+    order = torch.randperm(n, device=cuda, generator=g)
+    R = torch.full((m,), 0.08 if n > 100 else 0.3, device=cuda)
+    got = sel.knee_suppress(f, order, R)
+    fc, oc, Rc = f.cpu(), order.cpu().tolist(), R.cpu()
+    # the sequential definition: a point still selected when the walk reaches it deselects its later neighbours
+    pos = torch.empty(n, dtype=torch.int64)
+    pos[torch.tensor(oc)] = torch.arange(n)
+    keep = torch.ones(n, dtype=torch.bool)
+    for p in oc:
+        if keep[p]:
+            near = ((fc - fc[p]).abs() < Rc).all(1) & (pos > pos[p])
+            keep &= ~near
+    assert torch.equal(got.cpu(), keep)
+    assert 0 < int(keep.sum()) < n

@@ -1,5 +1,5 @@
 """Generation time of every multi-objective algorithm on DTLZ2 (m=3) on the GPU.
-usage: mo_survey.py [pop] ; one JSON line per algorithm (time per generation, IGD after 65 generations)."""
+usage: mo_survey.py [pop] [NAME ...] ; one JSON line per algorithm (time per generation, IGD after 65 generations)."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,8 @@ from evox_amd import algorithms, problems, workflows
 pop = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 names = ["NSGA2", "NSGA3", "RVEA", "RVEAa", "MOEAD", "MOEADDRA", "MOEADM2M", "EAGMOEAD", "IBEA", "BCEIBEA", "SPEA2", "HypE",
          "KnEA", "BiGE", "GDE3", "SRA", "TDEA", "LMOCSO", "IMMOEA"]
+if len(sys.argv) > 2:
+    names = [n for n in names if n in sys.argv[2:]]
 dev = torch.device("cuda")
 prob = problems.numerical.DTLZ2(m=3)
 lb, ub = torch.zeros(prob.d, device=dev), torch.ones(prob.d, device=dev)
