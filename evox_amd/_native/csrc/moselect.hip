@@ -7,6 +7,7 @@
 // (a score vector, one matrix row per step) lives in LDS / L2 and no other workgroup is
 // involved, so no inter-workgroup hand-off is needed.  Every loop has a fixed trip count.
 #include "hip_common.h"
+#include "sr_coins.h"
 
 using namespace evox;
 
@@ -208,10 +209,12 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(const float* __restr
 // L threads instead of n/2 passes of n steps by a single lane.
 // KEYS: the two key vectors and the coin flips are staged in LDS too (each instantiation addresses one memory
 // space only, so the loop compiles to LDS / global instructions rather than generic ones).
-template <int L, bool KEYS>
+// FRESH: every comparison draws its own coin (sr_coins.h: a hash of seed, sweep and position; a thread refreshes its
+// hash word every fourth position) instead of reading the per-position vector u.
+template <int L, bool KEYS, bool FRESH>
 __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
                                                                const float* __restrict__ u, float pc, int n,
-                                                               int64_t* __restrict__ rank) {
+                                                               int64_t* __restrict__ rank, const int32_t* __restrict__ seed_ptr) {
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
   int* rk = s_mem;                                       // the permutation, n entries
   float* l1 = reinterpret_cast<float*>(s_mem + n);       // copies of I1, I2, u when KEYS
@@ -220,9 +223,14 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
   const int lane = threadIdx.x;
   for (int i = lane; i < n; i += L) {
     rk[i] = i;
-    if constexpr (KEYS) { l1[i] = I1[i]; l2[i] = I2[i]; lu[i] = u[i]; }
+    if constexpr (KEYS) {
+      l1[i] = I1[i]; l2[i] = I2[i];
+      if constexpr (!FRESH) lu[i] = u[i];
+    }
   }
   __syncthreads();
+  const uint32_t seed = FRESH ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
+  uint32_t mask = 0;
   auto key1 = [&](int i) { if constexpr (KEYS) return l1[i]; else return I1[i]; };
   auto key2 = [&](int i) { if constexpr (KEYS) return l2[i]; else return I2[i]; };
   auto coin = [&](int j) { if constexpr (KEYS) return lu[j]; else return u[j]; };
@@ -238,7 +246,13 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
         if (j == 0) { a = rk[0]; a1 = key1(a); a2 = key2(a); }
         const int b = rk[j + 1];
         const float b1 = key1(b), b2 = key2(b);
-        const bool first = coin(j) < pc;
+        bool first;
+        if constexpr (FRESH) {
+          if ((j & 3) == 0) mask = sr_coin_mask(sr_coin_group(seed, (uint32_t)(s0 + lane), (uint32_t)j >> 2), pc7);
+          first = (mask >> (8 * (j & 3) + 7)) & 1u;
+        } else {
+          first = coin(j) < pc;
+        }
         if ((first ? a1 : a2) < (first ? b1 : b2)) {
           rk[j] = b;                                       // b moves left, a keeps bubbling right
         } else {
@@ -263,11 +277,15 @@ __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __re
 // to T·B entries with sentinels (both keys -inf) that no element can pass, which keeps every thread's range full.
 // Exactly the sequential result (a sweep without swaps changes nothing, so running all ⌈n/2⌉ sweeps is the same as
 // stopping early).
-template <int B>
+// FRESH: the coins of a thread's B comparators in sweep s are B/4 hash words (B is a multiple of 4), turned into
+// four coins each by one carry-free byte-wise comparison.
+template <int B, bool FRESH>
 __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const float* __restrict__ I1,
                                                                           const float* __restrict__ I2,
                                                                           const float* __restrict__ u, float pc, int n,
-                                                                          int64_t* __restrict__ rank) {
+                                                                          int64_t* __restrict__ rank,
+                                                                          const int32_t* __restrict__ seed_ptr) {
+  static_assert(B % 4 == 0, "coin groups hold four positions");
   constexpr int T = 1024;
   __shared__ int c_i[T], f_i[T];
   __shared__ float c_1[T], c_2[T], f_1[T], f_2[T];
@@ -284,8 +302,11 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
     xi[q] = p < n ? p : -1;
     x1[q] = p < n ? I1[p] : -INFINITY;
     x2[q] = p < n ? I2[p] : -INFINITY;
-    if (p < n - 1 && u[p] < pc) use_first |= 1u << q;
+    if constexpr (!FRESH) {
+      if (p < n - 1 && u[p] < pc) use_first |= 1u << q;
+    }
   }
+  const uint32_t seed = FRESH ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
   f_i[t] = xi[0]; f_1[t] = x1[0]; f_2[t] = x2[0];
   __syncthreads();
   const int sweeps = (n + 1) / 2;
@@ -301,11 +322,17 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
       const bool last = t == threads - 1;
       const int ni = last ? -1 : f_i[t + 1];
       const float n1 = last ? -INFINITY : f_1[t + 1], n2 = last ? -INFINITY : f_2[t + 1];
+      uint32_t masks[B / 4];
+      if constexpr (FRESH) {
+#pragma unroll
+        for (int w = 0; w < B / 4; ++w)
+          masks[w] = sr_coin_mask(sr_coin_group(seed, (uint32_t)(d >> 1), (uint32_t)(t * (B / 4) + w)), pc7);
+      }
 #pragma unroll
       for (int q = 0; q < B; ++q) {
         const int bi = q + 1 < B ? xi[q + 1] : ni;
         const float b1 = q + 1 < B ? x1[q + 1] : n1, b2 = q + 1 < B ? x2[q + 1] : n2;
-        const bool first = (use_first >> q) & 1u;
+        const bool first = FRESH ? (masks[q >> 2] >> (8 * (q & 3) + 7)) & 1u : (use_first >> q) & 1u;
         if ((first ? a1 : a2) < (first ? b1 : b2)) {
           xi[q] = bi; x1[q] = b1; x2[q] = b2;             // b moves left, a keeps bubbling right
         } else {
@@ -329,8 +356,10 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
 }
 
 template <int B>
-int launch_ranking_blocked(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, hipStream_t st) {
-  stochastic_ranking_blocked_kernel<B><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank);
+int launch_ranking_blocked(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank,
+                           const int32_t* seed, hipStream_t st) {
+  if (seed) stochastic_ranking_blocked_kernel<B, true><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed);
+  else stochastic_ranking_blocked_kernel<B, false><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed);
   return last_launch_status();
 }
 
@@ -338,17 +367,21 @@ int launch_ranking_blocked(const float* I1, const float* I2, const float* u, flo
 __global__ __launch_bounds__(64) void stochastic_ranking_serial_kernel(const float* __restrict__ I1,
                                                                        const float* __restrict__ I2,
                                                                        const float* __restrict__ u, float pc, int n,
-                                                                       int64_t* __restrict__ rank, int* __restrict__ rk) {
+                                                                       int64_t* __restrict__ rank, int* __restrict__ rk,
+                                                                       const int32_t* __restrict__ seed_ptr) {
   for (int i = threadIdx.x; i < n; i += 64) rk[i] = i;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int sweeps = (n + 1) / 2;
+    const bool fresh = seed_ptr != nullptr;
+    const uint32_t seed = fresh ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
     for (int s = 0; s < sweeps; ++s) {
-      bool swapped = false;
+      bool swapped = fresh;                                 // fresh coins: every sweep runs
       int a = rk[0];
       for (int j = 0; j + 1 < n; ++j) {
         const int b = rk[j + 1];
-        const float* key = u[j] < pc ? I1 : I2;
+        const bool first = fresh ? sr_coin(seed, (uint32_t)s, (uint32_t)j, pc7) : u[j] < pc;
+        const float* key = first ? I1 : I2;
         if (key[a] < key[b]) { rk[j] = b; swapped = true; }
         else { rk[j] = a; a = b; }
       }
@@ -485,27 +518,39 @@ EVOX_API int evox_hip_spea2_truncate(const float* dis, int n, int ld, int n_remo
   return last_launch_status();
 }
 
-template <int L>
-int launch_ranking(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
-                   int keys_in_lds, hipStream_t st) {
-  const void* fn = keys_in_lds ? (const void*)stochastic_ranking_kernel<L, true> : (const void*)stochastic_ranking_kernel<L, false>;
+template <int L, bool KEYS, bool FRESH>
+int launch_ranking_as(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
+                      const int32_t* seed, hipStream_t st) {
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel<L, KEYS, FRESH>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  if (keys_in_lds) stochastic_ranking_kernel<L, true><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank);
-  else stochastic_ranking_kernel<L, false><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank);
+  stochastic_ranking_kernel<L, KEYS, FRESH><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank, seed);
   return last_launch_status();
 }
 
-EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
-                                         int64_t* rank, int* scratch, void* stream) {
+template <int L>
+int launch_ranking(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
+                   int keys_in_lds, const int32_t* seed, hipStream_t st) {
+  if (seed) {
+    return keys_in_lds ? launch_ranking_as<L, true, true>(I1, I2, u, pc, n, rank, lds, seed, st)
+                       : launch_ranking_as<L, false, true>(I1, I2, u, pc, n, rank, lds, seed, st);
+  }
+  return keys_in_lds ? launch_ranking_as<L, true, false>(I1, I2, u, pc, n, rank, lds, seed, st)
+                     : launch_ranking_as<L, false, false>(I1, I2, u, pc, n, rank, lds, seed, st);
+}
+
+// u: n-1 per-position coins in [0, 1) (the comparison at position j ranks by I1 when u[j] < pc, in every sweep), or —
+// seed != null, u unused — a fresh coin for every comparison, drawn from a hash of (*seed, sweep, position).
+static int stochastic_ranking_any(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank,
+                                  int* scratch, const int32_t* seed, void* stream) {
   if (n <= 0) return 0;
   if (n > 4096 && n <= 1024 * 24) {
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 1024 * 8) return launch_ranking_blocked<8>(I1, I2, u, pc, n, rank, st);
-    if (n <= 1024 * 16) return launch_ranking_blocked<16>(I1, I2, u, pc, n, rank, st);
-    return launch_ranking_blocked<24>(I1, I2, u, pc, n, rank, st);
+    if (n <= 1024 * 8) return launch_ranking_blocked<8>(I1, I2, u, pc, n, rank, seed, st);
+    if (n <= 1024 * 16) return launch_ranking_blocked<16>(I1, I2, u, pc, n, rank, seed, st);
+    return launch_ranking_blocked<24>(I1, I2, u, pc, n, rank, seed, st);
   }
   const size_t perm = (size_t)n * sizeof(int);
   if (perm <= 160 * 1024) {
@@ -515,13 +560,25 @@ EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const
     const int sweeps = (n + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     // as many pipeline stages as there are sweeps, up to the 1024 threads of a workgroup
-    if (sweeps <= 64) return launch_ranking<64>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
-    if (sweeps <= 256) return launch_ranking<256>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
-    return launch_ranking<1024>(I1, I2, u, pc, n, rank, lds, keys_in_lds, st);
+    if (sweeps <= 64) return launch_ranking<64>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
+    if (sweeps <= 256) return launch_ranking<256>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
+    return launch_ranking<1024>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
   }
   if (scratch == nullptr) return (int)hipErrorInvalidValue;
-  stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch);
+  stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch, seed);
   return last_launch_status();
+}
+
+EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
+                                         int64_t* rank, int* scratch, void* stream) {
+  if (u == nullptr && n > 1) return (int)hipErrorInvalidValue;
+  return stochastic_ranking_any(I1, I2, u, pc, n, rank, scratch, nullptr, stream);
+}
+
+EVOX_API int evox_hip_stochastic_ranking_fresh(const float* I1, const float* I2, const int32_t* seed, float pc, int n,
+                                               int64_t* rank, int* scratch, void* stream) {
+  if (seed == nullptr) return (int)hipErrorInvalidValue;
+  return stochastic_ranking_any(I1, I2, nullptr, pc, n, rank, scratch, seed, stream);
 }
 
 EVOX_API int evox_hip_niche_fill(const int64_t* rho, const int64_t* cnt, int nref, const int64_t* k, int64_t* out,

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <vector>
 
+#include "sr_coins.h"
+
 extern "C" {
 
 // alive[j] = 1 for survivors.  fit is updated in place.
@@ -60,6 +62,27 @@ void evox_cpu_stochastic_ranking(const float* I1, const float* I2, const float* 
       }
     }
     if (!swapped) break;
+  }
+}
+
+// The same sort with a fresh coin for every comparison (sr_coins.h): comparison (sweep s, position j) ranks by I1 when
+// coin(seed, s, j), else by I2.
+void evox_cpu_stochastic_ranking_fresh(const float* I1, const float* I2, const int32_t* seed_ptr, float pc, int64_t n,
+                                       int64_t* rank) {
+  const uint32_t seed = (uint32_t)*seed_ptr, pc7 = evox::sr_pc7(pc);
+  for (int64_t i = 0; i < n; ++i) rank[i] = i;
+  const int64_t sweeps = (n + 1) / 2;
+  for (int64_t s = 0; s < sweeps; ++s) {
+    bool swapped = false;
+    for (int64_t j = 0; j + 1 < n; ++j) {
+      const float* key = evox::sr_coin(seed, (uint32_t)s, (uint32_t)j, pc7) ? I1 : I2;
+      if (key[rank[j]] < key[rank[j + 1]]) {
+        const int64_t t = rank[j]; rank[j] = rank[j + 1]; rank[j + 1] = t;
+        swapped = true;
+      }
+    }
+    // no early exit: a sweep without swaps under one set of coins says nothing about the next set
+    (void)swapped;
   }
 }
 

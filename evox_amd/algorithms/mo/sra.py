@@ -34,14 +34,23 @@ class SRA(MOAlgorithm):
     previous generation sit in front and are measured among themselves only, which acts as elitism; ``"all"`` — every
     other individual, as in SPEA2+SDE.  On three-objective DTLZ2 (population 2000, 65 generations) the first gives an IGD
     of 0.067, the second 0.078; both indicators are computed straight from the objective vectors
-    (``ops.moselect.sra_indicators``), no n × n matrix is formed."""
+    (``ops.moselect.sra_indicators``), no n × n matrix is formed.
 
-    def __init__(self, lb, ub, n_objs, pop_size, mutation_op=None, crossover_op=None, density: str = "preceding"):
+    ``coins`` selects how the stochastic ranking flips its coins: ``"per_comparison"`` (default) — every comparison of
+    every sweep draws its own coin, as in the SRA paper; ``"per_position"`` — one coin per position, reused by all sweeps,
+    the form of the reference (``sra.py:36-83``), which turns the ranking into a sort with a fixed criterion per position
+    and costs convergence: IGD on three-objective DTLZ2 after 100 generations at population 300, three seeds:
+    0.063–0.073 per position, 0.042–0.043 per comparison (NSGA-II: 0.041)."""
+
+    def __init__(self, lb, ub, n_objs, pop_size, mutation_op=None, crossover_op=None, density: str = "preceding",
+                 coins: str = "per_comparison"):
         self._init_mo(lb, ub, n_objs, pop_size, mutation_op,
                       crossover_op if crossover_op is not None else crossover.SimulatedBinary(type=2))
         if density not in ("all", "preceding"):
             raise ValueError("density must be 'all' or 'preceding'")
-        self.density = density
+        if coins not in ("per_comparison", "per_position"):
+            raise ValueError("coins must be 'per_comparison' or 'per_position'")
+        self.density, self.coins = density, coins
 
     def ask(self, state):
         key, k_sel, k_x, k_mut = rnd.split(state.key, 4)
@@ -58,7 +67,10 @@ class SRA(MOAlgorithm):
             I1, I2 = _sel.sra_indicators(obj, lower_only=True)
         else:
             I1, I2 = _sel.sra_indicators(obj, lower_only=False)
-        order = _sel.stochastic_ranking(I1, I2, rnd.uniform(k_env, (n - 1,)), float(pc))
+        if self.coins == "per_comparison":
+            order = _sel.stochastic_ranking(I1, I2, None, float(pc), seed=rnd.bits(k_env, (1,)))
+        else:
+            order = _sel.stochastic_ranking(I1, I2, rnd.uniform(k_env, (n - 1,)), float(pc))
         idx = order[: self.pop_size]
         return state.replace(population=pop[idx], fitness=obj[idx], key=key)
 

@@ -18,11 +18,13 @@ _native.register_cpu_api({
     "evox_cpu_ibea_remove": (None, [P, P, P, F, I64, I64, P]),
     "evox_cpu_spea2_truncate": (None, [P, I64, I64, P]),
     "evox_cpu_stochastic_ranking": (None, [P, P, P, F, I64, P]),
+    "evox_cpu_stochastic_ranking_fresh": (None, [P, P, P, F, I64, P]),
 })
 _native.register_hip_api({
     "evox_hip_ibea_remove": (I, [P, P, P, F, I, I, P, P]),
     "evox_hip_spea2_truncate": (I, [P, I, I, I, P, P, P, P]),
     "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
+    "evox_hip_stochastic_ranking_fresh": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
@@ -212,13 +214,49 @@ def stochastic_ranking_reference(I1, I2, u, pc):
     return torch.tensor(rank, dtype=torch.int64, device=I1.device)
 
 
-def stochastic_ranking(I1, I2, u, pc) -> torch.Tensor:
-    """SRA's stochastic bubble sort: at most ⌈n/2⌉ sweeps; position j of a sweep compares by
-    ``I1`` when ``u[j] < pc`` and by ``I2`` otherwise; larger values move to the front."""
+def coin_reference(seed: int, sweep: int, position: int, pc: float) -> bool:
+    """The coin of comparison (sweep, position) of :func:`stochastic_ranking` with ``seed`` — a plain-Python copy of
+    ``csrc/sr_coins.h`` for tests and documentation."""
+    M = 0xFFFFFFFF
+
+    def h(x):
+        x ^= x >> 16
+        x = (x * 0x7FEB352D) & M
+        x ^= x >> 15
+        x = (x * 0x846CA68B) & M
+        x ^= x >> 16
+        return x
+
+    pc7 = min(128, max(0, int(pc * 128.0 + 0.5)))
+    g = position >> 2
+    word = h((((seed & M) + sweep * 0x9E3779B1) & M) ^ ((g * 0x85EBCA77 + 0x165667B1) & M))
+    return ((word >> (8 * (position & 3))) & 0x7F) < pc7
+
+
+def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor:
+    """SRA's stochastic bubble sort, ⌈n/2⌉ sweeps; a comparison ranks by ``I1`` when its coin says so and by ``I2``
+    otherwise; larger values move to the front.
+
+    ``seed=None``: position j compares by ``I1`` when ``u[j] < pc`` — the same coin in every sweep, the form of the
+    reference (``algorithms/mo/sra.py:22-83``); the sort stops at the first sweep without a swap.
+    ``seed`` (an int32 tensor with one element, on the device of the keys; ``u`` is ignored): every comparison draws its
+    own coin — a counter-based hash of (seed, sweep, position), probability resolved to 1/128 (``csrc/sr_coins.h``) —
+    which is the stochastic ranking of the SRA paper; all sweeps run."""
     n = I1.shape[0]
-    I1, I2, u = I1.contiguous().float(), I2.contiguous().float(), u.contiguous().float()
+    I1, I2 = I1.contiguous().float(), I2.contiguous().float()
     rank = torch.empty(n, dtype=torch.int64, device=I1.device)
     pc = float(pc)
+    if seed is not None:
+        seed = seed.reshape(-1)[:1].to(device=I1.device, dtype=torch.int32).contiguous()
+        if on_gpu(I1):
+            scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
+            check(hip().evox_hip_stochastic_ranking_fresh(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pc, n, rank.data_ptr(),
+                                                          scratch.data_ptr() if scratch is not None else None, stream_of(I1)),
+                  "stochastic_ranking_fresh")
+        else:
+            _native.cpu().evox_cpu_stochastic_ranking_fresh(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pc, n, rank.data_ptr())
+        return rank
+    u = u.contiguous().float()
     if on_gpu(I1):
         scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
         check(hip().evox_hip_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr(),

@@ -100,3 +100,27 @@ def test_small_solve_host_path_and_crowd_remove_reference():
     big_r = (d / d.amin(1).mean() / 2).clamp_max(1.0)
     keep = moselect.crowd_remove(big_r, 12)                 # host tensors: the reference loop
     assert keep.dtype == torch.bool and int(keep.sum()) == 18
+
+
+def test_stochastic_ranking_fresh_coins_host_twin_follows_the_definition():
+    """The host twin of the coin-per-comparison stochastic ranking against a plain-Python bubble sort that takes its
+    coins from ``coin_reference``; the coins come out with the requested probability."""
+    import torch
+    from evox_amd.ops import moselect
+
+    n, pc, seed = 41, 0.55, 987654321
+    g = torch.Generator().manual_seed(1)
+    I1 = (torch.rand(n, generator=g) * 8).round() / 8
+    I2 = torch.rand(n, generator=g)
+    got = moselect.stochastic_ranking(I1, I2, None, pc, seed=torch.tensor([seed], dtype=torch.int64))
+    rank, a, b = list(range(n)), I1.tolist(), I2.tolist()
+    for s in range((n + 1) // 2):
+        for j in range(n - 1):
+            key = a if moselect.coin_reference(seed, s, j, pc) else b
+            if key[rank[j]] < key[rank[j + 1]]:
+                rank[j], rank[j + 1] = rank[j + 1], rank[j]
+    assert got.tolist() == rank
+    flips = [moselect.coin_reference(seed, s, j, pc) for s in range(60) for j in range(200)]
+    assert abs(sum(flips) / len(flips) - round(pc * 128) / 128) < 0.02
+    # different sweeps see different coins at the same position
+    assert len({tuple(moselect.coin_reference(seed, s, j, pc) for j in range(64)) for s in range(8)}) == 8

@@ -1461,3 +1461,19 @@ def test_knee_suppression_rounds_match_sequential_walk(cuda, n, m):
             keep &= ~near
     assert torch.equal(got.cpu(), keep)
     assert 0 < int(keep.sum()) < n
+
+
+@pytest.mark.parametrize("n", [2, 5, 64, 129, 700, 4096, 4097, 5000, 8193, 12001, 16385, 20000])
+def test_stochastic_ranking_with_fresh_coins_equals_host_twin(cuda, n):
+    """A coin per comparison (hash of seed, sweep, position): the pipelined kernels — element-wise for short
+    permutations, blocked with 8, 16 or 24 entries per thread for long ones — give exactly the host twin's order."""
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n + 7)
+    I1 = (torch.rand(n, generator=g) * 20).round() / 20
+    I2 = torch.rand(n, generator=g)
+    seed = torch.tensor([-1234567 + n], dtype=torch.int32)
+    got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), None, 0.47, seed=seed.to(cuda))
+    ref = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
+    assert torch.equal(got.cpu(), ref)
+    assert sorted(got.tolist()) == list(range(n))
