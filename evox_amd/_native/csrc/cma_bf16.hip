@@ -228,6 +228,106 @@ __global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict
   }
 }
 
+// Tile-packed upper triangle of a symmetric n x n matrix: the 64 x 64 tiles (i <= j) in the order of upper_tiles(), each
+// stored contiguously (row-major, zero beyond n).  It is what a multi-process job sums across ranks instead of the full
+// square: T(T+1)/2 tiles of 4096 floats — 0.56 n² at n = 1000.
+// gram_pack_kernel: tile = sum of the K-split slabs of the Gram product (same element order of summation as
+// cov_reduce_kernel).
+template <int MAXS>
+__global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ ws, int splits, float* __restrict__ packed,
+                                                        int n, int tiles) {
+  int i = 0, rem = blockIdx.x;
+  while (rem >= tiles - i) {
+    rem -= tiles - i;
+    ++i;
+  }
+  const int j = i + rem;
+  const int r0 = i * 64, c0 = j * 64;
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int64_t slab = (int64_t)n * n;
+  const int cc = c0 + 4 * q;
+  float* tile = packed + (int64_t)blockIdx.x * 4096;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = rg + 16 * p, r = r0 + rl;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < n && cc < n) {
+      const int64_t e = (int64_t)r * n + cc;
+      float4 g[MAXS];
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s)
+        g[s] = s < splits ? *reinterpret_cast<const float4*>(ws + s * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = MAXS; s < splits; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(ws + s * slab + e);
+        g[0].x += t.x; g[0].y += t.y; g[0].z += t.z; g[0].w += t.w;
+      }
+      sum = g[0];
+#pragma unroll
+      for (int s = 1; s < MAXS; ++s) { sum.x += g[s].x; sum.y += g[s].y; sum.z += g[s].z; sum.w += g[s].w; }
+    }
+    *reinterpret_cast<float4*>(tile + rl * 64 + 4 * q) = sum;
+  }
+}
+
+// out (n x n, both triangles, symmetric to the last bit) = alpha C + c1 pc pc^T + cmu G, G given tile-packed.  `poison`
+// (optional, one float): a positive value turns the result into NaNs.
+__global__ __launch_bounds__(256) void cov_from_packed_kernel(const float* __restrict__ packed, const float* __restrict__ C,
+                                                              const float* __restrict__ pc, const float* __restrict__ alpha,
+                                                              float c1, float cmu, const float* __restrict__ poison,
+                                                              float* __restrict__ out, int n, int tiles) {
+  __shared__ float tr[64][65];
+  int i = 0, rem = blockIdx.x;
+  while (rem >= tiles - i) {
+    rem -= tiles - i;
+    ++i;
+  }
+  const int j = i + rem;
+  const int r0 = i * 64, c0 = j * 64;
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const float a = alpha[0];
+  const bool bad = poison != nullptr && *poison > 0.f;
+  const float* tile = packed + (int64_t)blockIdx.x * 4096;
+  const int cc = c0 + 4 * q;
+  float pcc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) pcc[k] = cc + k < n ? pc[cc + k] : 0.f;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = rg + 16 * p, r = r0 + rl;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < n && cc < n) {
+      const int64_t e = (int64_t)r * n + cc;
+      const float4 gsum = *reinterpret_cast<const float4*>(tile + rl * 64 + 4 * q);
+      const float4 cv = *reinterpret_cast<const float4*>(C + e);
+      const float pr = pc[r];
+      v[0] = fmaf(a, cv.x, fmaf(c1, pr * pcc[0], cmu * gsum.x));
+      v[1] = fmaf(a, cv.y, fmaf(c1, pr * pcc[1], cmu * gsum.y));
+      v[2] = fmaf(a, cv.z, fmaf(c1, pr * pcc[2], cmu * gsum.z));
+      v[3] = fmaf(a, cv.w, fmaf(c1, pr * pcc[3], cmu * gsum.w));
+      if (bad) v[0] = v[1] = v[2] = v[3] = __builtin_nanf("");
+      if (i != j) *reinterpret_cast<float4*>(out + e) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tr[rl][4 * q + k] = v[k];
+  }
+  __syncthreads();
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  if (i == j) {
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+      const int rl = rr * 4 + grp, r = r0 + rl;
+      if (r < n && c0 + col < n) out[(int64_t)r * n + c0 + col] = rl <= col ? tr[rl][col] : tr[col][rl];
+    }
+    return;
+  }
+#pragma unroll 4
+  for (int rr = 0; rr < 16; ++rr) {
+    const int rl = rr * 4 + grp;
+    const int r = c0 + rl, c = r0 + col;
+    if (r < n && c < n) out[(int64_t)r * n + c] = tr[col][rl];
+  }
+}
+
 inline int ksteps_of(int64_t k) { return (int)((k + 63) / 64); }
 
 }  // namespace
@@ -305,11 +405,8 @@ EVOX_API int evox_hip_bf16_cov_splits(int n, int mu) {
   return (ks + per - 1) / per;
 }
 
-// out (n x n fp32, both triangles) = alpha[0] * C + c1 * pc pc^T + cmu * Yt Yt^T, Yt bf16 [n][ldy] with K = mu.
-// ws: evox_hip_bf16_cov_splits(n, mu) * n * n floats.
-EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C, const float* pc,
-                               const float* alpha, float c1, float cmu, float* out, float* ws, int64_t ws_floats,
-                               void* stream) {
+static int gram_slabs(const void* Yt, int64_t ldy, int n, int mu, float* ws, int64_t ws_floats, int* splits_out,
+                      hipStream_t st) {
   if (n <= 0 || mu <= 0) return (int)hipErrorInvalidValue;
   const int ks = ksteps_of(mu);
   const int splits = evox_hip_bf16_cov_splits(n, mu);
@@ -317,7 +414,6 @@ EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const
   if (ldy < (int64_t)ks * 64 || (ldy & 7) || ((uintptr_t)Yt & 15) || (n & 3) || ((uintptr_t)ws & 15) ||
       ws_floats < (int64_t)splits * n * n)
     return (int)hipErrorInvalidValue;
-  hipStream_t st = (hipStream_t)stream;
   const int T = (n + 127) / 128;
   Args<1> g{};
   g.a[0][0] = g.b[0][0] = (const uint16_t*)Yt;
@@ -327,7 +423,48 @@ EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const
   g.ksteps_per_split = per;
   g.tiles_m = g.tiles_n = T;
   EpiSlab epi{ws, (long long)n, (long long)n * n, n, n, splits};
-  int e = launch<128, 128, 2, 4, 1, true, 3, EpiSlab>(g, epi, upper_tiles(T), splits, 1, st);
+  *splits_out = splits;
+  return launch<128, 128, 2, 4, 1, true, 3, EpiSlab>(g, epi, upper_tiles(T), splits, 1, st);
+}
+
+// Floats of the tile-packed upper triangle of an n x n matrix (see gram_pack_kernel).
+EVOX_API int64_t evox_hip_packed_upper_floats(int n) {
+  const int T64 = (n + 63) / 64;
+  return (int64_t)upper_tiles(T64) * 4096;
+}
+
+// packed (evox_hip_packed_upper_floats(n) floats, 16-byte aligned) = upper triangle of Yt Yt^T, tile-packed.
+EVOX_API int evox_hip_bf16_gram_packed(const void* Yt, int64_t ldy, int n, int mu, float* packed, float* ws, int64_t ws_floats,
+                                       void* stream) {
+  if ((uintptr_t)packed & 15) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  int splits = 0;
+  int e = gram_slabs(Yt, ldy, n, mu, ws, ws_floats, &splits, st);
+  if (e) return e;
+  const int T64 = (n + 63) / 64;
+  gram_pack_kernel<8><<<upper_tiles(T64), 256, 0, st>>>(ws, splits, packed, n, T64);
+  return last_launch_status();
+}
+
+// out (n x n, both triangles) = alpha[0] C + c1 pc pc^T + cmu G from the tile-packed upper triangle of G; a positive
+// *poison (optional) turns the result into NaNs.
+EVOX_API int evox_hip_cov_from_packed(const float* packed, int n, const float* C, const float* pc, const float* alpha, float c1,
+                                      float cmu, const float* poison, float* out, void* stream) {
+  if (n <= 0 || (n & 3) || ((uintptr_t)packed & 15) || ((uintptr_t)C & 15) || ((uintptr_t)out & 15))
+    return (int)hipErrorInvalidValue;
+  const int T64 = (n + 63) / 64;
+  cov_from_packed_kernel<<<upper_tiles(T64), 256, 0, (hipStream_t)stream>>>(packed, C, pc, alpha, c1, cmu, poison, out, n, T64);
+  return last_launch_status();
+}
+
+// out (n x n fp32, both triangles) = alpha[0] * C + c1 * pc pc^T + cmu * Yt Yt^T, Yt bf16 [n][ldy] with K = mu.
+// ws: evox_hip_bf16_cov_splits(n, mu) * n * n floats.
+EVOX_API int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C, const float* pc,
+                               const float* alpha, float c1, float cmu, float* out, float* ws, int64_t ws_floats,
+                               void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int splits = 0;
+  int e = gram_slabs(Yt, ldy, n, mu, ws, ws_floats, &splits, st);
   if (e) return e;
   const int T64 = (n + 63) / 64;
   cov_reduce_kernel<8><<<upper_tiles(T64), 256, 0, st>>>(ws, splits, C, pc, alpha, c1, cmu, out, n, T64);

@@ -27,6 +27,8 @@ int evox_hip_cma_paths(const float* mean, const float* step, const float* whiten
                        float* pc_out, float* scalars, void* stream);
 int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C, const float* pc, const float* alpha,
                       float c1, float cmu, float* out, float* ws, int64_t ws_floats, void* stream);
+int evox_hip_cov_from_packed(const float* packed, int n, const float* C, const float* pc, const float* alpha, float c1,
+                             float cmu, const float* poison, float* out, void* stream);
 int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe, void* planes,
                           float* f32ws, float* vec, float* scal, const float* prev_sqrt, const float* prev_inv,
                           float* out_sqrt, float* out_inv, void* out_sqrt_bf16, void* stream);
@@ -368,8 +370,9 @@ struct CmaTell {
   // row-sharded generation: the selected rows were reduced on every rank and summed over the ranks beforehand; `step`
   // then is an INPUT (the summed mean shift) and `gram` the summed rank-mu term
   int sharded;
-  const float* gram;         // n x n
+  const float* gram;         // n x n, or its tile-packed upper triangle (gram_packed)
   const float* poison;       // one float (> 0: rows were dropped somewhere), or null
+  int gram_packed;           // gram holds evox_hip_packed_upper_floats(n) floats (64 x 64 upper tiles)
 };
 
 EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
@@ -393,6 +396,9 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   if (!t->sharded) {
     e = evox_hip_bf16_cov(t->yt, t->ldmu, n, t->mu, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->C_o,
                           t->cov_ws, t->cov_ws_floats, stream);
+  } else if (t->gram_packed) {
+    e = evox_hip_cov_from_packed(t->gram, n, t->C, t->pc_o, t->scalars_o + 1, t->consts[6], t->consts[7], t->poison, t->C_o,
+                                 stream);
   } else {
     cov_from_gram_kernel<<<stream_grid((int64_t)n * n, 256), 256, 0, st>>>(t->C, t->gram, t->pc_o, t->scalars_o + 1,
                                                                            t->consts[6], t->consts[7], t->poison, t->C_o, n);

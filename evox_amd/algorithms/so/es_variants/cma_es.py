@@ -397,7 +397,9 @@ class CMAES(Algorithm):
             from ....ops import gemm as _gemm
             consts = self._shard_consts(local, pop.device)
             keep = min(consts["keep"], local)
-            nn = self.dim * self.dim
+            # the message: rank-μ term, mean shift, four flag words.  The native path sends the rank-μ term as the
+            # tile-packed upper triangle (it is symmetric: 0.56 n² floats instead of n²)
+            nn = _b16.packed_upper_floats(self.dim) if native else self.dim * self.dim
             packed = torch.empty(nn + self.dim + 4, dtype=torch.float32, device=pop.device)   # Gram first: aligned base
             if native:
                 # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the ranks, so that number
@@ -425,11 +427,14 @@ class CMAES(Algorithm):
                 local_order = consts["ident"]
                 packed[nn + self.dim:] = 0.0
                 sqrt_w_local = consts["sqrt_w_padded"][my_rank]      # 0 for rows outside the best μ
-            gram_out = packed[:nn].view(self.dim, self.dim)
+            gram_out = packed[:nn] if native else packed[:nn].view(self.dim, self.dim)
             if self._bf16_kernels:
                 ws = self._workspace(local, keep)
                 _b16.elite_factor_t(pop, local_order, state.mean, state.sigma, sqrt_w_local, ws, out=packed[nn:nn + self.dim])
-                _b16.gram(ws, gram_out)
+                if native:
+                    _b16.gram_packed(ws, gram_out)
+                else:
+                    _b16.gram(ws, gram_out)
             else:
                 S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)
                 packed[nn:nn + self.dim] = step_sum
@@ -439,8 +444,8 @@ class CMAES(Algorithm):
             consts["calls"] += 1
             if consts["calls"] % 64 == 0 and float(overflow) > 0:
                 raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(overflow)} rank(s)")
-            gram = packed[:nn].view(self.dim, self.dim)
-            if self._native_calls and self._bf16_kernels and ws is not None:
+            gram = packed[:nn] if native else packed[:nn].view(self.dim, self.dim)
+            if native and ws is not None:
                 # everything after the all-reduce — whitening, paths, covariance, factorisation — in one native call;
                 # an overflow turns the covariance into NaNs there, on every rank alike
                 return self._tell_native(state, None, reduced=(packed[nn:nn + self.dim], gram, packed[nn + self.dim:]), ws=ws)

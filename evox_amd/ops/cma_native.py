@@ -43,7 +43,7 @@ class _Tell(ctypes.Structure):
                 ("B_o", c_void_p), ("inv_o", c_void_p), ("b16_o", c_void_p), ("ctrl_vec_o", c_void_p), ("rec_o", c_void_p),
                 ("factor", c_int), ("ns_iters", c_int), ("ns_power", c_int), ("ns_safe", c_int), ("ns_symmetric", c_int),
                 ("ns_cond", c_int), ("ns_first_poly4", c_int), ("ns_tune", c_int), ("rec_host", c_void_p),
-                ("sharded", c_int), ("gram", c_void_p), ("poison", c_void_p)]
+                ("sharded", c_int), ("gram", c_void_p), ("poison", c_void_p), ("gram_packed", c_int)]
 
 
 _native.register_hip_api({
@@ -193,7 +193,7 @@ class Generation:
         """Returns ``(mean, ps, pc, sigma, C, B, invsqrtC, b16, ctrl_vec, rec)``; the last five are ``None`` when the
         factorisation is skipped (``b16`` also when the fp32 library driver ran).
 
-        ``reduced = (step_sum, gram, poison | None)``: the row-sharded form — the selected rows have been reduced on every
+        ``reduced = (step_sum, gram, poison | None)`` (``gram``: (n, n), or flat = its tile-packed upper triangle): the row-sharded form — the selected rows have been reduced on every
         rank and summed over the ranks already; the call then starts at the whitening product (``fitness`` is unused)."""
         ws, t = self.ws, self._tell
         n, dev = ws.n, ws.device
@@ -205,12 +205,16 @@ class Generation:
         C_o = torch.empty((n, n), dtype=torch.float32, device=dev)
         pop = state.population
         if reduced is None:
-            t.sharded, t.gram, t.poison = 0, None, None
+            t.sharded, t.gram, t.poison, t.gram_packed = 0, None, None, 0
             t.step = self.vecs.data_ptr()
             t.fitness, t.pop, t.ldpop = fitness.data_ptr(), pop.data_ptr(), pop.stride(0)
         else:
             step_sum, gram, poison = reduced
             t.sharded, t.gram, t.step = 1, gram.data_ptr(), step_sum.data_ptr()
+            # a flat vector is the tile-packed upper triangle (``ops/cma_bf16.py::gram_packed``), a matrix the full square
+            t.gram_packed = int(gram.dim() == 1)
+            if gram.dim() == 1 and gram.numel() != _b16.packed_upper_floats(n):
+                raise ValueError("packed Gram matrix of the wrong size")
             t.poison = poison.data_ptr() if poison is not None else None
         t.mean, t.ps, t.pc, t.sigma = state.mean.data_ptr(), state.ps.data_ptr(), state.pc.data_ptr(), state.sigma.data_ptr()
         t.C, t.B, t.invsqrtC, t.iter_dev = state.C.data_ptr(), state.B.data_ptr(), state.invsqrtC.data_ptr(), state.count_iter_dev.data_ptr()

@@ -1477,3 +1477,41 @@ def test_stochastic_ranking_with_fresh_coins_equals_host_twin(cuda, n):
     ref = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
     assert torch.equal(got.cpu(), ref)
     assert sorted(got.tolist()) == list(range(n))
+
+
+@pytest.mark.parametrize("n,mu", [(1000, 5632), (64, 128), (260, 300)])
+def test_packed_gram_equals_full_gram(cuda, n, mu):
+    """The tile-packed upper triangle of the rank-mu product — what the ranks of a multi-process job sum — unpacks to the
+    full Gram matrix bit for bit, and the covariance built from it equals the one built from the full matrix."""
+    from evox_amd.ops import cma_bf16 as b16
+
+    lam = mu + 64
+    g = torch.Generator(device="cuda").manual_seed(n)
+    ws = b16.Workspace(n, lam, mu, torch.device(cuda))
+    pop = torch.randn(lam, n, device=cuda, generator=g)
+    order = torch.randperm(lam, device=cuda, generator=g)[:mu]
+    mean = torch.randn(n, device=cuda, generator=g) * 0.1
+    scale = torch.rand(mu, device=cuda, generator=g)
+    b16.elite_factor_t(pop, order, mean, torch.tensor(0.7, device=cuda), scale, ws)
+    full = torch.empty(n, n, device=cuda)
+    b16.gram(ws, full)
+    packed = torch.full((b16.packed_upper_floats(n),), float("nan"), device=cuda)
+    b16.gram_packed(ws, packed)
+    assert torch.isfinite(packed).all()
+    assert torch.equal(b16.unpack_upper(packed, n), full)
+    # covariance from the packed form against alpha C + c1 pc pc^T + cmu G
+    from evox_amd.ops._util import check, hip, stream_of
+    C = torch.randn(n, n, device=cuda, generator=g)
+    C = C @ C.T / n
+    pc = torch.randn(n, device=cuda, generator=g)
+    alpha = torch.tensor([0.9], device=cuda)
+    out = torch.empty(n, n, device=cuda)
+    check(hip().evox_hip_cov_from_packed(packed.data_ptr(), n, C.data_ptr(), pc.data_ptr(), alpha.data_ptr(), 0.01, 0.2, None,
+                                         out.data_ptr(), stream_of(out)), "cov_from_packed")
+    ref = 0.9 * C + 0.01 * torch.outer(pc, pc) + 0.2 * full
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert torch.equal(out, out.T)
+    poison = torch.ones(1, device=cuda)
+    check(hip().evox_hip_cov_from_packed(packed.data_ptr(), n, C.data_ptr(), pc.data_ptr(), alpha.data_ptr(), 0.01, 0.2,
+                                         poison.data_ptr(), out.data_ptr(), stream_of(out)), "cov_from_packed")
+    assert torch.isnan(out).all()
