@@ -439,7 +439,12 @@ class CMAES(Algorithm):
                 S, step_sum = _cma.elite_factor(pop, local_order, state.mean, state.sigma, sqrt_w_local, self.precision)
                 packed[nn:nn + self.dim] = step_sum
                 _gemm.gram(S, out=gram_out)
-            packed = dist.all_reduce_(packed)
+            reduced = dist.all_reduce_begin(packed)
+            if native and world > 1:
+                # the next generation's Gaussian draws depend on the key alone: issued now, they run underneath the
+                # all-reduce (which keeps only a few compute units busy) instead of after the tell
+                self._generation(ws).draw_ahead(state.key, local, rank * local)
+            packed = reduced.wait()
             overflow = packed[nn + self.dim]
             consts["calls"] += 1
             if consts["calls"] % 64 == 0 and float(overflow) > 0:

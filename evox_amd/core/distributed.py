@@ -178,6 +178,34 @@ def all_reduce_(x: torch.Tensor, group=None) -> torch.Tensor:
     return x
 
 
+class _Reduced:
+    """Handle of :func:`all_reduce_begin`: ``wait()`` returns the reduced tensor (on the RCCL path it makes the current
+    stream wait for the collective; the host does not block)."""
+
+    def __init__(self, result, work=None):
+        self._result, self._work = result, work
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._result
+
+
+def all_reduce_begin(x: torch.Tensor, group=None) -> _Reduced:
+    """Start the sum all-reduce of the message buffer ``x`` (overwritten, like :func:`all_reduce_`) and return a handle.
+    On the RCCL path the collective runs on the communicator's stream: kernels issued on the current stream before
+    ``wait()`` — work that does not depend on the result — overlap with it.  The other paths (single process, host
+    staging for gloo, peer-to-peer kernels) complete here and hand back a finished handle."""
+    if not is_dist_initialized() or get_world_size() == 1:
+        return _Reduced(x)
+    p2p_group = _p2p_group(x) if (group is None and x.dtype == torch.float32) else None
+    if p2p_group is not None or _via_host(x) or not x.is_cuda:
+        return _Reduced(all_reduce_(x, group))
+    x = x if x.is_contiguous() else x.contiguous()
+    return _Reduced(x, _dist().all_reduce(x, group=group, async_op=True))
+
+
 def broadcast(x: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if not is_dist_initialized() or get_world_size() == 1:
         return x

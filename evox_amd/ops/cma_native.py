@@ -159,7 +159,7 @@ class Generation:
         if ahead is not None and ahead[0] is key and ahead[3] == (rows, row_offset):
             keys_out, zi = ahead[1], ahead[2]
             a.split = a.draw = 0
-            a.wait_side = 1
+            a.wait_side = int(ahead[4])
         else:
             keys_out, zi = torch.empty((2, 2), dtype=torch.int32, device=dev), ws._z_next
             a.split = a.draw = 1
@@ -185,9 +185,25 @@ class Generation:
                 a.side, a.ev_main, a.ev_side = self._side.cuda_stream, self._events[0], self._events[1]
             keys_next = torch.empty((2, 2), dtype=torch.int32, device=dev)
             a.prefetch, a.keys_next, a.z_next = 1, keys_next.data_ptr(), ws._Z[zi ^ 1].data_ptr()
-            self._ahead = (next_key, keys_next, zi ^ 1, (rows, row_offset))
+            self._ahead = (next_key, keys_next, zi ^ 1, (rows, row_offset), True)
         check(hip().evox_hip_cma_ask(ctypes.addressof(a), stream_of(mean)), "cma_ask")
         return out, next_key, count_out
+
+    def draw_ahead(self, key, rows: int, row_offset: int) -> None:
+        """Split ``key`` and draw the Gaussian numbers of the generation that the next ``ask(key, ...)`` will sample —
+        now, on the current stream.  They depend on the key alone, so a caller that is about to wait for something else
+        (the all-reduce of a multi-process generation) issues them first and lets them run underneath.  The next ``ask``
+        uses them when it gets this very key tensor and the same row window; otherwise it draws on the spot (same values)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        ws = self.ws
+        zi = ws._z_next ^ 1
+        keys_next = torch.empty((2, 2), dtype=torch.int32, device=ws.device)
+        stream = stream_of(key)
+        check(hip().evox_hip_split(key.data_ptr(), keys_next.data_ptr(), 1, 2, stream), "split")
+        check(hip().evox_hip_normal_bf16_pitched(keys_next.data_ptr() + 8, ws._Z[zi].data_ptr(), rows, ws.n, ws.ldn,
+                                                 row_offset, stream), "normal_bf16")
+        self._ahead = (key, keys_next, zi, (rows, row_offset), False)
 
     def tell(self, state, fitness, factor: bool, plan: dict | None, reduced=None):
         """Returns ``(mean, ps, pc, sigma, C, B, invsqrtC, b16, ctrl_vec, rec)``; the last five are ``None`` when the
