@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from ...ops._util import pick
 from ... import _native
 from ...core import random as rnd
 from ...core.state import State
@@ -208,7 +209,7 @@ class HypE(MOAlgorithm):
         key, k_hv = rnd.split(state.key)
         rank = non_dominated_sort(obj, until=self.pop_size)
         order = torch.argsort(rank, stable=True)
-        cut_rank = rank[order[self.pop_size - 1]]
+        cut_rank = pick(rank, order[self.pop_size - 1])
         mask = rank == cut_rank
         # k = the number of points that will be removed, as in the HypE paper (the reference passes k = n, ``hype.py:136``,
         # which weights a sample dominated by j points with 1/j whatever j is)

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import torch
 
+from ...ops._util import count_groups, pick
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import selection
@@ -151,7 +152,7 @@ def theta_nd_sort(obj, w, mask):
     grouped = by_score[torch.argsort(cls[by_score], stable=True)]
     g = cls[grouped]
     start = torch.zeros(nw + 1, dtype=torch.int64, device=obj.device)
-    start[1:] = torch.cumsum(torch.bincount(g, minlength=nw), 0)
+    start[1:] = torch.cumsum(count_groups(g, nw), 0)
     level = torch.empty(n, dtype=torch.int64, device=obj.device)
     level[grouped] = ar - start[g] + 1
     return torch.where(mask, level.to(torch.float32), torch.full((n,), float("inf"), device=obj.device))
@@ -180,7 +181,7 @@ class TDEA(MOAlgorithm):
         m, n = self.n_objs, self.pop_size
         rank = non_dominated_sort(obj, until=n)
         order = torch.argsort(rank, stable=True)
-        mask = rank <= rank[order[n - 1]]
+        mask = rank <= pick(rank, order[n - 1])
         z = torch.minimum(state.z, obj.amin(0))
         w1 = torch.full((m, m), 1e-6, device=obj.device) + torch.eye(m, device=obj.device) * (1 - 1e-6)
         scaled = ((obj - z) / (state.z_nad - z)).abs()

@@ -6,6 +6,7 @@ import math
 
 import torch
 
+from ...ops._util import count_groups, pick
 from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
@@ -71,6 +72,14 @@ class EAGMOEAD(MOAlgorithm):
         nxt = self._vary(k_x, k_mut, mates)
         return nxt, state.replace(next_generation=nxt, offspring_loc=loc, key=key)
 
+    # a recorded generation: ``gen`` only selects the column of the success history it rewrites, so it may wrap at LGs,
+    # and every column has its own recording
+    def graph_host_counters(self):
+        return (("gen", self.LGs),)
+
+    def graph_variant(self, state):
+        return (state.gen + 1) % self.LGs
+
     def tell(self, state, fitness):
         gen = state.gen + 1
         n = self.pop_size
@@ -134,7 +143,7 @@ def m2m_associate(key, pop, obj, w, s):
     region = torch.argmax(cos_dist(obj, w), dim=1)
     rank = non_dominated_sort(obj)
     filler = rnd.randint(key, (k, s), 0, n)
-    cnt = torch.bincount(region, minlength=k)
+    cnt = count_groups(region, k)
     start = torch.cumsum(cnt, 0) - cnt
     by_rank = torch.argsort(rank, stable=True)
     by_rank = by_rank[torch.argsort(region[by_rank], stable=True)]          # grouped by region, ascending front index
@@ -170,7 +179,7 @@ def m2m_associate_reference(key, pop, obj, w, s):
         else:
             r = torch.where(mask, rank, torch.full_like(rank, float("inf")))
             order = torch.argsort(r, stable=True)
-            worst = r[order[s - 1]]
+            worst = pick(r, order[s - 1])
             cd = crowding_distance(obj, r == worst)
             tie = torch.where(r == worst, -cd, torch.zeros_like(cd))
             idx = torch.argsort(tie, stable=True)

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 
+from ...ops._util import count_groups, pick
 from ... import _native
 from ...core import random as rnd
 from ...core.state import State
@@ -102,7 +103,7 @@ class NSGA3(MOAlgorithm):
         n, k_total = fit.shape[0], self.pop_size
         rank = non_dominated_sort(fit, until=k_total)
         order = torch.argsort(rank, stable=True)
-        last_rank = rank[order[k_total - 1]]
+        last_rank = pick(rank, order[k_total - 1])
         considered = rank <= last_rank
         norm = self._normalise(fit, considered)
         cosine = cos_dist(norm, self.ref).clamp(-1, 1)
@@ -128,7 +129,7 @@ class NSGA3(MOAlgorithm):
         by_group = by_inner[torch.argsort(group[by_inner], stable=True)]           # grouped, inner-sorted
         g_sorted = group[by_group]
         start = torch.zeros(nref + 1, dtype=torch.int64, device=fit.device)
-        start[1:] = torch.cumsum(torch.bincount(g_sorted, minlength=nref), 0)
+        start[1:] = torch.cumsum(count_groups(g_sorted, nref), 0)
         pos_sorted = torch.arange(n, device=fit.device) - start[g_sorted]
         pos = torch.empty(n, dtype=torch.int64, device=fit.device)
         pos[by_group] = pos_sorted

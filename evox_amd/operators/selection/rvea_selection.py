@@ -30,7 +30,7 @@ def _select_fused(x, f, obj, v, theta):
                                        best.data_ptr(), _stream_of(f)), "rvea_select")
     empty = best == -1
     next_ind = torch.where(empty, torch.zeros_like(best), best & 0xFFFFFFFF)
-    nan = torch.tensor(float("nan"), device=f.device)
+    nan = f.new_full((), float("nan"))
     return torch.where(empty[:, None], nan, x[next_ind]), torch.where(empty[:, None], nan, f[next_ind])
 
 

@@ -37,3 +37,16 @@ def check(status, what):
 
 
 DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def pick(x: torch.Tensor, i: torch.Tensor) -> torch.Tensor:
+    """``x[i]`` for a 0-d index tensor without the host read that tensor indexing does for it (so the expression can be
+    recorded into a HIP graph)."""
+    return x.index_select(0, i.reshape(1))[0]
+
+
+def count_groups(group: torch.Tensor, n_groups: int) -> torch.Tensor:
+    """``torch.bincount(group, minlength=n_groups)`` for indices known to lie in ``[0, n_groups)``, without the host
+    read by which ``bincount`` sizes its result (so the expression can be recorded into a HIP graph)."""
+    out = torch.zeros(n_groups, dtype=torch.int64, device=group.device)
+    return out.index_add_(0, group, torch.ones_like(group, dtype=torch.int64))

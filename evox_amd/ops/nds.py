@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from .. import _native
-from ._util import check, hip, on_gpu, stream_of
+from ._util import pick, check, hip, on_gpu, stream_of
 
 
 def _has(symbol: str) -> bool:
@@ -106,7 +106,7 @@ def crowding_distance_reference(costs: torch.Tensor, mask: Optional[torch.Tensor
     order = torch.argsort(keyed, dim=0, stable=True)                       # (n, m)
     sorted_c = torch.gather(keyed, 0, order)
     last = (nvalid - 1).clamp_min(0)
-    span = sorted_c[last] - sorted_c[0]                                    # (m,)
+    span = pick(sorted_c, last) - sorted_c[0]                              # (m,)
     gaps = torch.zeros_like(sorted_c)
     gaps[1:-1] = (sorted_c[2:] - sorted_c[:-2]) / span
     pos = torch.arange(n, device=dev)[:, None]
@@ -165,6 +165,14 @@ def rank_crowding_select(fit: torch.Tensor, k: int) -> torch.Tensor:
         from . import _nds_hip
         from . import sort as _sort
 
+        if _nds_hip.supported(fit) and k < n and torch.cuda.is_current_stream_capturing():
+            # recording into a HIP graph: nothing may come back to the host.  Populations that the one-launch sort takes
+            # (merged size <= 1024) are ranked without a read-back and truncated by tensor ops; larger ones need the
+            # peeling loop's progress on the host and cannot be recorded
+            if n > _nds_hip._SMALL_MAX_N:
+                raise RuntimeError(f"a non-dominated sort of {n} > {_nds_hip._SMALL_MAX_N} points reads its progress "
+                                   "back to the host and cannot be recorded into a graph")
+            return _truncate_from_rank(fit, _nds_hip.rank(fit, until=k), k)
         if _nds_hip.supported(fit) and k < n:
             rank, (cut, n_before, cut_size) = _nds_hip.rank(fit, until=k, with_info=True)
             need = k - n_before
@@ -182,7 +190,7 @@ def rank_crowding_select(fit: torch.Tensor, k: int) -> torch.Tensor:
 
 def _truncate_from_rank(fit, rank, k):
     order = torch.argsort(rank, stable=True)
-    worst = rank[order[k - 1]]
+    worst = pick(rank, order[k - 1])
     mask = rank == worst
     dist = crowding_distance(fit, mask)
     key2 = torch.where(mask, -dist, torch.zeros_like(dist))

@@ -1515,3 +1515,32 @@ def test_packed_gram_equals_full_gram(cuda, n, mu):
     check(hip().evox_hip_cov_from_packed(packed.data_ptr(), n, C.data_ptr(), pc.data_ptr(), alpha.data_ptr(), 0.01, 0.2,
                                          poison.data_ptr(), out.data_ptr(), stream_of(out)), "cov_from_packed")
     assert torch.isnan(out).all()
+
+
+@pytest.mark.parametrize("name", ["NSGA2", "NSGA3", "GDE3", "TDEA", "HypE", "MOEAD", "IBEA", "BiGE", "EAGMOEAD"])
+def test_multi_objective_generation_replays_from_a_graph(cuda, name):
+    """A generation of these algorithms has no host read at the usual population sizes (the merged population is sorted
+    by the one-launch kernel, cuts and counts stay on the device): it is recorded once and replayed, and every replay
+    equals the eager generation."""
+    import evox_amd as ex
+    from evox_amd import algorithms, workflows
+    from evox_amd.core.tree import tree_leaves
+    from evox_amd.problems.numerical import DTLZ2
+
+    def build(graph):
+        algo = getattr(algorithms, name)(lb=torch.zeros(12, device=cuda), ub=torch.ones(12, device=cuda), n_objs=3, pop_size=100)
+        return workflows.StdWorkflow(algo, DTLZ2(m=3), graph_step=graph)
+
+    eager, graphed = build(False), build(True)
+    se, sg = eager.init(ex.PRNGKey(3).to(cuda)), graphed.init(ex.PRNGKey(3).to(cuda))
+    for step in range(24):
+        se, sg = eager.step(se), graphed.step(sg)
+        torch.cuda.synchronize()
+        scratch = torch.randn(128, 128, device=cuda).sum()                   # eager work between the replays
+        assert torch.isfinite(scratch)
+        fe, fg = se.get_child_state("algorithm").fitness, sg.get_child_state("algorithm").fitness
+        assert torch.equal(fe, fg), (name, step)
+    assert graphed._graphed and graphed.graph_replays >= 10
+    for a, b in zip(tree_leaves(se), tree_leaves(sg)):
+        if isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
