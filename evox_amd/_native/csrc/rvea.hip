@@ -20,6 +20,7 @@ namespace {
 template <int M, bool SELF>
 __global__ __launch_bounds__(256) void rvea_assoc_kernel(const float* __restrict__ rows, int n, const float* __restrict__ vn,
                                                          int nv, const float* __restrict__ gamma, float m_theta,
+                                                         const float* __restrict__ theta_dev,
                                                          float* __restrict__ gamma_out,
                                                          unsigned long long* __restrict__ best) {
   __shared__ float tile[M][256];
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(256) void rvea_assoc_kernel(const float* __restrict
   }
   if (bad || best_j == 0x7fffffff) return;
   const float angle = 2.0f * asinf(0.5f * sqrtf(best_d));
-  float apd = (1.0f + m_theta * angle / gamma[best_j]) * sqrtf(norm2);
+  // the penalty weight M·θ comes as a launch argument or — θ on the device, e.g. computed from a generation counter that a
+  // recorded graph advances — is read here
+  const float mt = theta_dev ? (float)M * theta_dev[0] : m_theta;
+  float apd = (1.0f + mt * angle / gamma[best_j]) * sqrtf(norm2);
   if (apd != apd) apd = INFINITY;
   // non-negative floats order like their bit patterns; ties go to the smaller solution index
   const unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf(apd, 0.f)) << 32) | (unsigned int)i;
@@ -77,10 +81,10 @@ __global__ __launch_bounds__(256) void rvea_assoc_kernel(const float* __restrict
 }
 
 template <int M>
-int launch(const float* obj, int n, const float* vn, int nv, float m_theta, float* gamma, unsigned long long* best,
-           hipStream_t st) {
-  rvea_assoc_kernel<M, true><<<(nv + 63) / 64, 256, 0, st>>>(vn, nv, vn, nv, nullptr, 0.f, gamma, nullptr);
-  rvea_assoc_kernel<M, false><<<(n + 63) / 64, 256, 0, st>>>(obj, n, vn, nv, gamma, m_theta, nullptr, best);
+int launch(const float* obj, int n, const float* vn, int nv, float m_theta, const float* theta_dev, float* gamma,
+           unsigned long long* best, hipStream_t st) {
+  rvea_assoc_kernel<M, true><<<(nv + 63) / 64, 256, 0, st>>>(vn, nv, vn, nv, nullptr, 0.f, nullptr, gamma, nullptr);
+  rvea_assoc_kernel<M, false><<<(n + 63) / 64, 256, 0, st>>>(obj, n, vn, nv, gamma, m_theta, theta_dev, nullptr, best);
   return last_launch_status();
 }
 
@@ -89,19 +93,31 @@ int launch(const float* obj, int n, const float* vn, int nv, float m_theta, floa
 // obj: (n, m) objectives minus the ideal point, clamped positive, NaN rows allowed; vn: (nv, m) unit reference
 // vectors; gamma: scratch (nv); best: (nv) 64-bit words preset to all ones — on return the low 32 bits of
 // best[v] hold the selected solution, all ones where no solution is associated with v.
-EVOX_API int evox_hip_rvea_select(const float* obj, int n, const float* vn, int nv, int m, float theta, float* gamma,
-                                  unsigned long long* best, void* stream) {
+static int rvea_select_any(const float* obj, int n, const float* vn, int nv, int m, float theta, const float* theta_dev,
+                           float* gamma, unsigned long long* best, void* stream) {
   if (n <= 0 || nv <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const float mt = (float)m * theta;
   switch (m) {
-    case 2: return launch<2>(obj, n, vn, nv, mt, gamma, best, st);
-    case 3: return launch<3>(obj, n, vn, nv, mt, gamma, best, st);
-    case 4: return launch<4>(obj, n, vn, nv, mt, gamma, best, st);
-    case 5: return launch<5>(obj, n, vn, nv, mt, gamma, best, st);
-    case 6: return launch<6>(obj, n, vn, nv, mt, gamma, best, st);
-    case 7: return launch<7>(obj, n, vn, nv, mt, gamma, best, st);
-    case 8: return launch<8>(obj, n, vn, nv, mt, gamma, best, st);
+    case 2: return launch<2>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 3: return launch<3>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 4: return launch<4>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 5: return launch<5>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 6: return launch<6>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 7: return launch<7>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    case 8: return launch<8>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+EVOX_API int evox_hip_rvea_select(const float* obj, int n, const float* vn, int nv, int m, float theta, float* gamma,
+                                  unsigned long long* best, void* stream) {
+  return rvea_select_any(obj, n, vn, nv, m, theta, nullptr, gamma, best, stream);
+}
+
+// The same with the angle-penalty weight θ read from the device (one float).
+EVOX_API int evox_hip_rvea_select_dev(const float* obj, int n, const float* vn, int nv, int m, const float* theta,
+                                      float* gamma, unsigned long long* best, void* stream) {
+  if (theta == nullptr) return (int)hipErrorInvalidValue;
+  return rvea_select_any(obj, n, vn, nv, m, 0.f, theta, gamma, best, stream);
 }

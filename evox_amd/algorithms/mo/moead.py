@@ -138,6 +138,13 @@ class MOEADDRA(MOAlgorithm):
         nxt = torch.clamp(nxt, self.lb, self.ub)
         return nxt, state.replace(next_generation=nxt, choosed_p=choosed, key=key, I_all=I_all)
 
+    # recorded generations: the counter only decides which generations refresh the utilities (every tenth)
+    def graph_host_counters(self):
+        return (("gen", 10),)
+
+    def graph_variant(self, state):
+        return (state.gen + 1) % 10 == 0
+
     def tell(self, state, fitness):
         gen = state.gen + 1
         w, p = state.weight_vector, state.choosed_p

@@ -46,7 +46,21 @@ class RVEA(MOAlgorithm):
 
     def setup(self, key):
         f = self._base_fields(key)
-        return State(reference_vector=self._v0, init_v=self._v0, gen=0, **f)
+        # the generation number twice: as a host integer (which generations adapt the vectors is control flow) and on the
+        # device, where the angle-penalty weight is computed from it — a recorded generation then follows the counter
+        return State(reference_vector=self._v0, init_v=self._v0, gen=0, gen_dev=torch.zeros((), device=self.device), **f)
+
+    def _theta(self, gen_dev):
+        return (gen_dev / self.max_gen) ** self.alpha
+
+    # recorded generations: the host counter only decides which generations adapt the reference vectors
+    def graph_host_counters(self):
+        period = round(1 / self.fr)
+        return (("gen", period),) if period > 0 else ("gen",)
+
+    def graph_variant(self, state):
+        period = round(1 / self.fr)
+        return period > 0 and (state.gen + 1) % period == 0
 
     def _mating_pool(self, key, population, n):
         order, count = _valid_first(population)
@@ -66,11 +80,11 @@ class RVEA(MOAlgorithm):
         return v
 
     def tell(self, state, fitness):
-        gen = state.gen + 1
+        gen, gen_dev = state.gen + 1, state.gen_dev + 1
         pop, fit = self._merged(state, fitness)
-        survivors, survivor_fit = self.selection(pop, fit, state.reference_vector, (gen / self.max_gen) ** self.alpha)
+        survivors, survivor_fit = self.selection(pop, fit, state.reference_vector, self._theta(gen_dev))
         v = self._adapt(gen, survivor_fit, state.reference_vector, state.init_v)
-        return state.replace(population=survivors, fitness=survivor_fit, reference_vector=v, gen=gen)
+        return state.replace(population=survivors, fitness=survivor_fit, reference_vector=v, gen=gen, gen_dev=gen_dev)
 
 
 def rv_regeneration(pop_obj, v, key):
@@ -80,8 +94,7 @@ def rv_regeneration(pop_obj, v, key):
     cosine = cos_dist(torch.where(torch.isnan(obj), torch.zeros_like(obj), obj), v)
     cosine = torch.where(torch.isnan(pop_obj).any(1, keepdim=True), torch.full_like(cosine, -1.0), cosine)
     associate = torch.argmax(cosine, dim=1)
-    used = torch.zeros(v.shape[0], dtype=torch.bool, device=v.device)
-    used[associate] = True
+    used = torch.zeros(v.shape[0], dtype=torch.bool, device=v.device).index_fill_(0, associate, True)
     fresh = rnd.uniform(key, v.shape) * _nan_amax(obj)
     return torch.where(used[:, None], v, fresh)
 
@@ -117,7 +130,7 @@ class RVEAa(RVEA):
         f["population"] = pop
         f["fitness"] = torch.zeros((n2, self.n_objs), device=self.device)
         f["next_generation"] = f["next_generation"]
-        return State(reference_vector=v, init_v=self._v0, gen=0, **f)
+        return State(reference_vector=v, init_v=self._v0, gen=0, gen_dev=torch.zeros((), device=self.device), **f)
 
     def init_ask(self, state):
         return state.population[: self.pop_size], state
@@ -133,7 +146,7 @@ class RVEAa(RVEA):
         return nxt, state.replace(next_generation=nxt, key=key)
 
     def tell(self, state, fitness):
-        gen = state.gen + 1
+        gen, gen_dev = state.gen + 1, state.gen_dev + 1
         key, k_rv = rnd.split(state.key)
         pop = torch.cat([state.population, state.next_generation], dim=0)
         fit = torch.cat([state.fitness, fitness], dim=0)
@@ -143,12 +156,12 @@ class RVEAa(RVEA):
         fit_f = torch.where(front[:, None], fit, torch.full_like(fit, float("nan")))
         pop_f = torch.where(front[:, None], pop, torch.full_like(pop, float("nan")))
         v = state.reference_vector
-        survivors, survivor_fit = ref_vec_guided(pop_f, fit_f, v, (gen / self.max_gen) ** self.alpha)
+        survivors, survivor_fit = ref_vec_guided(pop_f, fit_f, v, self._theta(gen_dev))
         n0 = self._v0.shape[0]
         v_main = self._adapt(gen, survivor_fit, v[:n0], state.init_v)
         v_extra = rv_regeneration(survivor_fit, v[n0:], k_rv)
         return state.replace(population=survivors, fitness=survivor_fit, reference_vector=torch.cat([v_main, v_extra]),
-                             gen=gen, key=key)
+                             gen=gen, gen_dev=gen_dev, key=key)
 
     def final_population(self, state):
         """First-front, angularly truncated population of size ``pop_size`` (call after the run)."""

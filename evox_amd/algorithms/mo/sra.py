@@ -102,7 +102,7 @@ class LMOCSO(MOAlgorithm):
         f = self._base_fields(key)
         f["fitness"] = torch.full((self.pop_size, self.n_objs), float("inf"), device=self.device)
         return State(velocity=torch.zeros((self.pop_size // 2 * 2, self.dim), device=self.device),
-                     reference_vector=self._v, gen=0, **f)
+                     reference_vector=self._v, gen=0, gen_dev=torch.zeros((), device=self.device), **f)
 
     def ask(self, state):
         key, k_mate, k_pair, k_r, k_mut = rnd.split(state.key, 5)
@@ -128,9 +128,12 @@ class LMOCSO(MOAlgorithm):
         return nxt, state.replace(next_generation=nxt, velocity=velocity, key=key)
 
     def tell(self, state, fitness):
-        gen = state.gen + 1
+        gen, gen_dev = state.gen + 1, state.gen_dev + 1          # the device copy feeds the angle penalty (graph replay)
         pop = torch.cat([state.population, state.next_generation])
         fit = torch.cat([state.fitness, fitness])
         fit = torch.where(torch.isinf(fit), torch.full_like(fit, float("nan")), fit)
-        survivors, survivor_fit = self.selection(pop, fit, state.reference_vector, (gen / self.max_gen) ** self.alpha)
-        return state.replace(population=survivors, fitness=survivor_fit, gen=gen)
+        survivors, survivor_fit = self.selection(pop, fit, state.reference_vector, (gen_dev / self.max_gen) ** self.alpha)
+        return state.replace(population=survivors, fitness=survivor_fit, gen=gen, gen_dev=gen_dev)
+
+    def graph_host_counters(self):
+        return ("gen",)

@@ -12,7 +12,9 @@ from ...ops._util import stream_of as _stream_of
 from ...utils.common import cos_dist
 
 _native.register_hip_api({"evox_hip_rvea_select": (_native.I, [_native.P, _native.I, _native.P, _native.I, _native.I, _native.F,
-                                                              _native.P, _native.P, _native.P])})
+                                                              _native.P, _native.P, _native.P]),
+                          "evox_hip_rvea_select_dev": (_native.I, [_native.P, _native.I, _native.P, _native.I, _native.I,
+                                                                  _native.P, _native.P, _native.P, _native.P])})
 
 
 def _fused_ok(f, v) -> bool:
@@ -26,8 +28,14 @@ def _select_fused(x, f, obj, v, theta):
     vn = (v / torch.linalg.vector_norm(v, dim=-1, keepdim=True)).contiguous()
     gamma = torch.empty(nv, dtype=torch.float32, device=f.device)
     best = torch.full((nv,), -1, dtype=torch.int64, device=f.device)          # all ones = no solution yet
-    _check(_hip().evox_hip_rvea_select(obj.contiguous().data_ptr(), n, vn.data_ptr(), nv, m, float(theta), gamma.data_ptr(),
-                                       best.data_ptr(), _stream_of(f)), "rvea_select")
+    if isinstance(theta, torch.Tensor):
+        # θ on the device (one float, e.g. a function of a device-side generation counter): no host value enters the launch
+        th = theta.reshape(1).to(device=f.device, dtype=torch.float32)
+        _check(_hip().evox_hip_rvea_select_dev(obj.contiguous().data_ptr(), n, vn.data_ptr(), nv, m, th.data_ptr(),
+                                               gamma.data_ptr(), best.data_ptr(), _stream_of(f)), "rvea_select")
+    else:
+        _check(_hip().evox_hip_rvea_select(obj.contiguous().data_ptr(), n, vn.data_ptr(), nv, m, float(theta), gamma.data_ptr(),
+                                           best.data_ptr(), _stream_of(f)), "rvea_select")
     empty = best == -1
     next_ind = torch.where(empty, torch.zeros_like(best), best & 0xFFFFFFFF)
     nan = f.new_full((), float("nan"))
@@ -39,7 +47,7 @@ def ref_vec_guided(x, f, v, theta):
     nv = v.shape[0]
     fmin = torch.where(torch.isnan(f), torch.full_like(f, float("inf")), f).amin(0)
     obj = (f - fmin).clamp_min(1e-32)
-    if _fused_ok(f, v) and not isinstance(theta, torch.Tensor):
+    if _fused_ok(f, v):
         return _select_fused(x, f, obj, v, theta)
     return _ref_vec_guided_dense(x, f, obj, v, theta)
 
@@ -63,7 +71,7 @@ def _ref_vec_guided_dense(x, f, obj, v, theta):
     apd = torch.where(torch.isnan(apd), torch.full_like(apd, float("inf")), apd)
     next_ind = torch.argmin(apd, dim=0)                                            # (nv,)
     empty = ~member.any(0)
-    nan = torch.tensor(float("nan"), device=f.device)
+    nan = f.new_full((), float("nan"))
     next_x = torch.where(empty[:, None], nan, x[next_ind])
     next_f = torch.where(empty[:, None], nan, f[next_ind])
     return next_x, next_f
