@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void cov_reduce_kernel(const float* __restrict
         const float4 t = *reinterpret_cast<const float4*>(ws + s * slab + e);
         g[0].x += t.x; g[0].y += t.y; g[0].z += t.z; g[0].w += t.w;
       }
-      const float4 cv = *reinterpret_cast<const float4*>(C + e);
+      // alpha = 0 (a plain Gram product): C is not read at all — it may be the uninitialised output buffer itself
+      const float4 cv = a != 0.f ? *reinterpret_cast<const float4*>(C + e) : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 sum = g[0];
 #pragma unroll
       for (int s = 1; s < MAXS; ++s) { sum.x += g[s].x; sum.y += g[s].y; sum.z += g[s].z; sum.w += g[s].w; }

@@ -1493,7 +1493,7 @@ def test_packed_gram_equals_full_gram(cuda, n, mu):
     mean = torch.randn(n, device=cuda, generator=g) * 0.1
     scale = torch.rand(mu, device=cuda, generator=g)
     b16.elite_factor_t(pop, order, mean, torch.tensor(0.7, device=cuda), scale, ws)
-    full = torch.empty(n, n, device=cuda)
+    full = torch.full((n, n), float("nan"), device=cuda)            # the output buffer is write-only: garbage must not leak in
     b16.gram(ws, full)
     packed = torch.full((b16.packed_upper_floats(n),), float("nan"), device=cuda)
     b16.gram_packed(ws, packed)
