@@ -57,3 +57,53 @@ class PSO(Algorithm):
             state.global_best_location, state.global_best_fitness, self.lb, self.ub, self.w, self.phi_p, self.phi_g)
         return state.replace(population=pop, velocity=vel, local_best_location=pbest, local_best_fitness=pbest_fit,
                              global_best_location=gbest, global_best_fitness=gbest_fit, key=key)
+
+    # -- row-sharded protocol (evox_amd.parallel.ShardedWorkflow) ---------------------------
+    # Every rank owns a block of particles — positions, velocities and personal bests — and nothing of the others'.
+    # A generation exchanges the fitness (the workflow's all-gather) and one (1 + dim)-float candidate per rank for the
+    # global best.  The random numbers are addressed by (key, particle, variable), so the swarm moves exactly as in a
+    # single process, for every number of ranks.
+    sharded_fields = ("population", "velocity", "local_best_location", "local_best_fitness")
+
+    def _local_rows(self, state, rank: int, world: int):
+        """The row-local fields cut to this rank's particles (a state that still holds the whole swarm — fresh from
+        ``setup``, or a single-process checkpoint — is cut here, once)."""
+        local = self.pop_size // world
+        if state.population.shape[0] == local:
+            return state
+        lo = rank * local
+        return state.replace(**{name: getattr(state, name)[lo:lo + local].clone() for name in self.sharded_fields})
+
+    def ask_sharded(self, state, rank: int, world: int):
+        if self.pop_size % world:
+            raise ValueError(f"pop_size {self.pop_size} is not divisible by the number of ranks {world}")
+        state = self._local_rows(state, rank, world)
+        return state.population, state
+
+    def tell_sharded(self, state, fitness, rank: int, world: int):
+        from ....core import distributed as dist
+
+        n, d = self.pop_size, self.dim
+        local = n // world
+        lo = rank * local
+        key, k_move = rnd.split(state.key)
+        fit = fitness[lo:lo + local]
+        # rows [lo, lo + local) of the two (n, d) coefficient matrices of the single-process step
+        r_p = rnd.uniform(k_move, (local, d), offset=lo * d)
+        r_g = rnd.uniform(k_move, (local, d), offset=n * d + lo * d)
+        pop = state.population
+        better = fit < state.local_best_fitness
+        pbest = torch.where(better[:, None], pop, state.local_best_location)
+        pbest_fit = torch.where(better, fit, state.local_best_fitness)
+        i = torch.argmin(pbest_fit)
+        mine = torch.cat([pbest_fit.index_select(0, i.reshape(1)), pbest.index_select(0, i.reshape(1)).reshape(-1)])
+        every = dist.all_gather(mine[None, :])                           # (world, 1 + d); ties go to the lowest rank,
+        j = torch.argmin(every[:, 0]).reshape(1)                          # i.e. to the lowest particle index
+        best = every.index_select(0, j)[0]
+        take = best[0] < state.global_best_fitness
+        gbest = torch.where(take, best[1:], state.global_best_location)
+        gbest_fit = torch.where(take, best[:1], state.global_best_fitness).reshape(state.global_best_fitness.shape)
+        vel = self.w * state.velocity + self.phi_p * r_p * (pbest - pop) + self.phi_g * r_g * (gbest - pop)
+        pop = torch.clamp(pop + vel, self.lb, self.ub)
+        return state.replace(population=pop, velocity=vel, local_best_location=pbest, local_best_fitness=pbest_fit,
+                             global_best_location=gbest, global_best_fitness=gbest_fit, key=key)

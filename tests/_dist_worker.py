@@ -32,7 +32,7 @@ def main():
     c = torch.full((dim,), 3.0, device=dev)
     lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}
-    if case in ("cmaes", "cmaes_resync", "cmaes_wide", "openes", "pgpe", "pso_replicated", "ars", "des", "snes", "sepcmaes", "maes"):
+    if case in ("cmaes", "cmaes_resync", "cmaes_wide", "openes", "pgpe", "pso_replicated", "pso", "ars", "des", "snes", "sepcmaes", "maes"):
         algo = {"cmaes_resync": lambda: A.CMAES(c, 1.0, pop_size=16),
                 "cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
                 # local shares wide enough that only the rank-ordered head of the local rows is processed
@@ -42,7 +42,9 @@ def main():
                 "ars": lambda: A.ARS(16, c, elite_ratio=0.5, lr=0.1, sigma=0.1), "des": lambda: A.DES(16, c, sigma_init=0.5),
                 "snes": lambda: A.SNES(16, c, sigma=0.5),
                 "sepcmaes": lambda: A.SepCMAES(c, 1.0, pop_size=16), "maes": lambda: A.MAES(c, 1.0, pop_size=16),
-                "pgpe": lambda: A.PGPE(16, c, "adam"), "pso_replicated": lambda: A.PSO(lb, ub, 16)}[case]()
+                "pgpe": lambda: A.PGPE(16, c, "adam"), "pso": lambda: A.PSO(lb, ub, 16),
+                # an algorithm without the row-sharded protocol: replicated state, sharded evaluation
+                "pso_replicated": lambda: A.CSO(lb, ub, 16)}[case]()
         mon = monitors.EvalMonitor()
         wf = ShardedWorkflow(algo, problems.numerical.Ackley(), monitors=[mon],
                              resync_every=5 if case == "cmaes_resync" else 0)
@@ -54,11 +56,12 @@ def main():
                 a = state.get_child_state("algorithm")
                 state = state.replace_child("algorithm", a.replace(C=a.C * 1.001, sigma=a.sigma * 1.001))
         alg = state.get_child_state("algorithm")
-        vec = alg.mean if case in ("cmaes", "cmaes_resync", "cmaes_wide", "sepcmaes", "maes") else (alg.global_best_location if case == "pso_replicated" else alg.center)
+        vec = alg.mean if case in ("cmaes", "cmaes_resync", "cmaes_wide", "sepcmaes", "maes") else (alg.global_best_location if case == "pso" else (alg.population[0] if case == "pso_replicated" else alg.center))
         result = {"vec": vec.tolist(), "world": state.world_size, "rank": state.rank,
                   "row_sharded": wf.row_sharded, "best": float(mon.get_best_fitness()),
                   "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_resync", "cmaes_wide", "sepcmaes") else None,
-                  "cov": alg.C.reshape(-1).tolist() if case == "cmaes_resync" else None}
+                  "cov": alg.C.reshape(-1).tolist() if case == "cmaes_resync" else None,
+                  "rows": alg.population.tolist() if case == "pso" else None}
     elif case == "sharded_ckpt":
         path = os.environ["EVOX_TEST_CKPT"]
 

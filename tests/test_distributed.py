@@ -95,6 +95,20 @@ def test_resync_brings_a_drifted_replica_back(tmp_path):
     assert res[0]["vec"] == res[1]["vec"] and res[0]["cov"] == res[1]["cov"]
 
 
+def test_row_sharded_pso_is_the_single_process_swarm_bit_for_bit(tmp_path):
+    """Particles dealt out over the ranks: draws are addressed by (key, particle, variable) and every update is
+    row-local, so the ranks' blocks put together ARE the single-process swarm — independent of the number of ranks, to
+    the last bit."""
+    base = launch("pso", 1, tmp_path)[0]
+    for world in (2, 4, 8):
+        res = launch("pso", world, tmp_path)
+        assert all(r["row_sharded"] and r["world"] == world for r in res)
+        rows = [row for r in sorted(res, key=lambda r: r["rank"]) for row in r["rows"]]
+        assert len(res[0]["rows"]) == 16 // world
+        assert rows == base["rows"]
+        assert all(r["vec"] == base["vec"] for r in res)
+
+
 def test_replicated_mode_for_algorithms_without_sharding(tmp_path):
     base = launch("pso_replicated", 1, tmp_path)[0]
     res = launch("pso_replicated", 2, tmp_path)
@@ -237,7 +251,7 @@ def test_process_distributed_workflow_worker_failure_is_reported():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cmaes", "cmaes_wide", "openes"])
+@pytest.mark.parametrize("case", ["cmaes", "cmaes_wide", "openes", "pso"])
 def test_row_sharded_on_gpu_matches_single_process(case, tmp_path):
     """The GPU code path of the row-sharded tell (gather kernel, Gram GEMM, fused path kernel): two
     and four ranks share the one GPU of the test box and talk over gloo."""
