@@ -82,7 +82,10 @@ def rank_sweep(x: torch.Tensor, until: Optional[int] = None, with_info: bool = F
     is_rep = torch.ones(n, dtype=torch.bool, device=dev)
     is_rep[1:] = (xs[1:] != xs[:-1]).any(dim=1)
     idx = torch.arange(n, device=dev)
-    rep_idx = torch.cummax(torch.where(is_rep, idx, torch.zeros_like(idx)), dim=0).values
+    # position of every point's representative: the first point of its group of identical points (group number by a
+    # prefix sum, first member by a scatter-min; the tensor library's running maximum is a slow single-pass scan)
+    gid = torch.cumsum(is_rep, 0) - 1
+    rep_idx = torch.full((n,), n, dtype=torch.int64, device=dev).scatter_reduce_(0, gid, idx, "amin")[gid]
     has_nan = torch.isnan(xs).any().to(torch.int32).reshape(1)
     npad = max(2048, 1 << (n - 1).bit_length())
     levels = npad.bit_length() - 1
@@ -216,8 +219,9 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
 
 
 def crowding(vals: torch.Tensor) -> torch.Tensor:
-    """Crowding distance of the rows of ``vals`` (count ≤ 16384, m), all of one front: one
-    counting-rank launch per objective and one pass that reads each member's two neighbours."""
+    """Crowding distance of the rows of ``vals`` (count, m), all of one front: one stable sort per objective (the
+    counting-rank launch up to 16384 members, the library's sort beyond) and one pass that reads each member's two
+    neighbours."""
     from . import sort as _sort
 
     count, m = vals.shape
@@ -225,8 +229,15 @@ def crowding(vals: torch.Tensor) -> torch.Tensor:
     order = torch.empty((m, count), dtype=torch.int64, device=vals.device)
     rnk = torch.empty((m, count), dtype=torch.int64, device=vals.device)
     lib, s = hip(), stream_of(soa)
-    for k in range(m):
-        check(lib.evox_hip_rank_sort(soa[k].data_ptr(), count, order[k].data_ptr(), rnk[k].data_ptr(), s), "rank_sort")
+    if count <= _sort._RANK_SORT_MAX:
+        for k in range(m):
+            check(lib.evox_hip_rank_sort(soa[k].data_ptr(), count, order[k].data_ptr(), rnk[k].data_ptr(), s), "rank_sort")
+    else:
+        # fronts beyond the counting sort's range: the library's stable sort per objective, ranks by a scatter
+        ar = torch.arange(count, device=vals.device)
+        for k in range(m):
+            order[k] = torch.argsort(soa[k], stable=True)
+            rnk[k].scatter_(0, order[k], ar)
     dist = torch.empty(count, dtype=torch.float32, device=vals.device)
     check(lib.evox_hip_crowding(soa.data_ptr(), order.data_ptr(), rnk.data_ptr(), count, m, dist.data_ptr(), s),
           "crowding")

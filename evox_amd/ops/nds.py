@@ -148,7 +148,7 @@ def segmented_crowding_distance(costs: torch.Tensor, group: torch.Tensor, mask: 
     return torch.where(mask, total, torch.full_like(total, float("-inf")))
 
 
-_CROWD_KERNEL_MAX = 16384        # front sizes up to which the scan-based crowding kernel is used
+_CROWD_KERNEL_MAX = 1 << 22      # front sizes up to which the neighbour-reading crowding kernel is used
 
 
 def rank_crowding_select(fit: torch.Tensor, k: int) -> torch.Tensor:

@@ -1551,3 +1551,18 @@ def test_multi_objective_generation_replays_from_a_graph(cuda, name):
     for a, b in zip(tree_leaves(se), tree_leaves(sg)):
         if isinstance(a, torch.Tensor):
             assert a.shape == b.shape and same(a, b), name
+
+
+def test_crowding_of_a_large_front_matches_the_sort_formulation(cuda):
+    """Fronts beyond the counting sort's range (16384 members) go through the library's sort per objective and the same
+    neighbour-reading kernel: equal to the tensor formulation, infinities at the boundary points included."""
+    from evox_amd.ops import _nds_hip, nds
+
+    g = torch.Generator(device="cuda").manual_seed(11)
+    vals = torch.rand(40000, 3, device=cuda, generator=g)
+    vals[::5] = vals[1::5]                                        # duplicates
+    got = _nds_hip.crowding(vals)
+    ref = nds.crowding_distance_reference(vals)
+    assert torch.equal(torch.isinf(got), torch.isinf(ref))
+    fin = torch.isfinite(ref)
+    assert torch.allclose(got[fin], ref[fin], rtol=1e-5, atol=1e-6)
