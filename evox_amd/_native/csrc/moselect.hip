@@ -581,6 +581,67 @@ EVOX_API int evox_hip_stochastic_ranking_fresh(const float* I1, const float* I2,
   return stochastic_ranking_any(I1, I2, nullptr, pc, n, rank, scratch, seed, stream);
 }
 
+// MOEA/D replacement as a scatter: entry e = (row, slot) offers values[e] to sub-problem target[e]; a sub-problem takes
+// the smallest offer below its current value, ties to the smallest row.  One 64-bit atomic minimum on (order-preserving
+// value bits, row) per IMPROVING offer — most offers do not improve and issue nothing — instead of two atomic scatter
+// passes over all N·T offers.  keys: n_sub words preset to all ones; finish: best value and winning row (-1: none).
+namespace {
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long* __restrict__ p, int n, unsigned long long v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t b) {
+  return __uint_as_float((b & 0x80000000u) ? (b & 0x7fffffffu) : ~b);
+}
+
+__global__ __launch_bounds__(256) void scatter_best_kernel(const float* __restrict__ values, const int64_t* __restrict__ target,
+                                                           const float* __restrict__ current, int64_t entries, int slots,
+                                                           int n_sub, unsigned long long* __restrict__ keys) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < entries; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = target[e];
+    if (t < 0 || t >= n_sub) continue;
+    const float v = values[e];
+    if (v < current[t]) {
+      const unsigned long long key = ((unsigned long long)ordered_bits(v) << 32) | (uint32_t)(e / slots);
+      atomicMin(&keys[t], key);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_best_finish_kernel(const unsigned long long* __restrict__ keys,
+                                                                  const float* __restrict__ current, int n_sub,
+                                                                  float* __restrict__ best, int64_t* __restrict__ winner) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_sub) return;
+  const unsigned long long k = keys[j];
+  const bool none = k == ~0ull;
+  best[j] = none ? current[j] : from_ordered_bits((uint32_t)(k >> 32));
+  winner[j] = none ? -1 : (int64_t)(uint32_t)k;
+}
+
+}  // namespace
+
+// values / target: entries = rows x slots (row-major); current, best: n_sub floats; winner: n_sub int64; keys: n_sub
+// 64-bit words of scratch (set here).
+EVOX_API int evox_hip_scatter_best(const float* values, const int64_t* target, const float* current, int64_t entries,
+                                   int slots, int n_sub, float* best, int64_t* winner, unsigned long long* keys,
+                                   void* stream) {
+  if (n_sub <= 0) return 0;
+  if (slots <= 0 || entries < 0 || entries / slots > 0xFFFFFFFEll) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  fill_u64_kernel<<<(n_sub + 255) / 256, 256, 0, st>>>(keys, n_sub, ~0ull);
+  if (entries > 0)
+    scatter_best_kernel<<<stream_grid(entries, 256), 256, 0, st>>>(values, target, current, entries, slots, n_sub, keys);
+  scatter_best_finish_kernel<<<(n_sub + 255) / 256, 256, 0, st>>>(keys, current, n_sub, best, winner);
+  return last_launch_status();
+}
+
 EVOX_API int evox_hip_niche_fill(const int64_t* rho, const int64_t* cnt, int nref, const int64_t* k, int64_t* out,
                                  void* stream) {
   if (nref <= 0) return 0;

@@ -16,6 +16,7 @@ from ...core import random as rnd
 from ...core.state import State
 from ...operators import crossover, selection
 from ...operators.sampling import LatinHypercubeSampling, UniformSampling
+from ...ops import moselect as _sel
 from ...ops.distance import cdist as _cdist
 from ...utils.common import AggregationFunction
 from .common import MOAlgorithm
@@ -23,7 +24,12 @@ from .common import MOAlgorithm
 
 def _scatter_best(values, target, n_sub, current):
     """For each sub-problem j: (best value, row index of the entry achieving it or -1 when the
-    current value is not beaten).  ``values`` (N, T) with targets ``target`` (N, T)."""
+    current value is not beaten).  ``values`` (N, T) with targets ``target`` (N, T).
+
+    On the GPU one pass with a 64-bit atomic minimum on (value, row) per improving entry (``ops.moselect.scatter_best``);
+    the tensor formulation below is two atomic scatter passes over all N·T entries."""
+    if values.is_cuda and values.dtype == torch.float32 and values.dim() == 2 and current.dtype == torch.float32:
+        return _sel.scatter_best(values, target, n_sub, current)
     flat_v, flat_t = values.reshape(-1), target.reshape(-1)
     best = current.clone().scatter_reduce(0, flat_t, flat_v, reduce="amin", include_self=True)
     improved = flat_v < current[flat_t]

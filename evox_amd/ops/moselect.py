@@ -31,6 +31,7 @@ _native.register_hip_api({
     "evox_hip_ibea_remove_obj_max": (I64, [I]),
     "evox_hip_sra_indicators": (I, [P, I, I, I, P, P, P]),
     "evox_hip_bige_crowding": (I, [P, P, I, I, P, P, P]),
+    "evox_hip_scatter_best": (I, [P, P, P, I64, I, I, P, P, P, P]),
     "evox_hip_knn_dist": (I, [P, I, I, I, P, P]),
     "evox_hip_knee_round": (I, [P, P, I, I, P, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
@@ -265,6 +266,22 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
     else:
         _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
     return rank
+
+
+def scatter_best(values: torch.Tensor, target: torch.Tensor, n_sub: int, current: torch.Tensor):
+    """``(best, winner)`` per sub-problem: entry (row, slot) offers ``values[row, slot]`` to sub-problem
+    ``target[row, slot]``; a sub-problem takes the smallest offer below ``current``, ties to the smallest row; ``winner``
+    is that row or -1.  One launch with a 64-bit atomic minimum per improving offer (``csrc/moselect.hip``)."""
+    v = values.contiguous()
+    t = target.contiguous().to(torch.int64)
+    cur = current.contiguous()
+    rows, slots = v.shape
+    best = torch.empty(n_sub, dtype=torch.float32, device=v.device)
+    winner = torch.empty(n_sub, dtype=torch.int64, device=v.device)
+    keys = torch.empty(n_sub, dtype=torch.int64, device=v.device)
+    check(hip().evox_hip_scatter_best(v.data_ptr(), t.data_ptr(), cur.data_ptr(), rows * slots, slots, n_sub, best.data_ptr(),
+                                      winner.data_ptr(), keys.data_ptr(), stream_of(v)), "scatter_best")
+    return best, winner
 
 
 def knn_distances(f: torch.Tensor, k: int) -> torch.Tensor:

@@ -1566,3 +1566,20 @@ def test_crowding_of_a_large_front_matches_the_sort_formulation(cuda):
     assert torch.equal(torch.isinf(got), torch.isinf(ref))
     fin = torch.isfinite(ref)
     assert torch.allclose(got[fin], ref[fin], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows,slots,n_sub", [(1000, 100, 1000), (257, 3, 50), (4000, 64, 4000)])
+def test_scatter_best_kernel_matches_tensor_formulation(cuda, rows, slots, n_sub):
+    """MOEA/D's replacement scatter: smallest improving offer per sub-problem, ties to the smallest row, -1 without one."""
+    from evox_amd.algorithms.mo import moead
+    from evox_amd.ops import moselect as sel
+
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    values = (torch.randn(rows, slots, device=cuda, generator=g) * 4).round() / 4       # ties, negative values
+    target = torch.randint(0, n_sub, (rows, slots), device=cuda, generator=g)
+    current = torch.randn(n_sub, device=cuda, generator=g) - 1.0
+    best, winner = sel.scatter_best(values, target, n_sub, current)
+    # the tensor formulation (taken on the CPU, where the kernel is not used)
+    rb, rw = moead._scatter_best(values.cpu(), target.cpu(), n_sub, current.cpu())
+    assert torch.equal(best.cpu(), rb) and torch.equal(winner.cpu(), rw)
+    assert int((winner >= 0).sum()) > 0 and int((winner < 0).sum()) > 0
