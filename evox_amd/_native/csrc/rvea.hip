@@ -80,6 +80,78 @@ __global__ __launch_bounds__(256) void rvea_assoc_kernel(const float* __restrict
   atomicMin(&best[best_j], key);
 }
 
+// Association of points with reference directions by perpendicular distance (NSGA-III niching, theta-DEA clustering):
+// for point p and unit direction v, c = clamp(<p, v> / |p|, -1, 1), d1 = |p| c (along v), d2 = |p| sqrt(1 - c^2)
+// (off v).  Every point gets the direction with the smallest d2 (ties: the lowest index), its d1 and d2; a point with a
+// NaN coordinate gets direction 0 and d2 = +inf.  The tensor formulation materialises five n x nv matrices.
+template <int M>
+__global__ __launch_bounds__(256) void ref_assoc_kernel(const float* __restrict__ rows, int n, const float* __restrict__ vn,
+                                                        int nv, int64_t* __restrict__ group, float* __restrict__ d1_out,
+                                                        float* __restrict__ d2_out) {
+  __shared__ float tile[M][256];
+  __shared__ float p_k[4][64], p_c[4][64];
+  __shared__ int p_i[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + r;
+  float mine[M];
+  float norm2 = 0.f;
+  bool bad = i >= n;
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    mine[k] = i < n ? rows[(int64_t)i * M + k] : 0.f;
+    bad = bad || (mine[k] != mine[k]);
+    norm2 += mine[k] * mine[k];
+  }
+  const float norm = sqrtf(norm2);
+  const float inv_norm = 1.0f / norm;
+#pragma unroll
+  for (int k = 0; k < M; ++k) mine[k] *= inv_norm;
+  float best_key = INFINITY, best_c = 0.f;
+  int best_j = 0x7fffffff;
+  for (int j0 = 0; j0 < nv; j0 += 256) {
+    __syncthreads();
+    const int jj = j0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = jj < nv ? vn[(int64_t)jj * M + k] : 0.f;
+    __syncthreads();
+    const int lim = min(64, nv - j0 - s * 64);
+    for (int q = 0; q < lim; ++q) {
+      const int c = s * 64 + q;
+      // through the chord between the unit vectors, h = |p^ - v|^2 / 2 = 1 - c: 1 - c^2 = h (2 - h) without the
+      // cancellation that 1 - c*c suffers for the small angles that matter here
+      float ch = 0.f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) { const float d = mine[k] - tile[k][c]; ch = fmaf(d, d, ch); }
+      const float h = fminf(0.5f * ch, 2.f);
+      const float key = fmaxf(h * (2.f - h), 0.f);
+      if (key < best_key) { best_key = key; best_c = 1.f - h; best_j = j0 + c; }
+    }
+  }
+  p_k[s][r] = best_key; p_c[s][r] = best_c; p_i[s][r] = best_j;
+  __syncthreads();
+  if (s != 0 || i >= n) return;
+  for (int t = 1; t < 4; ++t)
+    if (p_k[t][r] < best_key || (p_k[t][r] == best_key && p_i[t][r] < best_j)) {
+      best_key = p_k[t][r]; best_c = p_c[t][r]; best_j = p_i[t][r];
+    }
+  if (bad || best_j == 0x7fffffff || !(norm == norm)) {
+    group[i] = 0;
+    d1_out[i] = __builtin_nanf("");
+    d2_out[i] = INFINITY;
+    return;
+  }
+  group[i] = best_j;
+  d1_out[i] = norm * best_c;
+  const float d2 = norm * sqrtf(best_key);
+  d2_out[i] = d2 == d2 ? d2 : INFINITY;                    // the zero vector: 0 * (1 / 0) has no direction
+}
+
+template <int M>
+int launch_assoc(const float* rows, int n, const float* vn, int nv, int64_t* group, float* d1, float* d2, hipStream_t st) {
+  ref_assoc_kernel<M><<<(n + 63) / 64, 256, 0, st>>>(rows, n, vn, nv, group, d1, d2);
+  return last_launch_status();
+}
+
 template <int M>
 int launch(const float* obj, int n, const float* vn, int nv, float m_theta, const float* theta_dev, float* gamma,
            unsigned long long* best, hipStream_t st) {
@@ -106,6 +178,24 @@ static int rvea_select_any(const float* obj, int n, const float* vn, int nv, int
     case 6: return launch<6>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
     case 7: return launch<7>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
     case 8: return launch<8>(obj, n, vn, nv, mt, theta_dev, gamma, best, st);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+// rows: (n, m) points; vn: (nv, m) unit directions; group / d1 / d2: out (n).
+EVOX_API int evox_hip_ref_associate(const float* rows, int n, const float* vn, int nv, int m, int64_t* group, float* d1,
+                                    float* d2, void* stream) {
+  if (n <= 0) return 0;
+  if (nv <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  switch (m) {
+    case 2: return launch_assoc<2>(rows, n, vn, nv, group, d1, d2, st);
+    case 3: return launch_assoc<3>(rows, n, vn, nv, group, d1, d2, st);
+    case 4: return launch_assoc<4>(rows, n, vn, nv, group, d1, d2, st);
+    case 5: return launch_assoc<5>(rows, n, vn, nv, group, d1, d2, st);
+    case 6: return launch_assoc<6>(rows, n, vn, nv, group, d1, d2, st);
+    case 7: return launch_assoc<7>(rows, n, vn, nv, group, d1, d2, st);
+    case 8: return launch_assoc<8>(rows, n, vn, nv, group, d1, d2, st);
     default: return (int)hipErrorInvalidValue;
   }
 }

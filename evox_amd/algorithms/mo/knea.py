@@ -137,15 +137,11 @@ def theta_nd_sort(obj, w, mask):
     """θ-non-dominated level of every (masked) point: points are clustered to their nearest
     reference direction and ranked inside the cluster by d₁ + θ d₂."""
     n, nw = obj.shape[0], w.shape[0]
-    norm_p = torch.linalg.vector_norm(obj, dim=1, keepdim=True)
-    cosine = cos_dist(obj, w).clamp(-1, 1)
-    d1 = norm_p * cosine
-    d2 = norm_p * torch.sqrt((1 - cosine ** 2).clamp_min(0))
-    cls = torch.argmin(d2, dim=1)
+    cls, d1, d2 = _sel.ref_associate(obj, w)          # nearest direction by perpendicular distance (streamed on the GPU)
     theta = torch.full((nw,), 5.0, device=obj.device)
     theta = torch.where((w > 1e-4).sum(1) == 1, torch.full_like(theta, 1e6), theta)
     ar = torch.arange(n, device=obj.device)
-    score = d1[ar, cls] + theta[cls] * d2[ar, cls]
+    score = d1 + theta[cls] * d2
     score = torch.where(mask, score, torch.full_like(score, float("inf")))
     # rank inside each cluster = position among the cluster's members sorted by score
     by_score = torch.argsort(score, stable=True)

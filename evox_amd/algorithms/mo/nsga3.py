@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import torch
 
+from ...ops import moselect as _sel
 from ...ops._util import count_groups, pick
 from ... import _native
 from ...core import random as rnd
@@ -106,11 +107,8 @@ class NSGA3(MOAlgorithm):
         last_rank = pick(rank, order[k_total - 1])
         considered = rank <= last_rank
         norm = self._normalise(fit, considered)
-        cosine = cos_dist(norm, self.ref).clamp(-1, 1)
-        dist = torch.linalg.vector_norm(norm, dim=-1, keepdim=True) * torch.sqrt((1 - cosine ** 2).clamp_min(0))
-        dist = torch.where(torch.isnan(dist), torch.full_like(dist, float("inf")), dist)
-        group = torch.argmin(dist, dim=1)
-        gdist = dist.amin(1)
+        # niche of every point: the reference line at the smallest perpendicular distance (streamed on the GPU)
+        group, _, gdist = _sel.ref_associate(norm, self.ref)
         nref = self.ref.shape[0]
         earlier, last = rank < last_rank, rank == last_rank
         rho = torch.zeros(nref, dtype=torch.int64, device=fit.device).scatter_add(0, group, earlier.to(torch.int64))

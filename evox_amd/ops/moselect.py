@@ -32,6 +32,7 @@ _native.register_hip_api({
     "evox_hip_sra_indicators": (I, [P, I, I, I, P, P, P]),
     "evox_hip_bige_crowding": (I, [P, P, I, I, P, P, P]),
     "evox_hip_scatter_best": (I, [P, P, P, I64, I, I, P, P, P, P]),
+    "evox_hip_ref_associate": (I, [P, I, P, I, I, P, P, P, P]),
     "evox_hip_knn_dist": (I, [P, I, I, I, P, P]),
     "evox_hip_knee_round": (I, [P, P, I, I, P, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
@@ -266,6 +267,30 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
     else:
         _native.cpu().evox_cpu_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr())
     return rank
+
+
+def ref_associate(points: torch.Tensor, refs: torch.Tensor):
+    """``(group, d1, d2)``: every point's reference direction by smallest perpendicular distance ``d2`` (ties: lowest
+    index), with the distance along it (``d1``) — NSGA-III's niche association and θ-DEA's clustering.  Points with a NaN
+    coordinate get direction 0 and ``d2 = +inf``.  On the GPU one streaming launch (``csrc/rvea.hip::ref_assoc_kernel``);
+    the tensor formulation materialises the n × n_ref cosine and distance matrices."""
+    n, m = points.shape
+    if on_gpu(points) and 2 <= m <= 8 and points.dtype == torch.float32 and refs.dtype == torch.float32 and n > 0:
+        vn = (refs / torch.linalg.vector_norm(refs, dim=-1, keepdim=True)).contiguous()
+        p = points.contiguous()
+        group = torch.empty(n, dtype=torch.int64, device=p.device)
+        d1 = torch.empty(n, dtype=torch.float32, device=p.device)
+        d2 = torch.empty(n, dtype=torch.float32, device=p.device)
+        check(hip().evox_hip_ref_associate(p.data_ptr(), n, vn.data_ptr(), vn.shape[0], m, group.data_ptr(), d1.data_ptr(),
+                                           d2.data_ptr(), stream_of(p)), "ref_associate")
+        return group, d1, d2
+    norm = torch.linalg.vector_norm(points, dim=-1, keepdim=True)
+    cosine = ((points / norm) @ (refs / torch.linalg.vector_norm(refs, dim=-1, keepdim=True)).T).clamp(-1, 1)
+    dist = norm * torch.sqrt((1 - cosine ** 2).clamp_min(0))
+    dist = torch.where(torch.isnan(dist), torch.full_like(dist, float("inf")), dist)
+    group = torch.argmin(dist, dim=1)
+    ar = torch.arange(n, device=points.device)
+    return group, (norm * cosine)[ar, group], dist[ar, group]
 
 
 def scatter_best(values: torch.Tensor, target: torch.Tensor, n_sub: int, current: torch.Tensor):

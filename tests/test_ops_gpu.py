@@ -1583,3 +1583,28 @@ def test_scatter_best_kernel_matches_tensor_formulation(cuda, rows, slots, n_sub
     rb, rw = moead._scatter_best(values.cpu(), target.cpu(), n_sub, current.cpu())
     assert torch.equal(best.cpu(), rb) and torch.equal(winner.cpu(), rw)
     assert int((winner >= 0).sum()) > 0 and int((winner < 0).sum()) > 0
+
+
+@pytest.mark.parametrize("n,nw,m", [(3000, 1000, 3), (257, 91, 2), (2000, 500, 5)])
+def test_reference_direction_association_matches_tensor_formulation(cuda, n, nw, m):
+    from evox_amd.ops import moselect as sel
+
+    g = torch.Generator(device="cuda").manual_seed(n + nw)
+    pts = torch.rand(n, m, device=cuda, generator=g) * 2
+    pts[7] = float("nan")
+    refs = torch.rand(nw, m, device=cuda, generator=g) + 0.01
+    group, d1, d2 = sel.ref_associate(pts, refs)
+    rg, r1, r2 = sel.ref_associate(pts.cpu().double(), refs.cpu().double())            # tensor formulation in fp64
+    ok = torch.ones(n, dtype=torch.bool)
+    ok[7] = False
+    # the chosen direction is (within rounding) a nearest one, and the distances are those of that direction
+    pd, rd = pts.cpu().double(), refs.cpu().double()
+    rn = rd / rd.norm(dim=1, keepdim=True)
+    norm = pd.norm(dim=1)
+    cosg = ((pd / norm[:, None]) * rn[group.cpu()]).sum(1).clamp(-1, 1)
+    d2g = norm * torch.sqrt((1 - cosg ** 2).clamp_min(0))
+    assert torch.allclose(d2g[ok], r2[ok], rtol=1e-4, atol=1e-5)
+    assert float((group.cpu()[ok] == rg[ok]).double().mean()) > 0.999
+    assert torch.allclose(d2.cpu().double()[ok], d2g[ok], rtol=1e-3, atol=2e-4)
+    assert torch.allclose(d1.cpu().double()[ok], (norm * cosg)[ok], rtol=1e-4, atol=1e-5)
+    assert int(group[7]) == 0 and torch.isinf(d2[7])
