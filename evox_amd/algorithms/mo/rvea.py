@@ -11,6 +11,7 @@ from ...core.state import State
 from ...operators.sampling import UniformSampling
 from ...operators.selection.non_dominate import non_dominated_sort
 from ...operators.selection.rvea_selection import ReferenceVectorGuided, ref_vec_guided
+from ...ops import moselect as _sel
 from ...utils.common import cos_dist
 from .common import MOAlgorithm
 
@@ -91,9 +92,14 @@ def rv_regeneration(pop_obj, v, key):
     """Re-draw the additional vectors that lost all their solutions: uniform in the box spanned
     by the current objective ranges."""
     obj = pop_obj - _nan_amin(pop_obj)
-    cosine = cos_dist(torch.where(torch.isnan(obj), torch.zeros_like(obj), obj), v)
-    cosine = torch.where(torch.isnan(pop_obj).any(1, keepdim=True), torch.full_like(cosine, -1.0), cosine)
-    associate = torch.argmax(cosine, dim=1)
+    if obj.is_cuda and 2 <= obj.shape[1] <= 8 and obj.dtype == torch.float32 and v.dtype == torch.float32:
+        # nearest vector by angle, streamed (objectives and vectors are non-negative here, so the smallest perpendicular
+        # distance is the largest cosine); rows without a solution go to vector 0, as below
+        associate = _sel.ref_associate(obj, v)[0]
+    else:
+        cosine = cos_dist(torch.where(torch.isnan(obj), torch.zeros_like(obj), obj), v)
+        cosine = torch.where(torch.isnan(pop_obj).any(1, keepdim=True), torch.full_like(cosine, -1.0), cosine)
+        associate = torch.argmax(cosine, dim=1)
     used = torch.zeros(v.shape[0], dtype=torch.bool, device=v.device).index_fill_(0, associate, True)
     fresh = rnd.uniform(key, v.shape) * _nan_amax(obj)
     return torch.where(used[:, None], v, fresh)
