@@ -142,6 +142,132 @@ __global__ __launch_bounds__(NT) void ibea_remove_reg_kernel(const float* __rest
   }
 }
 
+// The removal loop spread over several compute units.  One workgroup is bound by the instruction issue of its compute
+// unit (about 12 operations per member and removal); here G workgroups of 256 threads each hold a slice of the members in
+// registers.  Per removal every workgroup publishes its local arg-min as one 64-bit word
+//     [ order-preserving fitness bits : 32 | removal number mod 4096 : 12 | member index : 20 ]
+// in its slot (two sets of slots, alternating with the parity of the removal number: a workgroup can run at most one
+// removal ahead of the slowest, so a slot is never overwritten before everyone has read it), waits until the G slots of
+// this removal are there, and takes their minimum — the same member on every workgroup, value first, index second, as in
+// the single-workgroup loop, so the survivors are identical.  The removed member's objectives and scale are read from
+// the (immutable) input arrays.  The wait is bounded: after spin_limit polls a workgroup raises *error and leaves, and so
+// do the others when their own waits run out.  Only every kGroupStride-th workgroup of the launch takes part: consecutive
+// workgroups go to different dies of the package, the ones that work then share one die's L2.
+constexpr int kGroupStride = 8;
+constexpr int kMultiThreads = 256;
+constexpr unsigned kIdxMask = 0xFFFFFu;
+
+__device__ __forceinline__ unsigned ordered_bits32(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int M, int E>
+__global__ __launch_bounds__(kMultiThreads) void ibea_remove_multi_kernel(const float* __restrict__ obj, int n,
+                                                                          const float* __restrict__ C, float kappa,
+                                                                          const float* __restrict__ fit_in, int n_remove,
+                                                                          uint8_t* __restrict__ alive_out,
+                                                                          unsigned long long* slots, int* error, int G,
+                                                                          int spin_limit) {
+  if (blockIdx.x % kGroupStride) return;
+  const int g = blockIdx.x / kGroupStride;
+  if (g >= G) return;
+  __shared__ float s_v[kMultiThreads / 64];
+  __shared__ int s_i[kMultiThreads / 64];
+  __shared__ unsigned long long s_win;
+  const int base = g * kMultiThreads * E;
+  float f[E], cj[E], oj[E][M];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = base + threadIdx.x + e * kMultiThreads;
+    f[e] = INFINITY; cj[e] = 1.f;
+#pragma unroll
+    for (int k = 0; k < M; ++k) oj[e][k] = 0.f;
+    if (j < n) {
+      f[e] = fit_in[j]; cj[e] = C[j];
+#pragma unroll
+      for (int k = 0; k < M; ++k) oj[e][k] = obj[(int64_t)j * M + k];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = 0; r < n_remove; ++r) {
+    float v = INFINITY; int idx = (int)kIdxMask;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (f[e] < v) { v = f[e]; idx = base + threadIdx.x + e * kMultiThreads; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+    if (lane == 0) { s_v[wave] = v; s_i[wave] = idx; }
+    __syncthreads();
+    const unsigned tag = (unsigned)r & 0xFFFu;
+    unsigned long long* set = slots + (size_t)(r & 1) * G;
+    if (wave == 0) {
+      if (lane == 0) {
+#pragma unroll
+        for (int w = 1; w < kMultiThreads / 64; ++w)
+          if (s_v[w] < v || (s_v[w] == v && s_i[w] < idx)) { v = s_v[w]; idx = s_i[w]; }
+        const unsigned long long mine = ((unsigned long long)ordered_bits32(v) << 32) | ((unsigned long long)tag << 20) |
+                                        (unsigned)idx;
+        __hip_atomic_store(&set[g], mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // lane q < G waits for workgroup q's word of this removal
+      unsigned long long word = ~0ull;
+      int late = 0;
+      if (lane < G) {
+        int polls = 0;
+        for (;;) {
+          word = __hip_atomic_load(&set[lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if ((((unsigned)(word >> 20)) & 0xFFFu) == tag) break;
+          if (++polls >= spin_limit) { late = 1; word = ~0ull; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      unsigned hi = (unsigned)(word >> 32), lo = (unsigned)word;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned ohi = __shfl_xor(hi, o, 64), olo = __shfl_xor(lo, o, 64);
+        if (ohi < hi || (ohi == hi && olo < lo)) { hi = ohi; lo = olo; }
+      }
+      const bool any_late = __any(late);
+      if (lane == 0) {
+        if (any_late) *error = 1;
+        s_win = any_late ? ~0ull : (((unsigned long long)hi << 32) | lo);
+      }
+    }
+    __syncthreads();
+    const unsigned long long win = s_win;
+    const int x = (int)((unsigned)win & kIdxMask);
+    if (win == ~0ull || x == (int)kIdxMask) break;        // a wait ran out, or nothing is left: uniform over the launch
+    float ox[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) ox[k] = obj[(int64_t)x * M + k];
+    const float s = -1.0f / (C[x] * kappa);
+    const int local = x - base;
+    if (local >= 0 && local < kMultiThreads * E && (local & (kMultiThreads - 1)) == (int)threadIdx.x) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (e == local / kMultiThreads) f[e] = INFINITY;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) f[e] += __expf(eps_ind<M>(ox, oj[e]) * s);      // +inf stays +inf
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = base + threadIdx.x + e * kMultiThreads;
+    if (j < n) alive_out[j] = f[e] < INFINITY ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(64) void ibea_multi_reset_kernel(unsigned long long* slots, int count, int* error) {
+  const int i = threadIdx.x;
+  for (int k = i; k < count; k += 64) slots[k] = ~0ull;
+  if (i == 0) *error = 0;
+}
+
 // SRA's two indicators for point j (thread), streamed over all points i like the fitness above:
 //   I1_j = 1 − Σ_i exp(−I(i, j) / 0.05)                                   (ε-indicator fitness, unscaled)
 //   I2_j = min_i ‖f_j − max(f_i, f_j)‖ = min_i sqrt(Σ_k max(f_i[k] − f_j[k], 0)²)     (shift-based density)
@@ -385,6 +511,33 @@ int launch_remove_reg(const float* obj, int n, const float* C, float kappa, cons
   return last_launch_status();
 }
 
+template <int M, int E>
+int launch_remove_multi(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove, uint8_t* alive,
+                        unsigned long long* slots, int* error, int G, int spin_limit, hipStream_t st) {
+  ibea_multi_reset_kernel<<<1, 64, 0, st>>>(slots, 2 * G, error);
+  ibea_remove_multi_kernel<M, E><<<G * kGroupStride, kMultiThreads, 0, st>>>(obj, n, C, kappa, fit, n_remove, alive, slots,
+                                                                           error, G, spin_limit);
+  return last_launch_status();
+}
+
+constexpr int kMultiGroups = 8;
+// members per thread of the multi-workgroup form
+constexpr int multi_capacity(int m) { return m <= 4 ? 12 : 6; }
+
+template <int M>
+int launch_remove_multi_any(const float* obj, int n, const float* C, float kappa, const float* fit, int n_remove,
+                            uint8_t* alive, unsigned long long* slots, int* error, int spin_limit, hipStream_t st) {
+  const int per = kMultiGroups * kMultiThreads;
+  const int e = (n + per - 1) / per;
+  if (e <= 3) return launch_remove_multi<M, 3>(obj, n, C, kappa, fit, n_remove, alive, slots, error, kMultiGroups, spin_limit, st);
+  if (e <= 6) return launch_remove_multi<M, 6>(obj, n, C, kappa, fit, n_remove, alive, slots, error, kMultiGroups, spin_limit, st);
+  if constexpr (M <= 4) {
+    if (e <= 12)
+      return launch_remove_multi<M, 12>(obj, n, C, kappa, fit, n_remove, alive, slots, error, kMultiGroups, spin_limit, st);
+  }
+  return (int)hipErrorInvalidValue;
+}
+
 // members per thread that the register form is built for, given m (0: none — use the matrix form)
 constexpr int reg_capacity(int m) { return m <= 3 ? 20 : (m <= 4 ? 16 : 8); }
 
@@ -450,6 +603,22 @@ EVOX_API int evox_hip_knee_round(const float* f, const float* R, int n, int m, c
 // Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix
 // form beyond it).
 EVOX_API int64_t evox_hip_ibea_remove_obj_max(int m) { return m >= 2 && m <= 8 ? (int64_t)reg_capacity(m) * NT : 0; }
+
+// Largest population of the multi-workgroup removal loop for m objectives (member indices take 20 bits).
+EVOX_API int64_t evox_hip_ibea_remove_multi_max(int m) {
+  return m >= 2 && m <= 8 ? (int64_t)multi_capacity(m) * kMultiGroups * kMultiThreads : 0;
+}
+
+// The removal loop on several compute units (see ibea_remove_multi_kernel).  slots: 2 x 8 64-bit words of scratch,
+// error: one int, set to 1 when a bounded wait ran out (the survivor mask is then not valid); both are reset here.
+EVOX_API int evox_hip_ibea_remove_obj_multi(const float* obj, int n, int m, const float* C, float kappa, const float* fit,
+                                            int n_remove, uint8_t* alive, unsigned long long* slots, int* error,
+                                            int spin_limit, void* stream) {
+  if (n <= 0) return 0;
+  if (n >= (int)kIdxMask || spin_limit <= 0 || slots == nullptr || error == nullptr) return (int)hipErrorInvalidValue;
+  EVOX_IBEA_DISPATCH(launch_remove_multi_any, obj, n, C, kappa, fit, n_remove, alive, slots, error, spin_limit,
+                     (hipStream_t)stream)
+}
 
 EVOX_API int evox_hip_ibea_remove_obj(const float* obj, int n, int m, const float* C, float kappa, const float* fit,
                                       int n_remove, uint8_t* alive, void* stream) {

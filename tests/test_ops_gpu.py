@@ -1608,3 +1608,27 @@ def test_reference_direction_association_matches_tensor_formulation(cuda, n, nw,
     assert torch.allclose(d2.cpu().double()[ok], d2g[ok], rtol=1e-3, atol=2e-4)
     assert torch.allclose(d1.cpu().double()[ok], (norm * cosg)[ok], rtol=1e-4, atol=1e-5)
     assert int(group[7]) == 0 and torch.isinf(d2[7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,n_remove", [(5000, 3, 2500), (9000, 3, 4500), (20000, 3, 3000), (12000, 4, 800), (6000, 6, 700),
+                                          (4097, 2, 4000)])
+def test_ibea_removal_on_eight_compute_units_equals_single_workgroup_loop(n, m, n_remove, monkeypatch):
+    """The removal loop spread over eight workgroups (members sliced over them, the arg-min of every removal agreed on
+    through one 64-bit word per workgroup) removes exactly the members the single-workgroup loop removes."""
+    from evox_amd.algorithms.mo import indicator
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n + m)
+    obj = indicator._normalised(torch.rand(n, m, generator=g).cuda())
+    obj[n // 3] = obj[n // 5]                                   # identical members: equal fitness, index decides
+    fit, C = moselect.ibea_fitness(obj, 0.05)
+    monkeypatch.setenv("EVOX_AMD_IBEA_MULTI", "1")             # opt-in form
+    assert moselect._ibea_multi(n, m)
+    got = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
+    monkeypatch.setenv("EVOX_AMD_IBEA_MULTI", "0")
+    assert not moselect._ibea_multi(n, m)
+    if moselect.ibea_remove_streaming_fits(n, m):
+        want = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
+        assert torch.equal(got, want)
+    assert int(got.sum()) == n - n_remove
