@@ -167,7 +167,10 @@ class ShardedWorkflow(StdWorkflow):
         return state.replace(rank=rank, world_size=world)
 
     def _step(self, state, hooks=None, aux=None):
-        if not self.row_sharded or state.world_size == 1 and not self.row_sharded:
+        # a population that the ranks cannot share evenly runs in replicated mode (remainder-aware evaluation slices)
+        pop_size = getattr(self.algorithm, "pop_size", None)
+        uneven = isinstance(pop_size, int) and state.world_size > 1 and pop_size % state.world_size != 0
+        if not self.row_sharded or uneven:
             return super()._step(state, hooks, aux)
         hooks = self.registered_hooks if hooks is None else hooks
         rank, world = state.rank, state.world_size
