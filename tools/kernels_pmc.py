@@ -93,5 +93,26 @@ wf = _W.StdWorkflow(algo, problems.numerical.Ackley())
 st = wf.init(rnd.PRNGKey(1))
 for _ in range(12):                                                          # gemm_nt_kernel family, cma_bf16 / cma_step kernels
     st = wf.step(st)
+# kernels of the row-sharded generation, the one-pass MaF / LSMOP evaluators and the streaming indicator / association /
+# replacement kernels
+from evox_amd.workflows import ShardedWorkflow as _SW
+algo2 = _A.CMAES(center_init=torch.full((n,), 2.0, device=dev), init_stdev=1.0, pop_size=lam, decomposition="newton_schulz",
+                 precision="bf16")
+wf2 = _SW(algo2, problems.numerical.Ackley())
+st2 = wf2.init(rnd.PRNGKey(1))
+for _ in range(6):                      # presorted_rank / select_local / gram_pack / cov_from_packed kernels
+    st2 = wf2.step(st2)
+for _ in range(2):
+    for name in ("LSMOP1", "LSMOP7", "MaF3", "MaF10", "MaF12", "MaF13", "MaF9"):
+        pr = getattr(problems.numerical, name)(m=3)
+        fo, _ = pr.evaluate(None, torch.rand(10000, pr.d, device=dev))       # grouped / maf / maf_wfg / maf9 kernels
+    f3 = torch.rand(20000, 3, device=dev)
+    cd = moselect.bige_crowding(f3, f3.sum(1), torch.tensor(0.05, device=dev))            # bige_crowding_kernel
+    kn = moselect.knn_distances(f3, 3)                                                    # knn_dist_kernel
+    kp = moselect.knee_suppress(f3[:4000], torch.randperm(4000, device=dev), torch.full((3,), 0.05, device=dev))   # knee_round_kernel
+    gp, d1, d2 = moselect.ref_associate(f3, torch.rand(10000, 3, device=dev) + 0.01)      # ref_assoc_kernel
+    bw = moselect.scatter_best(torch.randn(10000, 1000, device=dev), torch.randint(0, 10000, (10000, 1000), device=dev),
+                               10000, torch.zeros(10000, device=dev) - 1.0)               # scatter_best_kernel
+    rk3 = moselect.stochastic_ranking(i1, i2, None, 0.45, seed=torch.tensor([7], dtype=torch.int32, device=dev))   # fresh coins
 torch.cuda.synchronize()
 print("done")
