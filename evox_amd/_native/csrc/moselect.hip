@@ -214,7 +214,9 @@ __global__ __launch_bounds__(NT) void spea2_truncate_kernel(const float* __restr
 template <int L, bool KEYS, bool FRESH>
 __global__ __launch_bounds__(L) void stochastic_ranking_kernel(const float* __restrict__ I1, const float* __restrict__ I2,
                                                                const float* __restrict__ u, float pc, int n,
-                                                               int64_t* __restrict__ rank, const int32_t* __restrict__ seed_ptr) {
+                                                               int64_t* __restrict__ rank, const int32_t* __restrict__ seed_ptr,
+                                                               const float* __restrict__ pc_dev) {
+  if (pc_dev) pc = *pc_dev;                                // the probability on the device (a recorded graph reads it here)
   extern __shared__ __attribute__((aligned(16))) int s_mem[];
   int* rk = s_mem;                                       // the permutation, n entries
   float* l1 = reinterpret_cast<float*>(s_mem + n);       // copies of I1, I2, u when KEYS
@@ -284,8 +286,10 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
                                                                           const float* __restrict__ I2,
                                                                           const float* __restrict__ u, float pc, int n,
                                                                           int64_t* __restrict__ rank,
-                                                                          const int32_t* __restrict__ seed_ptr) {
+                                                                          const int32_t* __restrict__ seed_ptr,
+                                                                          const float* __restrict__ pc_dev) {
   static_assert(B % 4 == 0, "coin groups hold four positions");
+  if (pc_dev) pc = *pc_dev;
   constexpr int T = 1024;
   __shared__ int c_i[T], f_i[T];
   __shared__ float c_1[T], c_2[T], f_1[T], f_2[T];
@@ -357,9 +361,9 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
 
 template <int B>
 int launch_ranking_blocked(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank,
-                           const int32_t* seed, hipStream_t st) {
-  if (seed) stochastic_ranking_blocked_kernel<B, true><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed);
-  else stochastic_ranking_blocked_kernel<B, false><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed);
+                           const int32_t* seed, const float* pc_dev, hipStream_t st) {
+  if (seed) stochastic_ranking_blocked_kernel<B, true><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed, pc_dev);
+  else stochastic_ranking_blocked_kernel<B, false><<<1, 1024, 0, st>>>(I1, I2, u, pc, n, rank, seed, pc_dev);
   return last_launch_status();
 }
 
@@ -368,7 +372,9 @@ __global__ __launch_bounds__(64) void stochastic_ranking_serial_kernel(const flo
                                                                        const float* __restrict__ I2,
                                                                        const float* __restrict__ u, float pc, int n,
                                                                        int64_t* __restrict__ rank, int* __restrict__ rk,
-                                                                       const int32_t* __restrict__ seed_ptr) {
+                                                                       const int32_t* __restrict__ seed_ptr,
+                                                                       const float* __restrict__ pc_dev) {
+  if (pc_dev) pc = *pc_dev;
   for (int i = threadIdx.x; i < n; i += 64) rk[i] = i;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -520,37 +526,37 @@ EVOX_API int evox_hip_spea2_truncate(const float* dis, int n, int ld, int n_remo
 
 template <int L, bool KEYS, bool FRESH>
 int launch_ranking_as(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
-                      const int32_t* seed, hipStream_t st) {
+                      const int32_t* seed, const float* pc_dev, hipStream_t st) {
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)stochastic_ranking_kernel<L, KEYS, FRESH>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  stochastic_ranking_kernel<L, KEYS, FRESH><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank, seed);
+  stochastic_ranking_kernel<L, KEYS, FRESH><<<1, L, lds, st>>>(I1, I2, u, pc, n, rank, seed, pc_dev);
   return last_launch_status();
 }
 
 template <int L>
 int launch_ranking(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank, size_t lds,
-                   int keys_in_lds, const int32_t* seed, hipStream_t st) {
+                   int keys_in_lds, const int32_t* seed, const float* pc_dev, hipStream_t st) {
   if (seed) {
-    return keys_in_lds ? launch_ranking_as<L, true, true>(I1, I2, u, pc, n, rank, lds, seed, st)
-                       : launch_ranking_as<L, false, true>(I1, I2, u, pc, n, rank, lds, seed, st);
+    return keys_in_lds ? launch_ranking_as<L, true, true>(I1, I2, u, pc, n, rank, lds, seed, pc_dev, st)
+                       : launch_ranking_as<L, false, true>(I1, I2, u, pc, n, rank, lds, seed, pc_dev, st);
   }
-  return keys_in_lds ? launch_ranking_as<L, true, false>(I1, I2, u, pc, n, rank, lds, seed, st)
-                     : launch_ranking_as<L, false, false>(I1, I2, u, pc, n, rank, lds, seed, st);
+  return keys_in_lds ? launch_ranking_as<L, true, false>(I1, I2, u, pc, n, rank, lds, seed, pc_dev, st)
+                     : launch_ranking_as<L, false, false>(I1, I2, u, pc, n, rank, lds, seed, pc_dev, st);
 }
 
 // u: n-1 per-position coins in [0, 1) (the comparison at position j ranks by I1 when u[j] < pc, in every sweep), or —
 // seed != null, u unused — a fresh coin for every comparison, drawn from a hash of (*seed, sweep, position).
 static int stochastic_ranking_any(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank,
-                                  int* scratch, const int32_t* seed, void* stream) {
+                                  int* scratch, const int32_t* seed, const float* pc_dev, void* stream) {
   if (n <= 0) return 0;
   if (n > 4096 && n <= 1024 * 24) {
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 1024 * 8) return launch_ranking_blocked<8>(I1, I2, u, pc, n, rank, seed, st);
-    if (n <= 1024 * 16) return launch_ranking_blocked<16>(I1, I2, u, pc, n, rank, seed, st);
-    return launch_ranking_blocked<24>(I1, I2, u, pc, n, rank, seed, st);
+    if (n <= 1024 * 8) return launch_ranking_blocked<8>(I1, I2, u, pc, n, rank, seed, pc_dev, st);
+    if (n <= 1024 * 16) return launch_ranking_blocked<16>(I1, I2, u, pc, n, rank, seed, pc_dev, st);
+    return launch_ranking_blocked<24>(I1, I2, u, pc, n, rank, seed, pc_dev, st);
   }
   const size_t perm = (size_t)n * sizeof(int);
   if (perm <= 160 * 1024) {
@@ -560,25 +566,32 @@ static int stochastic_ranking_any(const float* I1, const float* I2, const float*
     const int sweeps = (n + 1) / 2;
     hipStream_t st = (hipStream_t)stream;
     // as many pipeline stages as there are sweeps, up to the 1024 threads of a workgroup
-    if (sweeps <= 64) return launch_ranking<64>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
-    if (sweeps <= 256) return launch_ranking<256>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
-    return launch_ranking<1024>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, st);
+    if (sweeps <= 64) return launch_ranking<64>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, pc_dev, st);
+    if (sweeps <= 256) return launch_ranking<256>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, pc_dev, st);
+    return launch_ranking<1024>(I1, I2, u, pc, n, rank, lds, keys_in_lds, seed, pc_dev, st);
   }
   if (scratch == nullptr) return (int)hipErrorInvalidValue;
-  stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch, seed);
+  stochastic_ranking_serial_kernel<<<1, 64, 0, (hipStream_t)stream>>>(I1, I2, u, pc, n, rank, scratch, seed, pc_dev);
   return last_launch_status();
 }
 
 EVOX_API int evox_hip_stochastic_ranking(const float* I1, const float* I2, const float* u, float pc, int n,
                                          int64_t* rank, int* scratch, void* stream) {
   if (u == nullptr && n > 1) return (int)hipErrorInvalidValue;
-  return stochastic_ranking_any(I1, I2, u, pc, n, rank, scratch, nullptr, stream);
+  return stochastic_ranking_any(I1, I2, u, pc, n, rank, scratch, nullptr, nullptr, stream);
 }
 
 EVOX_API int evox_hip_stochastic_ranking_fresh(const float* I1, const float* I2, const int32_t* seed, float pc, int n,
                                                int64_t* rank, int* scratch, void* stream) {
   if (seed == nullptr) return (int)hipErrorInvalidValue;
-  return stochastic_ranking_any(I1, I2, nullptr, pc, n, rank, scratch, seed, stream);
+  return stochastic_ranking_any(I1, I2, nullptr, pc, n, rank, scratch, seed, nullptr, stream);
+}
+
+// The same with the probability read from the device (one float): nothing of the call depends on a host value.
+EVOX_API int evox_hip_stochastic_ranking_fresh_dev(const float* I1, const float* I2, const int32_t* seed, const float* pc,
+                                                   int n, int64_t* rank, int* scratch, void* stream) {
+  if (seed == nullptr || pc == nullptr) return (int)hipErrorInvalidValue;
+  return stochastic_ranking_any(I1, I2, nullptr, 0.5f, n, rank, scratch, seed, pc, stream);
 }
 
 // MOEA/D replacement as a scatter: entry e = (row, slot) offers values[e] to sub-problem target[e]; a sub-problem takes

@@ -68,7 +68,8 @@ class SRA(MOAlgorithm):
         else:
             I1, I2 = _sel.sra_indicators(obj, lower_only=False)
         if self.coins == "per_comparison":
-            order = _sel.stochastic_ranking(I1, I2, None, float(pc), seed=rnd.bits(k_env, (1,)))
+            # probability and seed stay on the device: no host value enters the ranking (replayable from a graph)
+            order = _sel.stochastic_ranking(I1, I2, None, pc if obj.is_cuda else float(pc), seed=rnd.bits(k_env, (1,)))
         else:
             order = _sel.stochastic_ranking(I1, I2, rnd.uniform(k_env, (n - 1,)), float(pc))
         idx = order[: self.pop_size]

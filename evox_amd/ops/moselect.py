@@ -27,6 +27,7 @@ _native.register_hip_api({
     "evox_hip_spea2_truncate": (I, [P, I, I, I, P, P, P, P]),
     "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_stochastic_ranking_fresh": (I, [P, P, P, F, I, P, P, P]),
+    "evox_hip_stochastic_ranking_fresh_dev": (I, [P, P, P, P, I, P, P, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
@@ -277,6 +278,15 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
     n = I1.shape[0]
     I1, I2 = I1.contiguous().float(), I2.contiguous().float()
     rank = torch.empty(n, dtype=torch.int64, device=I1.device)
+    if seed is not None and on_gpu(I1) and isinstance(pc, torch.Tensor) and pc.is_cuda:
+        # probability and seed both on the device: the call reads no host value (it can be recorded into a HIP graph)
+        seed = seed.reshape(-1)[:1].to(device=I1.device, dtype=torch.int32).contiguous()
+        pcd = pc.reshape(-1)[:1].to(torch.float32).contiguous()
+        scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
+        check(hip().evox_hip_stochastic_ranking_fresh_dev(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pcd.data_ptr(), n,
+                                                          rank.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                                                          stream_of(I1)), "stochastic_ranking_fresh")
+        return rank
     pc = float(pc)
     if seed is not None:
         seed = seed.reshape(-1)[:1].to(device=I1.device, dtype=torch.int32).contiguous()

@@ -1477,6 +1477,9 @@ def test_stochastic_ranking_with_fresh_coins_equals_host_twin(cuda, n):
     ref = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
     assert torch.equal(got.cpu(), ref)
     assert sorted(got.tolist()) == list(range(n))
+    # the probability on the device (the form a recorded generation uses): the same order
+    got_dev = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), None, torch.tensor(0.47, device=cuda), seed=seed.to(cuda))
+    assert torch.equal(got_dev, got)
 
 
 @pytest.mark.parametrize("n,mu", [(1000, 5632), (64, 128), (260, 300)])
@@ -1518,7 +1521,7 @@ def test_packed_gram_equals_full_gram(cuda, n, mu):
 
 
 @pytest.mark.parametrize("name", ["NSGA2", "NSGA3", "GDE3", "TDEA", "HypE", "MOEAD", "IBEA", "BiGE", "EAGMOEAD", "RVEA", "RVEAa",
-                                  "MOEADDRA", "LMOCSO"])
+                                  "MOEADDRA", "LMOCSO", "SRA"])
 def test_multi_objective_generation_replays_from_a_graph(cuda, name):
     """A generation of these algorithms has no host read at the usual population sizes (the merged population is sorted
     by the one-launch kernel, cuts and counts stay on the device): it is recorded once and replayed, and every replay
