@@ -108,6 +108,9 @@ class CMAES(Algorithm):
                                              initial_cond=1.0)        # the covariance starts as the identity
         else:
             self._ns = None
+        # eager generations before a workflow first records the step into a HIP graph: the factorisation's iteration
+        # control starts conservative and settles within a couple of dozen calls, one decision per call
+        self.graph_settle_steps = 24 if self._ns is not None else 0
 
     # ------------------------------------------------------------------------------------
     def setup(self, key):
@@ -197,8 +200,19 @@ class CMAES(Algorithm):
         iters, safe = ns._policy(old_iters, max(0, old_safe - 8), rec[5], rec[6] != 0.0, max(1, old_iters))
         cond = rec[1] if not rec[0] > 0.0 else min(rec[1], ns.COND_TRUST * rec[0])
         symmetric = bool(ns.planes and 0.0 < cond <= ns.SYM_COND_MAX and safe == 0)
-        if iters == old_iters and (safe > 0) == (old_safe > 0) and symmetric == bool(int(state.ns_sym)):
+        old_sym = bool(int(state.ns_sym))
+        if iters == old_iters and (safe > 0) == (old_safe > 0) and symmetric == old_sym:
+            self._retune_relax = 0
             return None
+        # a new recording costs milliseconds.  Decisions that the accuracy needs (more iterations, safe scaling, leaving
+        # the bf16 driver) are taken at once; decisions that only save work must be asked for by three polls in a row, so
+        # that a residual hovering around the tolerance does not make the recording flap
+        needed = iters > old_iters or (safe > 0 and old_safe == 0) or (old_sym and not symmetric)
+        if not needed:
+            self._retune_relax = getattr(self, "_retune_relax", 0) + 1
+            if self._retune_relax < 3:
+                return None
+        self._retune_relax = 0
         return state.replace(ns_iters=iters, ns_safe=safe, ns_sym=int(symmetric))
 
     def _sample_scale(self, state):

@@ -103,6 +103,7 @@ class StdWorkflow(Workflow):
         self.graph_step = graph_step
         self.graph_mode = graph_mode
         self.graph_replays = 0
+        self._eager_before_graph = 0
         if external_problem and num_objectives is None:
             raise ValueError("Using external problem, but num_objectives isn't set")
         self.pmap_axis_name = None
@@ -237,6 +238,13 @@ class StdWorkflow(Workflow):
 
     def step(self, state):
         if not (self.graph_step and not state.first_step):
+            return self._step(state)
+        # An algorithm whose host-side control settles over its first generations (the iteration count of CMA-ES's
+        # factorisation starts conservative) asks for that many eager generations before the first recording: in eager
+        # mode the control adapts every generation, in a recording it is frozen between polls.
+        settle = int(getattr(self.algorithm, "graph_settle_steps", 0) or 0)
+        if self._graphed is None and self._eager_before_graph < settle:
+            self._eager_before_graph += 1
             return self._step(state)
         # Steady-state generations replay a recording of the bare step; the monitors observe
         # it from outside: pre_* hooks see the incoming state, post_* hooks the outgoing one,

@@ -1,6 +1,6 @@
 """Which algorithms' steady-state step can be replayed from a HIP graph, and what it buys.
 
-    python tools/graph_survey.py [--dim 100] [--pop 1024] [--steps 100] [--warmup 20]
+    python tools/graph_survey.py [--dim 100] [--pop 1024] [--steps 100] [--warmup 80]
 
 For every algorithm: eager ms/step, graphed ms/step (pointer-stable ring replay, and the copy-in / clone-out
 mode for comparison), and whether the graphed run reproduces the eager one exactly.  A step that synchronises with the host or keeps a changing Python value in
@@ -66,7 +66,7 @@ if __name__ == "__main__":
     ap.add_argument("--dim", type=int, default=100)
     ap.add_argument("--pop", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=80)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     dev = torch.device("cuda")
