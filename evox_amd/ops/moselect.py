@@ -41,6 +41,10 @@ _native.register_hip_api({
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
     "evox_hip_ibea_remove_multi_max": (I64, [I]),
     "evox_hip_ibea_remove_obj_multi": (I, [P, I, I, P, F, P, I, P, P, P, I, P]),
+    "evox_hip_ibea_lazy_max": (I64, [I]),
+    "evox_hip_ibea_lazy_rem_floats": (I64, [I]),
+    "evox_hip_ibea_lazy_ctrl_words": (I64, []),
+    "evox_hip_ibea_lazy_rounds": (I, [P, I, I, P, F, P, I, P, P, I, I, I, P]),
 })
 
 
@@ -99,8 +103,66 @@ def _ibea_multi(n: int, m: int) -> bool:
             and n <= int(hip().evox_hip_ibea_remove_multi_max(int(m))) and not torch.cuda.is_current_stream_capturing())
 
 
+_IBEA_LAZY_MIN_N = 2048          # from here on the removal runs in chip-wide rounds
+_IBEA_LAZY_K = 256               # members a round looks at (``csrc/ibea_lazy.hip::kK``)
+_IBEA_LAZY_MIN_RATE = 6.0        # removals per round below which the one-at-a-time loop is the cheaper way
+
+
+def _ibea_lazy(n: int, m: int) -> bool:
+    return (os.environ.get("EVOX_AMD_IBEA_LAZY", "1") == "1" and n >= _IBEA_LAZY_MIN_N
+            and n <= int(hip().evox_hip_ibea_lazy_max(int(m))) and not torch.cuda.is_current_stream_capturing())
+
+
 def ibea_remove_streaming_fits(n: int, m: int) -> bool:
-    return int(n) <= int(hip().evox_hip_ibea_remove_obj_max(int(m))) or _ibea_multi(int(n), int(m))
+    return (int(n) <= int(hip().evox_hip_ibea_remove_obj_max(int(m))) or _ibea_lazy(int(n), int(m))
+            or _ibea_multi(int(n), int(m)))
+
+
+def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, flags: int = 0,
+                       min_rate: float = None) -> torch.Tensor:
+    """The removal loop in rounds (``csrc/ibea_lazy.hip``): fitness values only grow while members are removed, so the
+    256 members with the smallest fitness can be played through on one wave for as long as their smallest stays below
+    the 257th of the round's start, and the increments of everything removed are then added to the whole population by a
+    chip-wide launch.  The survivors are those of the one-at-a-time loop.  The number of rounds depends on the data
+    (≈ removals / 150 on converging populations): rounds are issued in chunks and the count of removed members is read
+    back after each chunk (later rounds of a chunk are no-ops once the removal is complete).  A chunk that removed fewer
+    than ``min_rate`` members per round hands the rest to the one-at-a-time loop.  ``flags`` = 1 switches the sentinel
+    rounds off (tests)."""
+    n, m = obj.shape
+    n_remove = int(n_remove)
+    work = fit.detach().clone().contiguous()
+    if n_remove <= 0:
+        return work < float("inf")
+    obj = obj.contiguous()
+    C = C.contiguous()
+    ctrl = torch.empty(int(hip().evox_hip_ibea_lazy_ctrl_words()), dtype=torch.int32, device=obj.device)
+    rem = torch.empty(int(hip().evox_hip_ibea_lazy_rem_floats(m)), dtype=torch.float32, device=obj.device)
+    rounds = max(4, int(n_remove / (0.6 * _IBEA_LAZY_K)) + 2)
+    reset, done, worked, issued, fallback, alive = 1, 0, 0, 0, False, None
+    while True:
+        check(hip().evox_hip_ibea_lazy_rounds(obj.data_ptr(), n, m, C.data_ptr(), float(kappa), work.data_ptr(), n_remove,
+                                              ctrl.data_ptr(), rem.data_ptr(), reset, rounds, int(flags), stream_of(obj)),
+              "ibea_lazy_rounds")
+        issued += rounds
+        state = ctrl.tolist()
+        if state[0] >= n_remove or state[0] == done:        # complete, or nothing left to remove
+            break
+        chunk_rate = (state[0] - done) / max(1, state[1] - worked)
+        done, worked, reset = state[0], state[1], 0
+        if chunk_rate < (_IBEA_LAZY_MIN_RATE if min_rate is None else min_rate) and n <= int(hip().evox_hip_ibea_remove_obj_max(int(m))):
+            # rounds that remove only a handful each (everyone's fitness rises together, e.g. tight clusters of
+            # near-copies) cost more than the one-at-a-time loop: it finishes the job from the current fitness values
+            alive = torch.empty(n, dtype=torch.uint8, device=obj.device)
+            check(hip().evox_hip_ibea_remove_obj(obj.data_ptr(), n, m, C.data_ptr(), float(kappa), work.data_ptr(),
+                                                 n_remove - done, alive.data_ptr(), stream_of(obj)), "ibea_remove_obj")
+            fallback = True
+            break
+        per_round = max(1.0, done / max(1, state[1]))
+        rounds = max(4, int(1.25 * (n_remove - done) / per_round) + 1)
+    if stats is not None:
+        stats.update(removed=state[0], rounds=state[1], tie_rounds=state[3], issued=issued, select_us=state[4] / 100.0,
+                     simulate_us=state[5] / 100.0, bisections=state[6], sentinel_rounds=state[9], fallback=fallback)
+    return alive.bool() if fallback else work < float("inf")
 
 
 def ibea_remove_streaming(obj, fit, C, kappa, n_remove: int) -> torch.Tensor:
@@ -113,6 +175,8 @@ def ibea_remove_streaming(obj, fit, C, kappa, n_remove: int) -> torch.Tensor:
     agreement costs ≈ 2.5 µs per removal on this part (device-scope traffic between workgroups leaves the die), as much
     as the single compute unit needs for the whole removal — 29.4 against 31.7 ms per generation at population 10⁴."""
     n, m = obj.shape
+    if _ibea_lazy(n, m) and not _ibea_multi(n, m):
+        return ibea_remove_rounds(obj, fit, C, kappa, n_remove)
     obj = obj.contiguous()
     alive = torch.empty(n, dtype=torch.uint8, device=obj.device)
     if _ibea_multi(n, m):

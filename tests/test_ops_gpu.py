@@ -1627,6 +1627,7 @@ def test_ibea_removal_on_eight_compute_units_equals_single_workgroup_loop(n, m, 
     obj[n // 3] = obj[n // 5]                                   # identical members: equal fitness, index decides
     fit, C = moselect.ibea_fitness(obj, 0.05)
     monkeypatch.setenv("EVOX_AMD_IBEA_MULTI", "1")             # opt-in form
+    monkeypatch.setenv("EVOX_AMD_IBEA_LAZY", "0")              # the reference is the single-workgroup loop
     assert moselect._ibea_multi(n, m)
     got = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
     monkeypatch.setenv("EVOX_AMD_IBEA_MULTI", "0")
@@ -1635,3 +1636,69 @@ def test_ibea_removal_on_eight_compute_units_equals_single_workgroup_loop(n, m, 
         want = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
         assert torch.equal(got, want)
     assert int(got.sum()) == n - n_remove
+
+
+def _ibea_front(n, m, seed, kind):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(n, m, generator=g).abs()
+    d = d / d.norm(dim=1, keepdim=True)
+    rad = 1 + torch.where(torch.arange(n) < n // 2, 0.02, 0.15) * torch.randn(n, generator=g).abs()
+    obj = d * rad[:, None]
+    if kind == "quantised":                              # a few hundred distinct points, each many times
+        obj = (obj * 8).round() / 8
+    elif kind == "flood":                                # clones of one point among distinct ones
+        obj[n // 3: n // 3 + n // 6] = obj[7]
+    elif kind == "pairs":
+        obj[n // 2:] = obj[: n - n // 2]
+    return ((obj - obj.min()) / (obj.max() - obj.min())).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,kind", [(2500, 3, "front"), (6000, 3, "front"), (9000, 2, "front"), (5000, 5, "front"),
+                                      (17000, 3, "front"), (4000, 3, "quantised"), (6000, 3, "flood"), (5000, 4, "pairs"),
+                                      (3000, 3, "identical")])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_ibea_round_wise_removal_equals_one_at_a_time_loop(n, m, kind, flags, monkeypatch):
+    """Removal in rounds (the 256 members of smallest fitness played through on one wave while their smallest stays below
+    the 257th of the round's start, then one chip-wide update) removes exactly the members the one-at-a-time loop
+    removes: fitness only grows during the loop, and additions happen in the same order with the same expression.
+    Covered: converging fronts, exact duplicates (equal fitness: the index decides), a flood of clones of one point (tie
+    rounds, with and without the sentinel: ``flags``) and a population made of two points."""
+    from evox_amd.ops import moselect
+
+    obj = _ibea_front(n, m, n + m, kind)
+    if kind == "identical":                              # two points, each many times
+        obj = torch.where((torch.arange(n, device="cuda") % 3 == 0)[:, None], obj[:1], obj[1:2]).contiguous()
+    fit, C = moselect.ibea_fitness(obj, 0.05)
+    n_remove = n // 2 + 3
+    monkeypatch.setenv("EVOX_AMD_IBEA_LAZY", "0")
+    want = moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove)
+    monkeypatch.setenv("EVOX_AMD_IBEA_LAZY", "1")
+    stats = {}
+    got = moselect.ibea_remove_rounds(obj, fit, C, 0.05, n_remove, stats, flags=flags, min_rate=0.0)   # rounds to the end
+    assert stats["removed"] == n_remove and not stats["fallback"]
+    assert torch.equal(got, want), (int((got != want).sum()), stats)
+    assert int(got.sum()) == n - n_remove
+    if kind in ("flood", "identical"):
+        assert stats["tie_rounds"] > 0 and (stats["sentinel_rounds"] > 0) == (flags == 0)
+    if flags == 0:
+        # the dispatcher (fallback to the one-at-a-time loop when rounds remove too few) gives the same survivors
+        assert moselect._ibea_lazy(n, m)
+        assert torch.equal(moselect.ibea_remove_streaming(obj, fit, C, 0.05, n_remove), want)
+
+
+@pytest.mark.gpu
+def test_ibea_round_wise_removal_edge_counts():
+    from evox_amd.ops import moselect
+
+    obj = _ibea_front(3000, 3, 5, "front")
+    fit, C = moselect.ibea_fitness(obj, 0.05)
+    assert bool(moselect.ibea_remove_rounds(obj, fit, C, 0.05, 0).all())
+    one = moselect.ibea_remove_rounds(obj, fit, C, 0.05, 1)
+    assert int((~one).sum()) == 1 and int(torch.nonzero(~one)[0, 0]) == int(torch.argmin(fit))
+    # more removals asked for than members: everything goes, and the call returns
+    none = moselect.ibea_remove_rounds(obj, fit, C, 0.05, 5000)
+    assert int(none.sum()) == 0
+    # fewer than a round's 256 members left at the end
+    few = moselect.ibea_remove_rounds(obj, fit, C, 0.05, 2990, min_rate=0.0)
+    assert int(few.sum()) == 10
