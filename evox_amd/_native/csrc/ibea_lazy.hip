@@ -22,10 +22,15 @@ constexpr int kSel = 1024;          // threads of the select / simulate workgrou
 constexpr int kK = 256;             // size of S
 constexpr int kPerLane = kK / 64;
 constexpr unsigned kDeadKey = 0xFFFFFFFFu;
+constexpr int kClones = 32;         // clones of a flooding point that a round keeps in S
+constexpr int kCandPer = 8;          // candidates per thread of the select workgroup
+constexpr int kCandCap = kCandPer * kSel;
 constexpr int kNoSentinel = 1;      // flag: tie rounds never use the sentinel (for tests of the plain tie order)
+constexpr int kNoCandidates = 2;    // flag: every round scans the whole population for S
 
 // control words (int32) shared by the launches of one removal
-enum { kRemoved = 0, kRounds = 1, kRoundCount = 2, kTieRounds = 3, kSelectTicks = 4, kSimTicks = 5, kBisections = 6, kTau = 7, kTauStep = 8, kSentinelRounds = 9, kCtrlWords = 12 };
+enum { kRemoved = 0, kRounds = 1, kRoundCount = 2, kTieRounds = 3, kSelectTicks = 4, kSimTicks = 5, kBisections = 6, kTau = 7, kTauStep = 8, kSentinelRounds = 9, kGuess = 10, kGuessMult = 11, kCandCount = 12, kCandRounds = 13,
+       kCtrlWords = 16 };
 
 template <int M>
 __device__ __forceinline__ float eps_ind(const float (&a)[M], const float (&b)[M]) {
@@ -80,6 +85,32 @@ __device__ __forceinline__ int block_count_below(const unsigned (&key)[E], unsig
 #pragma unroll
   for (int w = 0; w < kSel / 64; ++w) total += buf[w];
   return total;
+}
+
+// τ with count(key < τ) ≤ K, as large as a short search finds: count(lo) ≤ K < count(hi) throughout.  Keys only grow from
+// round to round, so the previous round's τ is still a valid lower end, and the distance it moved last time is a good
+// first step from there.  `tie`: the search ran out with fewer than K/2 members below τ — more than K/2 share the key τ.
+template <int E>
+__device__ __forceinline__ unsigned find_tau(const unsigned (&key)[E], unsigned tau_prev, unsigned step, int (*s_cnt)[kSel / 64],
+                                             int& flip, int& bisections, int& below, bool& tie) {
+  unsigned lo = tau_prev, hi = kDeadKey;
+  below = 0;
+  if (lo != 0) { below = block_count_below<E>(key, lo, s_cnt[flip]); flip ^= 1; ++bisections; }
+  while (step != 0 && below < kK / 2) {
+    const unsigned cand = lo + step;
+    if (cand < lo || cand >= kDeadKey) break;
+    const int c = block_count_below<E>(key, cand, s_cnt[flip]); flip ^= 1;
+    ++bisections;
+    if (c <= kK) { lo = cand; below = c; step = step < 0x40000000u ? step * 2 : step; } else { hi = cand; break; }
+  }
+  while (hi - lo > 1 && below < kK / 2) {
+    const unsigned mid = lo + (hi - lo) / 2;
+    const int c = block_count_below<E>(key, mid, s_cnt[flip]); flip ^= 1;
+    if (c <= kK) { lo = mid; below = c; } else hi = mid;
+    ++bisections;
+  }
+  tie = below < kK / 2;
+  return lo;
 }
 
 // The removals among the members of S, by one wave; returns how many.  The arg-min runs on integer keys with the order
@@ -181,11 +212,13 @@ template <int M, int E>
 __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __restrict__ obj, int n,
                                                                 const float* __restrict__ C, float kappa,
                                                                 float* __restrict__ fit, int n_remove,
-                                                                int* __restrict__ ctrl, float* __restrict__ rem, int flags) {
+                                                                int* __restrict__ ctrl, float* __restrict__ rem,
+                                                                const int* __restrict__ cand, int flags) {
   __shared__ int s_cnt[2][kSel / 64];
   __shared__ int s_scan[kSel / 64];
   __shared__ int s_n;                 // members of S so far
   __shared__ int s_tidx;              // index part of T
+  __shared__ int s_tclone;            // tie round: the clone after the first kClones
   __shared__ int s_idx[kK];
   __shared__ float s_f[kK];
   __shared__ float s_obj[M][kK];
@@ -203,52 +236,57 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
   const long long t_start = wall_clock64();
   int bisections = 0;
   const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned tau_prev = (unsigned)ctrl[kTau], step_prev = (unsigned)ctrl[kTauStep];
+  const int cc = ctrl[kCandCount];
+  int mult = ctrl[kGuessMult];
+  if (mult == 0) mult = 4;
+  if (ctrl[kGuess] != 0) {            // the last apply launch collected candidates: too few, or too many?
+    if (cc <= kK) mult = min(mult * 2, 256);
+    else if (cc > kCandCap / 2) mult = max(mult / 2, 1);
+  }
+  if (tid == 0) { s_n = 0; s_tidx = -1; s_dup = 1; s_next = kDeadKey; }
+  if (tid < kK) { s_idx[tid] = 0x7fffffff; s_f[tid] = INFINITY; }
+  int flip = 0;
+  unsigned tau = kDeadKey, tau_warm = kDeadKey;
+  int below = 0;
+  bool tie = false, clones = false;
+
+  // ---- select among the candidates the last apply launch listed: every member with a key below its guess G.  More
+  // than K of them: the K + 1 smallest of the population are among them.  (A tie needs the index order: full scan.)
+  bool from_cand = cc > kK && cc <= kCandCap && (flags & kNoCandidates) == 0;
+  if (from_cand) {
+    unsigned ck[kCandPer];
+    int ci[kCandPer];
+#pragma unroll
+    for (int e = 0; e < kCandPer; ++e) {
+      const int p = tid + e * kSel;
+      ck[e] = kDeadKey; ci[e] = 0;
+      if (p < cc) { ck[e] = (unsigned)cand[2 * p]; ci[e] = cand[2 * p + 1]; }
+    }
+    tau = find_tau<kCandPer>(ck, tau_prev, step_prev, s_cnt, flip, bisections, below, tie);
+    tau_warm = tau;
+    if (tie) from_cand = false;
+    else {
+#pragma unroll
+      for (int e = 0; e < kCandPer; ++e)
+        if (ck[e] < tau) s_idx[atomicAdd(&s_n, 1)] = ci[e];
+    }
+  }
+  if (!from_cand) {
   unsigned key[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const int j = tid * E + e;
     key[e] = j < n ? member_key(fit[j]) : kDeadKey;
   }
-  if (tid == 0) { s_n = 0; s_tidx = -1; s_dup = 1; s_next = kDeadKey; }
-  if (tid < kK) { s_idx[tid] = 0x7fffffff; s_f[tid] = INFINITY; }
-
-  // ---- select: τ with count(key < τ) ≤ K, as large as a bisection finds quickly
-  int flip = 0;
   const int alive = block_count_below<E>(key, kDeadKey, s_cnt[flip]); flip ^= 1;
-  unsigned tau = kDeadKey;            // alive ≤ K: S is everyone
-  int below = alive;
-  bool tie = false;
-  if (alive > kK) {
-    // count(lo) ≤ K < count(hi).  Keys only grow from round to round, so the previous round's τ is still a valid lower
-    // end, and the distance it moved last time is a good first step from there.
-    unsigned lo = (unsigned)ctrl[kTau], hi = kDeadKey;
-    unsigned step = (unsigned)ctrl[kTauStep];
-    const unsigned tau_prev = lo;
-    below = 0;
-    if (lo != 0) { below = block_count_below<E>(key, lo, s_cnt[flip]); flip ^= 1; ++bisections; }
-    while (step != 0 && below < kK / 2) {
-      const unsigned cand = lo + step;
-      if (cand < lo || cand >= kDeadKey) break;
-      const int c = block_count_below<E>(key, cand, s_cnt[flip]); flip ^= 1;
-      ++bisections;
-      if (c <= kK) { lo = cand; below = c; step = step < 0x40000000u ? step * 2 : step; } else { hi = cand; break; }
-    }
-    while (hi - lo > 1 && below < kK / 2) {
-      const unsigned mid = lo + (hi - lo) / 2;
-      const int c = block_count_below<E>(key, mid, s_cnt[flip]); flip ^= 1;
-      if (c <= kK) { lo = mid; below = c; } else hi = mid;
-      ++bisections;
-    }
-    tau = lo;
-    tie = below < kK / 2;             // bisection ran out: more than K/2 members share the key τ
-    if (tid == 0) { ctrl[kTau] = (int)tau; ctrl[kTauStep] = (int)(tau_prev != 0 && tau > tau_prev ? tau - tau_prev : 0); }
-  }
-  // members below τ go to S in any order
-#pragma unroll
-  for (int e = 0; e < E; ++e)
-    if (key[e] < tau) s_idx[atomicAdd(&s_n, 1)] = tid * E + e;
+  tau = kDeadKey;                     // alive ≤ K: S is everyone
+  below = alive;
+  tie = false;
+  if (alive > kK) tau = find_tau<E>(key, tau_prev, step_prev, s_cnt, flip, bisections, below, tie);
+  tau_warm = tau;
   if (tie) {
-    // the members with key == τ join in index order until S is full; the first one left out is T
+    // position of every member with key == τ among them, in index order
     int mine = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) mine += key[e] == tau ? 1 : 0;
@@ -263,22 +301,19 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
     int before = incl - mine;
     for (int w = 0; w < (tid >> 6); ++w) before += s_scan[w];
     const int room = kK - below;      // > K/2
-    int pos = before;
+    {
+      int pos = before;
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (key[e] == tau) {
-        if (pos < room) s_idx[below + pos] = tid * E + e;
-        else if (pos == room) s_tidx = tid * E + e;
-        ++pos;
-      }
-    unsigned above = kDeadKey;
-#pragma unroll
-    for (int e = 0; e < E; ++e) above = key[e] > tau ? min(above, key[e]) : above;
-    above = wave_min_dpp(above);
-    if (lane == 0) atomicMin(&s_next, above);
+      for (int e = 0; e < E; ++e)
+        if (key[e] == tau) {
+          if (pos == room) s_tidx = tid * E + e;
+          if (pos == kClones) s_tclone = tid * E + e;
+          ++pos;
+        }
+    }
     __syncthreads();
-    // are the members of the tie group copies of one point?  (T's member is one of them)
-    const int tj = s_tidx;
+    // are the members of the tie group copies of one point?
+    const int tj = s_tclone;
     float o_t[M];
 #pragma unroll
     for (int k = 0; k < M; ++k) o_t[k] = obj[(int64_t)tj * M + k];
@@ -293,7 +328,45 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
         for (int k = 0; k < M; ++k) same = same && obj[(int64_t)j * M + k] == o_t[k];
       }
     if (!same) s_dup = 0;
+    __syncthreads();
+    clones = s_dup != 0 && (flags & kNoSentinel) == 0;
+    if (clones) {
+      // A flood of clones: only the first kClones of them (by index) stand for the group in S, the next one is the
+      // sentinel, and the freed places go to the members above τ: the search runs again with the other clones struck
+      // out and yields τ₂ ≥ τ, the stale bound of everyone outside S who is not a clone.
+      int pos = before;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (key[e] == tau) {
+          if (pos >= kClones) key[e] = kDeadKey;
+          ++pos;
+        }
+      int below2;
+      bool tie2;
+      const unsigned tau2 = find_tau<E>(key, tau, step_prev, s_cnt, flip, bisections, below2, tie2);
+      if (tid == 0) { s_tidx = s_tclone; s_next = tau2; }
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (key[e] < tau2) s_idx[atomicAdd(&s_n, 1)] = tid * E + e;
+    } else {
+      // the members with key == τ join in index order until S is full; the first one left out is T
+      int pos = before;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if (key[e] < tau) s_idx[atomicAdd(&s_n, 1)] = tid * E + e;
+        if (key[e] == tau) {
+          if (pos < room) s_idx[below + pos] = tid * E + e;
+          ++pos;
+        }
+      }
+    }
+  } else {
+    // members below τ go to S in any order
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (key[e] < tau) s_idx[atomicAdd(&s_n, 1)] = tid * E + e;
   }
+  }  // full scan
   __syncthreads();
   if (tid < kK) {
     const int j = s_idx[tid];
@@ -313,7 +386,7 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
 
   // ---- simulate: wave 0, no barrier from here on
   const long long t_sim = wall_clock64();
-  const bool sentinel = tie && s_dup != 0 && (flags & kNoSentinel) == 0;
+  const bool sentinel = clones;
   const int tau_key = (int)(tau ^ 0x80000000u);            // τ in the signed order of `simulate`
   const int removed = sentinel
       ? simulate<M, true>(s_f, s_idx, s_obj, s_s, s_order, lane, budget, tau_key, s_tidx, (int)(s_next ^ 0x80000000u), obj, fit)
@@ -332,6 +405,18 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
     ctrl[kRoundCount] = removed;
     if (tie) ctrl[kTieRounds] += 1;
     if (sentinel) ctrl[kSentinelRounds] += 1;
+    if (from_cand) ctrl[kCandRounds] += 1;
+    // for the next round: τ, how far it moved, and the guess G below which the apply launch lists candidates
+    const unsigned moved = tau_warm != kDeadKey && tau_prev != 0 && tau_warm > tau_prev ? tau_warm - tau_prev : 0;
+    unsigned guess = 0;
+    if (moved != 0 && !tie) {
+      const unsigned long long g = (unsigned long long)tau_warm + (unsigned long long)moved * (unsigned)mult;
+      guess = g < kDeadKey ? (unsigned)g : 0;
+    }
+    if (tau_warm != kDeadKey) { ctrl[kTau] = (int)tau_warm; ctrl[kTauStep] = (int)moved; }
+    ctrl[kGuess] = (int)guess;
+    ctrl[kGuessMult] = mult;
+    ctrl[kCandCount] = 0;
     // time spent (100 MHz ticks) finding S and playing the removals, and bisection steps: for tuning
     ctrl[kSelectTicks] += (int)(t_sim - t_start);
     ctrl[kSimTicks] += (int)(wall_clock64() - t_sim);
@@ -339,29 +424,46 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
   }
 }
 
-// fit[j] += Σ_t exp(I(x_t, j) · s_t) over the members removed in the round, in removal order
+// fit[j] += Σ_t exp(I(x_t, j) · s_t) over the members removed in the round, in removal order.  Members whose new key is
+// below the guess G that the select launch left in ctrl are listed in `cand` as (key, index) for the next select launch.
 template <int M>
 __global__ __launch_bounds__(256) void ibea_lazy_apply_kernel(const float* __restrict__ obj, int n, float* __restrict__ fit,
-                                                              const int* __restrict__ ctrl, const float* __restrict__ rem) {
+                                                              int* __restrict__ ctrl, const float* __restrict__ rem,
+                                                              int* __restrict__ cand) {
   __shared__ float s_rem[kK * (M + 1)];
   const int count = ctrl[kRoundCount];
   if (count <= 0) return;
+  const unsigned guess = (unsigned)ctrl[kGuess];
   for (int i = threadIdx.x; i < count * (M + 1); i += 256) s_rem[i] = rem[i];
   __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  float f = fit[j];
-  if (!(f < INFINITY)) return;
-  float oj[M];
+  float f = j < n ? fit[j] : INFINITY;
+  const bool live = f < INFINITY;
+  if (live) {
+    float oj[M];
 #pragma unroll
-  for (int k = 0; k < M; ++k) oj[k] = obj[(int64_t)j * M + k];
-  for (int t = 0; t < count; ++t) {
-    float ox[M];
+    for (int k = 0; k < M; ++k) oj[k] = obj[(int64_t)j * M + k];
+    for (int t = 0; t < count; ++t) {
+      float ox[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) ox[k] = s_rem[t * (M + 1) + k];
-    f += __expf(eps_ind<M>(ox, oj) * s_rem[t * (M + 1) + M]);
+      for (int k = 0; k < M; ++k) ox[k] = s_rem[t * (M + 1) + k];
+      f += __expf(eps_ind<M>(ox, oj) * s_rem[t * (M + 1) + M]);
+    }
+    fit[j] = f;
   }
-  fit[j] = f;
+  const unsigned key = live ? member_key(f) : kDeadKey;
+  const bool listed = guess != 0 && key < guess;
+  const unsigned long long mask = __ballot(listed);
+  if (mask != 0) {                                        // one atomic per wave
+    const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(mask);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&ctrl[kCandCount], (int)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (listed) {
+      const int pos = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+      if (pos < kCandCap) { cand[2 * pos] = (int)key; cand[2 * pos + 1] = j; }
+    }
+  }
 }
 
 __global__ __launch_bounds__(64) void ibea_lazy_reset_kernel(int* ctrl) {
@@ -370,22 +472,26 @@ __global__ __launch_bounds__(64) void ibea_lazy_reset_kernel(int* ctrl) {
 
 template <int M, int E>
 int launch_rounds(const float* obj, int n, const float* C, float kappa, float* fit, int n_remove, int* ctrl, float* rem,
-                  int rounds, int flags, hipStream_t st) {
+                  int* cand, int rounds, int flags, hipStream_t st) {
   const int blocks = (n + 255) / 256;
   for (int r = 0; r < rounds; ++r) {
-    ibea_lazy_select_kernel<M, E><<<1, kSel, 0, st>>>(obj, n, C, kappa, fit, n_remove, ctrl, rem, flags);
-    ibea_lazy_apply_kernel<M><<<blocks, 256, 0, st>>>(obj, n, fit, ctrl, rem);
+    ibea_lazy_select_kernel<M, E><<<1, kSel, 0, st>>>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, flags);
+    ibea_lazy_apply_kernel<M><<<blocks, 256, 0, st>>>(obj, n, fit, ctrl, rem, cand);
   }
   return last_launch_status();
 }
 
 template <int M>
 int launch_rounds_any(const float* obj, int n, const float* C, float kappa, float* fit, int n_remove, int* ctrl, float* rem,
-                      int rounds, int flags, hipStream_t st) {
-  if (n <= 8 * kSel) return launch_rounds<M, 8>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-  if (n <= 16 * kSel) return launch_rounds<M, 16>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-  if (n <= 32 * kSel) return launch_rounds<M, 32>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-  if (n <= 64 * kSel) return launch_rounds<M, 64>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
+                      int* cand, int rounds, int flags, hipStream_t st) {
+  if (n <= 4 * kSel) return launch_rounds<M, 4>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 8 * kSel) return launch_rounds<M, 8>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 12 * kSel) return launch_rounds<M, 12>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 16 * kSel) return launch_rounds<M, 16>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 20 * kSel) return launch_rounds<M, 20>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 24 * kSel) return launch_rounds<M, 24>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 32 * kSel) return launch_rounds<M, 32>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+  if (n <= 64 * kSel) return launch_rounds<M, 64>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
   return (int)hipErrorInvalidValue;
 }
 
@@ -397,24 +503,25 @@ EVOX_API int64_t evox_hip_ibea_lazy_max(int m) { return m >= 2 && m <= 8 ? (int6
 // Floats of the `rem` scratch and int32 words of `ctrl`.
 EVOX_API int64_t evox_hip_ibea_lazy_rem_floats(int m) { return (int64_t)kK * (m + 1); }
 EVOX_API int64_t evox_hip_ibea_lazy_ctrl_words() { return kCtrlWords; }
+EVOX_API int64_t evox_hip_ibea_lazy_cand_words() { return 2 * kCandCap; }
 
 // reset != 0: start a removal (zeroes ctrl).  Then `rounds` rounds are issued; rounds after the n_remove-th removal do
 // nothing.  fit: (n) working copy, removed members end at +inf.  ctrl[0] = members removed so far, ctrl[1] = rounds
 // that did work, ctrl[3] = rounds that needed the tie order, ctrl[9] = of those, rounds with a sentinel.  flags: 1 = no
-// sentinel rounds.
+// sentinel rounds, 2 = no candidate lists.  cand: scratch of evox_hip_ibea_lazy_cand_words() int32.
 EVOX_API int evox_hip_ibea_lazy_rounds(const float* obj, int n, int m, const float* C, float kappa, float* fit, int n_remove,
-                                       int* ctrl, float* rem, int reset, int rounds, int flags, void* stream) {
+                                       int* ctrl, float* rem, int* cand, int reset, int rounds, int flags, void* stream) {
   if (n <= 0 || rounds <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (reset) ibea_lazy_reset_kernel<<<1, 64, 0, st>>>(ctrl);
   switch (m) {
-    case 2: return launch_rounds_any<2>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 3: return launch_rounds_any<3>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 4: return launch_rounds_any<4>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 5: return launch_rounds_any<5>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 6: return launch_rounds_any<6>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 7: return launch_rounds_any<7>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
-    case 8: return launch_rounds_any<8>(obj, n, C, kappa, fit, n_remove, ctrl, rem, rounds, flags, st);
+    case 2: return launch_rounds_any<2>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 3: return launch_rounds_any<3>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 4: return launch_rounds_any<4>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 5: return launch_rounds_any<5>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 6: return launch_rounds_any<6>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 7: return launch_rounds_any<7>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
+    case 8: return launch_rounds_any<8>(obj, n, C, kappa, fit, n_remove, ctrl, rem, cand, rounds, flags, st);
     default: return (int)hipErrorInvalidValue;
   }
 }

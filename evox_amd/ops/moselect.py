@@ -44,7 +44,8 @@ _native.register_hip_api({
     "evox_hip_ibea_lazy_max": (I64, [I]),
     "evox_hip_ibea_lazy_rem_floats": (I64, [I]),
     "evox_hip_ibea_lazy_ctrl_words": (I64, []),
-    "evox_hip_ibea_lazy_rounds": (I, [P, I, I, P, F, P, I, P, P, I, I, I, P]),
+    "evox_hip_ibea_lazy_rounds": (I, [P, I, I, P, F, P, I, P, P, P, I, I, I, P]),
+    "evox_hip_ibea_lazy_cand_words": (I64, []),
 })
 
 
@@ -105,6 +106,7 @@ def _ibea_multi(n: int, m: int) -> bool:
 
 _IBEA_LAZY_MIN_N = 2048          # from here on the removal runs in chip-wide rounds
 _IBEA_LAZY_K = 256               # members a round looks at (``csrc/ibea_lazy.hip::kK``)
+_IBEA_LAZY_CHUNK = 64             # rounds issued between two looks at the progress
 _IBEA_LAZY_MIN_RATE = 6.0        # removals per round below which the one-at-a-time loop is the cheaper way
 
 
@@ -126,8 +128,8 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
     chip-wide launch.  The survivors are those of the one-at-a-time loop.  The number of rounds depends on the data
     (≈ removals / 150 on converging populations): rounds are issued in chunks and the count of removed members is read
     back after each chunk (later rounds of a chunk are no-ops once the removal is complete).  A chunk that removed fewer
-    than ``min_rate`` members per round hands the rest to the one-at-a-time loop.  ``flags`` = 1 switches the sentinel
-    rounds off (tests)."""
+    than ``min_rate`` members per round hands the rest to the one-at-a-time loop.  ``flags``: 1 switches the sentinel
+    rounds off, 2 the candidate lists (tests)."""
     n, m = obj.shape
     n_remove = int(n_remove)
     work = fit.detach().clone().contiguous()
@@ -137,11 +139,13 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
     C = C.contiguous()
     ctrl = torch.empty(int(hip().evox_hip_ibea_lazy_ctrl_words()), dtype=torch.int32, device=obj.device)
     rem = torch.empty(int(hip().evox_hip_ibea_lazy_rem_floats(m)), dtype=torch.float32, device=obj.device)
-    rounds = max(4, int(n_remove / (0.6 * _IBEA_LAZY_K)) + 2)
+    cand = torch.empty(int(hip().evox_hip_ibea_lazy_cand_words()), dtype=torch.int32, device=obj.device)
+    rounds = min(_IBEA_LAZY_CHUNK, max(4, int(n_remove / (0.6 * _IBEA_LAZY_K)) + 2))
     reset, done, worked, issued, fallback, alive = 1, 0, 0, 0, False, None
     while True:
         check(hip().evox_hip_ibea_lazy_rounds(obj.data_ptr(), n, m, C.data_ptr(), float(kappa), work.data_ptr(), n_remove,
-                                              ctrl.data_ptr(), rem.data_ptr(), reset, rounds, int(flags), stream_of(obj)),
+                                              ctrl.data_ptr(), rem.data_ptr(), cand.data_ptr(), reset, rounds, int(flags),
+                                              stream_of(obj)),
               "ibea_lazy_rounds")
         issued += rounds
         state = ctrl.tolist()
@@ -158,10 +162,10 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
             fallback = True
             break
         per_round = max(1.0, done / max(1, state[1]))
-        rounds = max(4, int(1.25 * (n_remove - done) / per_round) + 1)
+        rounds = min(_IBEA_LAZY_CHUNK, max(4, int(1.25 * (n_remove - done) / per_round) + 1))
     if stats is not None:
         stats.update(removed=state[0], rounds=state[1], tie_rounds=state[3], issued=issued, select_us=state[4] / 100.0,
-                     simulate_us=state[5] / 100.0, bisections=state[6], sentinel_rounds=state[9], fallback=fallback)
+                     simulate_us=state[5] / 100.0, bisections=state[6], sentinel_rounds=state[9], candidate_rounds=state[13], fallback=fallback)
     return alive.bool() if fallback else work < float("inf")
 
 

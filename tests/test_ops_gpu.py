@@ -401,6 +401,7 @@ def test_cmaes_graph_step_matches_eager(cuda):
         # the eager path adapts its Newton-Schulz iteration count from a lagged residual while a
         # recording freezes it: pin the count so that both runs do identical arithmetic
         algo._ns.iters = algo._ns.min_iters = algo._ns.max_iters = 8
+        algo.graph_settle_steps = 0              # nothing to settle with a pinned count: record at once
         wf = workflows.StdWorkflow(algo, problems.numerical.Ackley(), graph_step=graph)
         s = wf.init(ex.PRNGKey(8))
         out = []
@@ -1657,13 +1658,14 @@ def _ibea_front(n, m, seed, kind):
 @pytest.mark.parametrize("n,m,kind", [(2500, 3, "front"), (6000, 3, "front"), (9000, 2, "front"), (5000, 5, "front"),
                                       (17000, 3, "front"), (4000, 3, "quantised"), (6000, 3, "flood"), (5000, 4, "pairs"),
                                       (3000, 3, "identical")])
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 2])
 def test_ibea_round_wise_removal_equals_one_at_a_time_loop(n, m, kind, flags, monkeypatch):
     """Removal in rounds (the 256 members of smallest fitness played through on one wave while their smallest stays below
     the 257th of the round's start, then one chip-wide update) removes exactly the members the one-at-a-time loop
     removes: fitness only grows during the loop, and additions happen in the same order with the same expression.
     Covered: converging fronts, exact duplicates (equal fitness: the index decides), a flood of clones of one point (tie
-    rounds, with and without the sentinel: ``flags``) and a population made of two points."""
+    rounds, with and without the sentinel: ``flags`` 1; ``flags`` 2: every round scans the whole population instead of
+    the candidates listed by the previous update launch) and a population made of two points."""
     from evox_amd.ops import moselect
 
     obj = _ibea_front(n, m, n + m, kind)
@@ -1680,7 +1682,10 @@ def test_ibea_round_wise_removal_equals_one_at_a_time_loop(n, m, kind, flags, mo
     assert torch.equal(got, want), (int((got != want).sum()), stats)
     assert int(got.sum()) == n - n_remove
     if kind in ("flood", "identical"):
-        assert stats["tie_rounds"] > 0 and (stats["sentinel_rounds"] > 0) == (flags == 0)
+        assert stats["tie_rounds"] > 0 and (stats["sentinel_rounds"] > 0) == (flags != 1)
+    if kind == "front" and n >= 5000:
+        # most rounds pick S from the candidates listed by the previous round's update launch
+        assert (stats["candidate_rounds"] > stats["rounds"] // 2) == (flags != 2), stats
     if flags == 0:
         # the dispatcher (fallback to the one-at-a-time loop when rounds remove too few) gives the same survivors
         assert moselect._ibea_lazy(n, m)
