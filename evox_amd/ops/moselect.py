@@ -46,6 +46,10 @@ _native.register_hip_api({
     "evox_hip_ibea_lazy_ctrl_words": (I64, []),
     "evox_hip_ibea_lazy_rounds": (I, [P, I, I, P, F, P, I, P, P, P, I, I, I, P]),
     "evox_hip_ibea_lazy_cand_words": (I64, []),
+    "evox_hip_spea2_lazy_max": (I64, [I]),
+    "evox_hip_spea2_lazy_ctrl_words": (I64, []),
+    "evox_hip_spea2_lazy_scratch_words": (I64, [I]),
+    "evox_hip_spea2_lazy_rounds": (I, [P, I, I, P, P, P, I, P, P, I, I, P]),
 })
 
 
@@ -268,6 +272,49 @@ def spea2_truncate_reference(obj, mask, n_remove: int) -> torch.Tensor:
     return keep
 
 
+_SPEA2_LAZY_MIN_N = 2048         # from here on the truncation runs in chip-wide rounds
+
+
+def _spea2_lazy(n: int, m: int) -> bool:
+    return (os.environ.get("EVOX_AMD_SPEA2_LAZY", "1") == "1" and _SPEA2_LAZY_MIN_N <= n
+            <= int(hip().evox_hip_spea2_lazy_max(int(m))) and not torch.cuda.is_current_stream_capturing())
+
+
+def spea2_truncate_rounds(points, n_remove: int, stats: dict = None) -> torch.Tensor:
+    """SPEA2 truncation of ``points`` (n, m), all of them candidates, in rounds (``csrc/spea2_lazy.hip``): nearest-neighbour
+    distances only grow while points are removed, so the 256 points with the smallest distance are played through on one
+    wave (each with the list of its 8 nearest live neighbours, collected by 256 workgroups at once) while their smallest
+    stays below the 257th of the round's start; every live point whose neighbour went is then rescanned chip-wide.  No
+    n × n distance matrix is formed, and the survivors are those of the one-at-a-time loop.  Returns the survivor mask."""
+    n, m = points.shape
+    n_remove = int(n_remove)
+    points = points.contiguous().float()
+    dev = points.device
+    alive = torch.ones(n, dtype=torch.uint8, device=dev)
+    if n_remove <= 0:
+        return alive.bool()
+    rowmin = torch.empty(n, dtype=torch.float32, device=dev)
+    nn = torch.empty(n, dtype=torch.int32, device=dev)
+    ctrl = torch.empty(int(hip().evox_hip_spea2_lazy_ctrl_words()), dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(hip().evox_hip_spea2_lazy_scratch_words(n)) // 2 + 1, dtype=torch.int64, device=dev)
+    rounds = min(_IBEA_LAZY_CHUNK, max(4, int(n_remove / (0.5 * _IBEA_LAZY_K)) + 2))
+    reset, done, issued = 1, 0, 0
+    while True:
+        check(hip().evox_hip_spea2_lazy_rounds(points.data_ptr(), n, m, alive.data_ptr(), rowmin.data_ptr(), nn.data_ptr(),
+                                               n_remove, ctrl.data_ptr(), scratch.data_ptr(), reset, rounds, stream_of(points)),
+              "spea2_lazy_rounds")
+        issued += rounds
+        state = ctrl.tolist()
+        if state[0] >= n_remove or state[0] == done:        # complete, or nothing left to remove
+            break
+        done, reset = state[0], 0
+        per_round = max(1.0, done / max(1, state[1]))
+        rounds = min(_IBEA_LAZY_CHUNK, max(4, int(1.25 * (n_remove - done) / per_round) + 1))
+    if stats is not None:
+        stats.update(removed=state[0], rounds=state[1], tie_rounds=state[8], short_rounds=state[9], issued=issued)
+    return alive.bool()
+
+
 def spea2_truncate(obj, mask, n_remove: int) -> torch.Tensor:
     """SPEA2 archive truncation among the rows selected by ``mask``: repeatedly drop the point
     whose nearest remaining neighbour is closest.  Returns the survivor mask (⊂ mask)."""
@@ -280,6 +327,10 @@ def spea2_truncate(obj, mask, n_remove: int) -> torch.Tensor:
         idx = torch.nonzero(mask).squeeze(1)
         sub = obj[idx].float()
         nv = sub.shape[0]
+        if _spea2_lazy(nv, sub.shape[1]):
+            keep = torch.zeros(n, dtype=torch.bool, device=obj.device)
+            keep[idx] = spea2_truncate_rounds(sub, n_remove)
+            return keep
         ld = (nv + 3) // 4 * 4
         dis = torch.full((nv, ld), float("inf"), dtype=torch.float32, device=obj.device)
         dis[:, :nv] = _cdist(sub, sub)

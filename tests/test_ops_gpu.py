@@ -1707,3 +1707,62 @@ def test_ibea_round_wise_removal_edge_counts():
     # fewer than a round's 256 members left at the end
     few = moselect.ibea_remove_rounds(obj, fit, C, 0.05, 2990, min_rate=0.0)
     assert int(few.sum()) == 10
+
+
+def _spea2_points(n, m, seed, kind):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(n, m, generator=g).abs()
+    d = d / d.norm(dim=1, keepdim=True)
+    if kind == "clones":                                 # distance zero among many points: tie rounds, lists run out
+        d[n // 3: n // 3 + n // 8] = d[5]
+    elif kind == "grid":                                 # many exactly equal distances
+        d = (d * 16).round() / 16
+    elif kind == "line":                                 # equidistant points: every nearest-neighbour distance is the same
+        d = torch.stack([torch.arange(n, dtype=torch.float32) / 8] + [torch.zeros(n)] * (m - 1), dim=1)
+    return d.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,kind", [(2100, 3, "front"), (6000, 2, "front"), (5000, 5, "front"), (13000, 3, "front"),
+                                      (4000, 3, "clones"), (5000, 3, "grid"), (3000, 2, "line")])
+def test_spea2_round_wise_truncation_equals_one_at_a_time_loop(n, m, kind, monkeypatch):
+    """Truncation in rounds (the 256 points with the closest neighbour played through on one wave with lists of their 8
+    nearest live neighbours, then a chip-wide rescan of every point whose neighbour went) keeps exactly the points the
+    one-at-a-time loop over the distance matrix keeps: nearest-neighbour distances only grow during the loop, and the
+    distances are computed with the expression of the matrix.  Equal distances (closest pairs, grids, clones, a line of
+    equidistant points) are decided by the index in both."""
+    from evox_amd.ops import moselect
+
+    pts = _spea2_points(n, m, n + m, kind)
+    mask = torch.ones(n, dtype=torch.bool, device="cuda")
+    n_remove = n // 2 + 7
+    monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "0")
+    want = moselect.spea2_truncate(pts, mask, n_remove)
+    monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "1")
+    assert moselect._spea2_lazy(n, m)
+    stats = {}
+    got = moselect.spea2_truncate_rounds(pts, n_remove, stats)
+    assert stats["removed"] == n_remove
+    assert torch.equal(got, want), (int((got != want).sum()), stats)
+    if kind in ("clones", "line"):
+        assert stats["tie_rounds"] > 0
+    # through the dispatcher, with a mask that leaves some points out
+    mask[::7] = False
+    sub_remove = int(mask.sum()) // 3
+    monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "0")
+    want = moselect.spea2_truncate(pts, mask, sub_remove)
+    monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "1")
+    got = moselect.spea2_truncate(pts, mask, sub_remove)
+    assert torch.equal(got, want) and int(got.sum()) == int(mask.sum()) - sub_remove
+
+
+@pytest.mark.gpu
+def test_spea2_round_wise_truncation_edge_counts():
+    from evox_amd.ops import moselect
+
+    pts = _spea2_points(2500, 3, 3, "front")
+    assert bool(moselect.spea2_truncate_rounds(pts, 0).all())
+    assert int(moselect.spea2_truncate_rounds(pts, 1).sum()) == 2499
+    # down to two points, and an attempt to go below one: the last point has no neighbour and stays
+    assert int(moselect.spea2_truncate_rounds(pts, 2498).sum()) == 2
+    assert int(moselect.spea2_truncate_rounds(pts, 2600).sum()) == 1
