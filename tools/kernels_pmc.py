@@ -114,5 +114,13 @@ for _ in range(2):
     bw = moselect.scatter_best(torch.randn(10000, 1000, device=dev), torch.randint(0, 10000, (10000, 1000), device=dev),
                                10000, torch.zeros(10000, device=dev) - 1.0)               # scatter_best_kernel
     rk3 = moselect.stochastic_ranking(i1, i2, None, 0.45, seed=torch.tensor([7], dtype=torch.int32, device=dev))   # fresh coins
+# removal loops in chip-wide rounds (select / simulate / apply; select / lists / play / rescan)
+front = torch.randn(20000, 3, device=dev).abs()
+front = front / front.norm(dim=1, keepdim=True) * (1 + 0.05 * torch.rand(20000, 1, device=dev))
+front = (front - front.min()) / (front.max() - front.min())
+for _ in range(2):
+    fit20k, c20k = moselect.ibea_fitness(front, 0.05)
+    keep = moselect.ibea_remove_rounds(front, fit20k, c20k, 0.05, 10000)                  # ibea_lazy_select / apply kernels
+    keep = moselect.spea2_truncate_rounds(front, 10000)                                   # spea2_lazy_* / flag / scan / finish kernels
 torch.cuda.synchronize()
 print("done")
