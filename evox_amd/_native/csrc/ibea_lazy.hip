@@ -222,17 +222,31 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
       if (lane >= o) incl += up;
     }
     if (lane == 63) s_scan[tid >> 6] = incl;
+    unsigned above = kDeadKey;        // the smallest key above τ
+#pragma unroll
+    for (int e = 0; e < E; ++e) above = key[e] > tau ? min(above, key[e]) : above;
+    above = wave_min_dpp(above);
+    if (lane == 0) atomicMin(&s_next, above);
     __syncthreads();
     int before = incl - mine;
     for (int w = 0; w < (tid >> 6); ++w) before += s_scan[w];
     const int room = kK - below;      // > K/2
+    // Clones of a flooding point that a round would keep in S: removing one lifts the others by exactly 1, so about
+    // (next fitness above − their fitness) of them go before anyone else is due; at least kClones, and one is left over
+    // as the sentinel.
+    int n_cl = kClones;
+    {
+      const float gap = key_value(s_next) - key_value(tau);
+      if (!(gap < (float)(room - 2))) n_cl = room - 1;
+      else n_cl = max(kClones, min(room - 1, (int)gap + 2));
+    }
     {
       int pos = before;
 #pragma unroll
       for (int e = 0; e < E; ++e)
         if (key[e] == tau) {
           if (pos == room) s_tidx = tid * E + e;
-          if (pos == kClones) s_tclone = tid * E + e;
+          if (pos == n_cl) s_tclone = tid * E + e;
           ++pos;
         }
     }
@@ -256,14 +270,14 @@ __global__ __launch_bounds__(kSel) void ibea_lazy_select_kernel(const float* __r
     __syncthreads();
     clones = s_dup != 0 && (flags & kNoSentinel) == 0;
     if (clones) {
-      // A flood of clones: only the first kClones of them (by index) stand for the group in S, the next one is the
+      // A flood of clones: only the first n_cl of them (by index) stand for the group in S, the next one is the
       // sentinel, and the freed places go to the members above τ: the search runs again with the other clones struck
       // out and yields τ₂ ≥ τ, the stale bound of everyone outside S who is not a clone.
       int pos = before;
 #pragma unroll
       for (int e = 0; e < E; ++e)
         if (key[e] == tau) {
-          if (pos >= kClones) key[e] = kDeadKey;
+          if (pos >= n_cl) key[e] = kDeadKey;
           ++pos;
         }
       int below2;

@@ -17,6 +17,11 @@ __device__ __forceinline__ unsigned ordered_bits(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// the float behind a key (kDeadKey reads as a NaN)
+__device__ __forceinline__ float key_value(unsigned key) {
+  return __uint_as_float((key & 0x80000000u) ? (key ^ 0x80000000u) : ~key);
+}
+
 // +inf (removed) and NaN never take part
 __device__ __forceinline__ unsigned member_key(float f) { return f < INFINITY ? ordered_bits(f) : kDeadKey; }
 
