@@ -18,6 +18,8 @@ _native.register_hip_api({
     "evox_hip_crowding": (I, [P, P, P, I, I, P, P]),
     "evox_hip_nds_sweep_build": (I, [P, I, I, P, P, P, P]),
     "evox_hip_nds_sweep_rounds": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
+    "evox_hip_nds2_scan_max": (_native.I64, []),
+    "evox_hip_nds2_scan": (I, [P, P, P, I, I, P, P, P, P]),
 })
 
 MAX_OBJECTIVES = 8
@@ -130,6 +132,45 @@ def rank_sweep(x: torch.Tensor, until: Optional[int] = None, with_info: bool = F
     return _finish(rk64, host_sizes, target, cur, order, with_info)
 
 
+_M2_SCAN_MIN_N = 4097             # up to 4096 points one workgroup finishes the pair-test sort just as fast
+
+
+def _m2_scan() -> bool:
+    import os
+
+    return os.environ.get("EVOX_AMD_NDS_M2_SCAN", "1") == "1"
+
+
+def rank_m2_scan(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
+    """``rank`` for two objectives in one launch (``csrc/nds2.hip``): the points are put in lexicographic order (one sort on a
+    64-bit key) and one workgroup peels front after front — a front is the set of points whose second objective lies
+    below the prefix-minimum of the remaining points in front of them (with the tie rules of dominance for equal first
+    objectives), i.e. one block-wide scan per front.  Returns None when a row holds a NaN (the caller then takes the
+    pair-test path)."""
+    n = x.shape[0]
+    dev = x.device
+    xf = x.float() + 0.0                                         # -0.0 and 0.0 are one value
+    # one sort on a 64-bit key: the bits of a float, negative values flipped, order like integers
+    bits = xf.contiguous().view(torch.int32)
+    skey = (bits ^ ((bits >> 31) & 0x7FFFFFFF)).to(torch.int64)
+    order = torch.sort(skey[:, 0] * (1 << 32) + (skey[:, 1] + (1 << 31)), stable=True).indices
+    xs = xf[order]
+    f1, f2 = xs[:, 0].contiguous(), xs[:, 1].contiguous()
+    target = n if until is None else max(1, min(int(until), n))
+    rk = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    gstart = torch.empty(n, dtype=torch.int32, device=dev)
+    buf = torch.zeros(3 + n, dtype=torch.int32, device=dev)                       # fronts, ranked, NaN flag | front sizes
+    buf[2] = torch.isnan(xs).any().to(torch.int32)
+    check(hip().evox_hip_nds2_scan(f1.data_ptr(), f2.data_ptr(), gstart.data_ptr(), n, target, rk.data_ptr(),
+                                   buf[3:].data_ptr(), buf.data_ptr(), stream_of(f2)), "nds2_scan")
+    host = buf.cpu()                                                              # the one read-back of the sort
+    if int(host[2]):
+        return None
+    cur = int(host[0])
+    host_sizes = host[3:3 + cur].cumsum(0).tolist()
+    return _finish(rk.to(torch.int64), host_sizes, target, cur, order, with_info)
+
+
 def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     """Front index of every row (int64).  With ``until`` peeling stops after the front that brings
     the number of ranked points to at least ``until``; all later points share the next index.
@@ -142,6 +183,11 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     # with the pair tests unless asked for explicitly (EVOX_AMD_NDS_SWEEP_MIN with EVOX_AMD_NDS_SWEEP_M2=1)
     if (m == 3 or (m == 2 and _sweep_m2())) and n >= _sweep_min_n():
         got = rank_sweep(x, until, with_info)
+        if got is not None:
+            return got
+    if (m == 2 and _M2_SCAN_MIN_N <= n <= int(hip().evox_hip_nds2_scan_max()) and _m2_scan()
+            and not torch.cuda.is_current_stream_capturing()):
+        got = rank_m2_scan(x, until, with_info)
         if got is not None:
             return got
     if n <= _SMALL_MAX_N:

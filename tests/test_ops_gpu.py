@@ -1766,3 +1766,57 @@ def test_spea2_round_wise_truncation_edge_counts():
     # down to two points, and an attempt to go below one: the last point has no neighbour and stays
     assert int(moselect.spea2_truncate_rounds(pts, 2498).sum()) == 2
     assert int(moselect.spea2_truncate_rounds(pts, 2600).sum()) == 1
+
+
+def _two_objective_points(n, kind, seed):
+    g = torch.Generator().manual_seed(seed)
+    if kind == "cloud":
+        x = torch.rand(n, 2, generator=g)
+    elif kind == "front":                                # many points per front, few fronts
+        t = torch.rand(n, generator=g)
+        x = torch.stack([t, 1 - t + 0.05 * torch.randint(0, 6, (n,), generator=g)], dim=1)
+    elif kind == "grid":                                 # equal first objectives, equal second objectives, identical points
+        x = torch.randint(0, 40, (n, 2), generator=g).float()
+    elif kind == "chain":                                # every point its own front
+        t = torch.arange(n, dtype=torch.float32)
+        x = torch.stack([t, t], dim=1)[torch.randperm(n, generator=g)]
+    elif kind == "columns":                              # few distinct first objectives: long groups
+        x = torch.stack([torch.randint(0, 5, (n,), generator=g).float(), torch.rand(n, generator=g)], dim=1)
+    elif kind == "infs":
+        x = torch.rand(n, 2, generator=g)
+        x[::17, 1] = float("inf"); x[5::23, 0] = float("-inf")
+    return x.cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kind", [(1500, "cloud"), (9000, "cloud"), (20000, "cloud"), (24576, "cloud"), (5000, "front"),
+                                    (6000, "grid"), (2500, "chain"), (7000, "columns"), (3000, "infs")])
+@pytest.mark.parametrize("until", [None, 0.5])
+def test_two_objective_sort_in_one_launch_equals_pair_test_sort(n, kind, until, monkeypatch):
+    """Two objectives: one workgroup peels all fronts with one prefix-minimum scan per front over the lexicographically
+    ordered points; front indices (and the collapse of everything behind the target) equal the pair-test sort, ties in
+    either objective, identical points and infinities included."""
+    from evox_amd.ops import _nds_hip
+
+    x = _two_objective_points(n, kind, n)
+    k = None if until is None else int(n * until)
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_SCAN", "0")
+    want, info_w = _nds_hip.rank(x, k, with_info=True)
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_SCAN", "1")
+    got, info_g = _nds_hip.rank_m2_scan(x, k, with_info=True)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert tuple(info_g) == tuple(info_w)
+    assert torch.equal(_nds_hip.rank(x, k), want)                           # the dispatcher (the scan from 4097 points on)
+    if n <= 3000:
+        from evox_amd.ops import nds
+        assert torch.equal(got, nds.non_dominated_rank_reference(x.cpu(), k).cuda())
+
+
+@pytest.mark.gpu
+def test_two_objective_sort_with_nan_falls_back():
+    from evox_amd.ops import _nds_hip
+
+    x = torch.rand(3000, 2, device="cuda")
+    x[7, 1] = float("nan")
+    assert _nds_hip.rank_m2_scan(x) is None
+    assert _nds_hip.rank(x).shape == (3000,)
