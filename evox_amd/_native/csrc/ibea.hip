@@ -476,6 +476,146 @@ __global__ __launch_bounds__(256) void knee_round_kernel(const float* __restrict
   if (s == 0 && q < n) keep_out[q] = !(hit[0][r] | hit[1][r] | hit[2][r] | hit[3][r]);
 }
 
+// The same fixed point with three states per point — 0 undecided, 1 knee candidate for good, 2 suppressed for good — so
+// that a round only looks at the undecided points (listed, ascending, in `todo`):
+//   some earlier close point is 1            -> 2
+//   no earlier close point is 0 or 1         -> 1      (every earlier close point is suppressed, or there is none)
+//   otherwise                                -> stays 0.
+// Both rules only use final states, so states never flip and the result is the sequential walk's whatever the number of
+// rounds; the undecided set shrinks geometrically (a point is decided once the chain of close predecessors it hangs
+// on is), and with it the work of a round.  state_out must hold a copy of state_in on entry.  suppress_only: apply the
+// first rule alone (state_out may then be state_in itself) — afterwards no undecided point has a final-kept close
+// predecessor, which is what the tail kernel below relies on.
+template <int M>
+__global__ __launch_bounds__(256) void knee_state_kernel(const float* __restrict__ f, const float* __restrict__ R, int n,
+                                                         const int64_t* __restrict__ todo, int n_todo,
+                                                         const uint8_t* __restrict__ state_in, uint8_t* __restrict__ state_out,
+                                                         int suppress_only) {
+  __shared__ float tile[M][256];
+  __shared__ uint8_t tstate[256];
+  __shared__ int hit[4][64];
+  const int r = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + r;
+  const int q = row < n_todo ? (int)todo[row] : -1;
+  float mine[M], rad[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    mine[k] = q >= 0 ? f[(int64_t)q * M + k] : 0.f;
+    rad[k] = R[k];
+  }
+  int found = 0;                                            // bit 0: a close earlier point is final-kept, bit 1: undecided
+  const int last = min(n_todo, blockIdx.x * 64 + 64) - 1;
+  const int end = (int)todo[last];                          // the largest point of this block: later points cannot precede
+  for (int i0 = 0; i0 < end; i0 += 256) {
+    __syncthreads();
+    const int ii = i0 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < M; ++k) tile[k][threadIdx.x] = ii < n ? f[(int64_t)ii * M + k] : 0.f;
+    tstate[threadIdx.x] = ii < n ? state_in[ii] : 2;
+    __syncthreads();
+    const int lim = min(64, end - i0 - s * 64);
+    for (int t = 0; t < lim; ++t) {
+      const int c = s * 64 + t;
+      const int p = i0 + c;
+      const int st = tstate[c];
+      bool close = st != 2 && p < q;
+#pragma unroll
+      for (int k = 0; k < M; ++k) close = close && fabsf(tile[k][c] - mine[k]) < rad[k];
+      found |= close ? (st == 1 ? 1 : 2) : 0;
+    }
+  }
+  hit[s][r] = found;
+  __syncthreads();
+  if (s == 0 && q >= 0) {
+    const int all = hit[0][r] | hit[1][r] | hit[2][r] | hit[3][r];
+    if (all & 1) state_out[q] = 2;
+    else if (!(all & 2) && !suppress_only) state_out[q] = 1;
+  }
+}
+
+// The tail of the three-state iteration in one workgroup: once at most 1024 points are undecided, their fate only depends
+// on each other (a close earlier point that is final-kept would have decided them; final-suppressed ones do not count).
+// Thread i takes the i-th undecided point, lists its close undecided predecessors once (up to kTailPred of them in LDS; a
+// thread with more re-tests all its predecessors every round) and the rounds then run on LDS states without the host.
+constexpr int kTail = 1024;
+constexpr int kTailPred = 16;
+
+template <int M>
+__global__ __launch_bounds__(kTail) void knee_tail_kernel(const float* __restrict__ f, const float* __restrict__ R,
+                                                          const int64_t* __restrict__ todo, int n_todo,
+                                                          uint8_t* __restrict__ state) {
+  __shared__ float s_obj[M][kTail];
+  __shared__ uint16_t s_pred[kTailPred][kTail];
+  __shared__ uint8_t s_state[kTail];
+  const int i = threadIdx.x;
+  const bool have = i < n_todo;
+  const int q = have ? (int)todo[i] : 0;
+  float mine[M], rad[M];
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    mine[k] = have ? f[(int64_t)q * M + k] : 0.f;
+    rad[k] = R[k];
+    s_obj[k][i] = mine[k];
+  }
+  int mystate = have ? (int)state[q] : 2;                   // 0, or 2 from the suppress-only pass before this launch
+  s_state[i] = (uint8_t)mystate;
+  __syncthreads();
+  int cnt = 0;
+  if (have) {
+    for (int j = 0; j < i; ++j) {                           // todo is ascending: the predecessors are the entries before i
+      bool close = true;
+#pragma unroll
+      for (int k = 0; k < M; ++k) close = close && fabsf(s_obj[k][j] - mine[k]) < rad[k];
+      if (close) {
+        if (cnt < kTailPred) s_pred[cnt][i] = (uint16_t)j;
+        ++cnt;
+      }
+    }
+  }
+  for (int round = 0; round < kTail; ++round) {            // a round decides at least the first undecided point
+    int next = mystate;
+    if (mystate == 0) {
+      bool kept = false, open = false;
+      if (cnt <= kTailPred) {
+        for (int t = 0; t < cnt; ++t) {
+          const int st = s_state[s_pred[t][i]];
+          kept = kept || st == 1;
+          open = open || st == 0;
+        }
+      } else {
+        for (int j = 0; j < i; ++j) {
+          const int st = s_state[j];
+          if (st == 2) continue;
+          bool close = true;
+#pragma unroll
+          for (int k = 0; k < M; ++k) close = close && fabsf(s_obj[k][j] - mine[k]) < rad[k];
+          kept = kept || (close && st == 1);
+          open = open || (close && st == 0);
+        }
+      }
+      next = kept ? 2 : (open ? 0 : 1);
+    }
+    __syncthreads();                                        // everyone has read the old states
+    s_state[i] = (uint8_t)next;
+    mystate = next;
+    if (!__syncthreads_or(mystate == 0)) break;
+  }
+  if (have) state[q] = (uint8_t)mystate;
+}
+
+template <int M>
+int launch_knee_tail(const float* f, const float* R, const int64_t* todo, int n_todo, uint8_t* state, hipStream_t st) {
+  knee_tail_kernel<M><<<1, kTail, 0, st>>>(f, R, todo, n_todo, state);
+  return last_launch_status();
+}
+
+template <int M>
+int launch_knee_state(const float* f, const float* R, int n, const int64_t* todo, int n_todo, const uint8_t* state_in,
+                      uint8_t* state_out, int suppress_only, hipStream_t st) {
+  knee_state_kernel<M><<<(n_todo + 63) / 64, 256, 0, st>>>(f, R, n, todo, n_todo, state_in, state_out, suppress_only);
+  return last_launch_status();
+}
+
 template <int M>
 int launch_knee(const float* f, const float* R, int n, const uint8_t* keep_in, uint8_t* keep_out, hipStream_t st) {
   knee_round_kernel<M><<<(n + 63) / 64, 256, 0, st>>>(f, R, n, keep_in, keep_out);
@@ -598,6 +738,24 @@ EVOX_API int evox_hip_knee_round(const float* f, const float* R, int n, int m, c
                                  void* stream) {
   if (n <= 0) return 0;
   EVOX_IBEA_DISPATCH(launch_knee, f, R, n, keep_in, keep_out, (hipStream_t)stream)
+}
+
+// One round of the three-state form: todo (n_todo, ascending int64) lists the undecided points; state_out holds a copy of
+// state_in on entry.
+EVOX_API int evox_hip_knee_state_round(const float* f, const float* R, int n, int m, const int64_t* todo, int n_todo,
+                                       const uint8_t* state_in, uint8_t* state_out, int suppress_only, void* stream) {
+  if (n <= 0 || n_todo <= 0) return 0;
+  EVOX_IBEA_DISPATCH(launch_knee_state, f, R, n, todo, n_todo, state_in, state_out, suppress_only, (hipStream_t)stream)
+}
+
+// The rest of the three-state iteration in one launch: todo (n_todo <= 1024, ascending) lists the undecided points, whose
+// final states are written to `state`.  No listed point may have a final-kept close predecessor any more (run a
+// suppress-only round over the list first); listed points that round suppressed are skipped.
+EVOX_API int evox_hip_knee_state_tail(const float* f, const float* R, int m, const int64_t* todo, int n_todo, uint8_t* state,
+                                      void* stream) {
+  if (n_todo <= 0) return 0;
+  if (n_todo > kTail) return (int)hipErrorInvalidValue;
+  EVOX_IBEA_DISPATCH(launch_knee_tail, f, R, todo, n_todo, state, (hipStream_t)stream)
 }
 
 // Largest population the register-resident removal loop takes for m objectives (the caller uses the matrix

@@ -38,6 +38,8 @@ _native.register_hip_api({
     "evox_hip_ref_associate": (I, [P, I, P, I, I, P, P, P, P]),
     "evox_hip_knn_dist": (I, [P, I, I, I, P, P]),
     "evox_hip_knee_round": (I, [P, P, I, I, P, P, P]),
+    "evox_hip_knee_state_round": (I, [P, P, I, I, P, I, P, P, I, P]),
+    "evox_hip_knee_state_tail": (I, [P, P, I, P, I, P, P]),
     "evox_hip_ibea_remove_obj": (I, [P, I, I, P, F, P, I, P, P]),
     "evox_hip_ibea_remove_multi_max": (I64, [I]),
     "evox_hip_ibea_remove_obj_multi": (I, [P, I, I, P, F, P, I, P, P, P, I, P]),
@@ -493,6 +495,30 @@ def knee_suppress(f: torch.Tensor, order: torch.Tensor, R: torch.Tensor) -> torc
     if on_gpu(f) and 2 <= m <= 8 and f.dtype == torch.float32:
         fs = f[order].contiguous()
         Rc = R.to(torch.float32).contiguous()
+        if not torch.cuda.is_current_stream_capturing() and os.environ.get("EVOX_AMD_KNEE", "states") == "states":
+            # three states per point (undecided / candidate for good / suppressed for good): a round only looks at the
+            # undecided points, whose number — read back once per round to size the next launch — falls geometrically
+            state = torch.zeros(n, dtype=torch.uint8, device=f.device)
+            todo = torch.arange(n, device=f.device)
+            while todo.numel() > 0:
+                if todo.numel() <= 1024:
+                    # few enough for one workgroup: it lists each point's close undecided predecessors once and runs
+                    # the remaining rounds on chip (their fate no longer depends on the decided points)
+                    # (first the points that the last round's new candidates suppress are taken out)
+                    check(hip().evox_hip_knee_state_round(fs.data_ptr(), Rc.data_ptr(), n, m, todo.data_ptr(), todo.numel(),
+                                                          state.data_ptr(), state.data_ptr(), 1, stream_of(fs)),
+                          "knee_state_round")
+                    check(hip().evox_hip_knee_state_tail(fs.data_ptr(), Rc.data_ptr(), m, todo.data_ptr(), todo.numel(),
+                                                         state.data_ptr(), stream_of(fs)), "knee_state_tail")
+                    break
+                nxt = state.clone()
+                check(hip().evox_hip_knee_state_round(fs.data_ptr(), Rc.data_ptr(), n, m, todo.data_ptr(), todo.numel(),
+                                                      state.data_ptr(), nxt.data_ptr(), 0, stream_of(fs)), "knee_state_round")
+                state = nxt
+                todo = torch.nonzero(state == 0).squeeze(1)
+            keep = torch.empty(n, dtype=torch.bool, device=f.device)
+            keep[order] = state == 1
+            return keep
         a = torch.ones(n, dtype=torch.uint8, device=f.device)
         b = torch.empty_like(a)
         for rounds in range(1, n + 1):

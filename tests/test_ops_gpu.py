@@ -1441,15 +1441,19 @@ def test_knn_distance_kernel_matches_sorted_distance_matrix(cuda, n, m, k):
     assert float(got[5, 0]) == 0.0
 
 
-@pytest.mark.parametrize("n,m", [(700, 3), (64, 2), (2500, 4)])
-def test_knee_suppression_rounds_match_sequential_walk(cuda, n, m):
-    """The fixed-point rounds (one streaming launch each) select exactly what the sequential walk selects."""
+@pytest.mark.parametrize("n,m", [(700, 3), (64, 2), (1000, 2), (2500, 4), (9000, 3)])
+@pytest.mark.parametrize("form", ["states", "rounds"])
+def test_knee_suppression_rounds_match_sequential_walk(cuda, n, m, form, monkeypatch):
+    """The fixed-point rounds (one streaming launch each; "states": three states per point, a round only looks at the
+    undecided points; "rounds": every point every round) select exactly what the sequential walk selects."""
     from evox_amd.ops import moselect as sel
 
+    monkeypatch.setenv("EVOX_AMD_KNEE", form)
     g = torch.Generator(device="cuda").manual_seed(n)
     f = torch.rand(n, m, device=cuda, generator=g)
     order = torch.randperm(n, device=cuda, generator=g)
-    R = torch.full((m,), 0.08 if n > 100 else 0.3, device=cuda)
+    # (1000, 2): wide neighbourhoods, dozens of close predecessors per point (the tail kernel's re-testing path)
+    R = torch.full((m,), (0.08 if n < 5000 else 0.04) if n > 100 and m > 2 else 0.3, device=cuda)
     got = sel.knee_suppress(f, order, R)
     fc, oc, Rc = f.cpu(), order.cpu().tolist(), R.cpu()
     # the sequential definition: a point still selected when the walk reaches it deselects its later neighbours
