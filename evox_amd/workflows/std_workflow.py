@@ -76,7 +76,12 @@ class StdWorkflow(Workflow):
                                 ``num_objectives``.
         migrate_helper          object with ``migrate_from_human() -> (do, pop, fit)``; when
                                 ``do`` is true ``algorithm.migrate(state, pop, fit)`` is called.
-        graph_step              replay the steady-state step from a HIP graph (GPU only).
+        graph_step              replay the steady-state step from a HIP graph (GPU only).  ``"auto"``: decide by
+                                measurement — after the algorithm's settling generations, 16 generations are issued
+                                eagerly and 16 replayed, and the faster way is kept (a step that cannot be recorded
+                                stays eager); the timings end up in ``graph_choice``.  Replays win where a generation
+                                is many small kernels; a generation that already keeps the GPU busy (full-matrix
+                                CMA-ES) is faster issued eagerly.
         graph_mode              "ring": pointer-stable replay, the state tensors handed out are the recordings' own
                                 buffers (valid for one further step; clone what must live longer); "copy": value
                                 semantics, every replay copies the state in and clones it out (``utils.graph``).
@@ -104,6 +109,8 @@ class StdWorkflow(Workflow):
         self.graph_mode = graph_mode
         self.graph_replays = 0
         self._eager_before_graph = 0
+        self._auto = None
+        self.graph_choice = None
         if external_problem and num_objectives is None:
             raise ValueError("Using external problem, but num_objectives isn't set")
         self.pmap_axis_name = None
@@ -236,9 +243,73 @@ class StdWorkflow(Workflow):
         state = self._step(state, hooks=_NO_HOOKS, aux=aux)
         return state, aux
 
+    _AUTO_GENERATIONS = 16           # generations timed each way by graph_step="auto"
+
     def step(self, state):
         if not (self.graph_step and not state.first_step):
             return self._step(state)
+        if self.graph_step == "auto":
+            return self._step_auto(state)
+        return self._step_graphed(state)
+
+    def _step_auto(self, state):
+        """``graph_step="auto"``: settle, time eager generations, record, time replays, keep the faster way.  Every call
+        advances the run by one generation; the four synchronisations of the measurement are its only cost."""
+        import time
+
+        a = self._auto
+        if a is None:
+            on_gpu = any(isinstance(t, torch.Tensor) and t.is_cuda for t in _tree.tree_leaves(state))
+            if not on_gpu or self.migrate_helper is not None or self.external_problem:
+                self.graph_step = False
+                self.graph_choice = {"mode": "eager", "reason": "nothing to record (host-side step or no GPU)"}
+                return self._step(state)
+            settle = max(4, int(getattr(self.algorithm, "graph_settle_steps", 0) or 0))
+            a = self._auto = {"phase": "settle", "count": 0, "settle": settle}
+
+        def clock():
+            torch.cuda.synchronize()
+            return time.perf_counter()
+
+        n = self._AUTO_GENERATIONS
+        if a["phase"] == "settle":
+            a["count"] += 1
+            out = self._step(state)
+            if a["count"] >= a["settle"]:
+                a.update(phase="eager", count=0, t0=clock())
+            return out
+        if a["phase"] == "eager":
+            out = self._step(state)
+            a["count"] += 1
+            if a["count"] >= n:
+                a.update(phase="record", count=0, eager_ms=(clock() - a["t0"]) / n * 1e3)
+                self._eager_before_graph = a["settle"]           # the settling generations are behind us
+            return out
+        try:
+            out = self._step_graphed(state)
+        except Exception as e:                                   # the step cannot be recorded: eager it is
+            from ..utils.graph import GraphCaptureError
+
+            if not isinstance(e, (GraphCaptureError, ValueError)):
+                raise
+            self.graph_step, self._graphed = False, None
+            self.graph_choice = {"mode": "eager", "eager_ms": a["eager_ms"], "reason": str(e).splitlines()[0]}
+            return self._step(state)
+        a["count"] += 1
+        if a["phase"] == "record":                               # the recording and its first replays are not timed
+            if a["count"] >= 4:
+                a.update(phase="graph", count=0, t0=clock())
+            return out
+        if a["count"] >= n:
+            graph_ms = (clock() - a["t0"]) / n * 1e3
+            keep = graph_ms < 0.97 * a["eager_ms"]
+            self.graph_choice = {"mode": "graph" if keep else "eager", "eager_ms": a["eager_ms"], "graph_ms": graph_ms}
+            self.graph_step = bool(keep)
+            if not keep:
+                self._graphed = None
+        return out
+
+    def _step_graphed(self, state):
         # An algorithm whose host-side control settles over its first generations (the iteration count of CMA-ES's
         # factorisation starts conservative) asks for that many eager generations before the first recording: in eager
         # mode the control adapts every generation, in a recording it is frozen between polls.

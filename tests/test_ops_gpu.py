@@ -1824,3 +1824,37 @@ def test_two_objective_sort_with_nan_falls_back():
     x[7, 1] = float("nan")
     assert _nds_hip.rank_m2_scan(x) is None
     assert _nds_hip.rank(x).shape == (3000,)
+
+
+@pytest.mark.gpu
+def test_graph_step_auto_measures_and_keeps_the_faster_way():
+    """``graph_step="auto"``: a swarm generation (dozens of small kernels) ends up replayed, an algorithm whose step
+    synchronises with the host stays eager with the reason on record, and the run is the same sequence of generations
+    either way."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    dev = torch.device("cuda")
+    lb, ub = torch.full((50,), -5.0, device=dev), torch.full((50,), 5.0, device=dev)
+
+    def run(mode, algo):
+        wf = workflows.StdWorkflow(algo(), problems.numerical.Rastrigin(), graph_step=mode)
+        s = wf.init(ex.PRNGKey(4).to(dev))
+        for _ in range(60):
+            s = wf.step(s)
+        torch.cuda.synchronize()
+        return wf, s
+
+    pso = lambda: algorithms.SHADE(lb, ub, 256)
+    wa, sa = run("auto", pso)
+    we, se = run(False, pso)
+    assert wa.graph_choice is not None and wa.graph_choice["mode"] in ("graph", "eager")
+    assert wa.graph_choice["eager_ms"] > 0 and wa.graph_choice["graph_ms"] > 0
+    assert wa.graph_choice["mode"] == "graph" and wa.graph_step is True and wa.graph_replays > 20
+    a, e = sa.get_child_state("algorithm"), se.get_child_state("algorithm")
+    assert torch.equal(a.population, e.population) and torch.equal(a.fitness, e.fitness)
+    assert int(sa.generation) == int(se.generation) == 60
+    # a step that reads back to the host cannot be recorded: eager, and said so
+    wx, sx = run("auto", lambda: algorithms.XNES(init_mean=torch.zeros(10, device=dev), init_covar=torch.eye(10, device=dev), pop_size=32))
+    assert wx.graph_choice["mode"] == "eager" and wx.graph_step is False and "reason" in wx.graph_choice
+    assert int(sx.generation) == 60

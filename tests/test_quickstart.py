@@ -47,3 +47,19 @@ def test_examples_run():
                              timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "best fitness" in out.stdout
+
+
+def test_graph_step_auto_without_a_gpu_is_eager():
+    import torch
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    wf = workflows.StdWorkflow(algorithms.PSO(lb=torch.full((5,), -3.0), ub=torch.full((5,), 3.0), pop_size=20),
+                               problems.numerical.Sphere(), graph_step="auto")
+    ref = workflows.StdWorkflow(algorithms.PSO(lb=torch.full((5,), -3.0), ub=torch.full((5,), 3.0), pop_size=20),
+                                problems.numerical.Sphere())
+    s, r = wf.init(ex.PRNGKey(1)), ref.init(ex.PRNGKey(1))
+    for _ in range(6):
+        s, r = wf.step(s), ref.step(r)
+    assert wf.graph_step is False and wf.graph_choice["mode"] == "eager"
+    assert torch.equal(s.get_child_state("algorithm").population, r.get_child_state("algorithm").population)
