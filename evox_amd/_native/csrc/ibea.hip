@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void ibea_fitness_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < M; ++k) mine[k] = j < n ? obj[(int64_t)j * M + k] : 0.f;
   const float cj = (PASS == 1 && j < n) ? C[j] : 1.f;
+  const float sj = -1.0f / (cj * kappa);                  // the scale of the removal loop's increments: one product per pair
   float acc = 0.f;
   for (int i0 = 0; i0 < n; i0 += 256) {
     __syncthreads();
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(256) void ibea_fitness_kernel(const float* __restri
       for (int k = 0; k < M; ++k) other[k] = tile[k][c];
       const float v = eps_ind<M>(other, mine);
       if (PASS == 0) acc = fmaxf(acc, fabsf(v));
-      else acc += expf(-v / cj / kappa);
+      else acc += __expf(v * sj);
     }
   }
   part[s][r] = acc;
