@@ -130,10 +130,14 @@ def segmented_crowding_distance(costs: torch.Tensor, group: torch.Tensor, mask: 
     dev = costs.device
     c = costs.float()
     g = torch.where(mask, group, torch.full_like(group, n_groups))
-    where = g[:, None].expand(n, m)
-    inf = torch.full((n_groups + 1, m), float("inf"), device=dev)
-    span = (-inf).scatter_reduce(0, where, c, reduce="amax") - inf.scatter_reduce(0, where, c, reduce="amin")
     total = torch.zeros(n, device=dev)
+    spare = torch.full_like(g, n_groups + 1)
+    span_all = None
+    if n < 8192:
+        # few rows: one pair of atomic reductions for all objectives costs less than two scatters per objective
+        where = g[:, None].expand(n, m)
+        inf = torch.full((n_groups + 1, m), float("inf"), device=dev)
+        span_all = (-inf).scatter_reduce(0, where, c, reduce="amax") - inf.scatter_reduce(0, where, c, reduce="amin")
     for k in range(m):
         o = torch.argsort(c[:, k], stable=True)
         o = o[torch.argsort(g[o], stable=True)]                          # grouped, ascending inside a group
@@ -142,7 +146,15 @@ def segmented_crowding_distance(costs: torch.Tensor, group: torch.Tensor, mask: 
         edge[1:] = gs[1:] != gs[:-1]
         tail = torch.ones(n, dtype=torch.bool, device=dev)
         tail[:-1] = edge[1:]
-        gap = (torch.roll(v, -1) - torch.roll(v, 1)) / span[gs, k]
+        # a set's extremes are the first and the last value of its segment: two plain scatters with one writer per set
+        # (everything else goes to a spare row) instead of atomic min / max reductions of all rows onto a few addresses
+        if span_all is None:
+            lo = torch.zeros(n_groups + 2, device=dev).scatter_(0, torch.where(edge, gs, spare), v)
+            hi = torch.zeros(n_groups + 2, device=dev).scatter_(0, torch.where(tail, gs, spare), v)
+            span = hi - lo
+        else:
+            span = span_all[:, k]
+        gap = (torch.roll(v, -1) - torch.roll(v, 1)) / span[gs]
         gap = torch.where(edge | tail, torch.full_like(gap, float("inf")), gap)
         total[o] += gap
     return torch.where(mask, total, torch.full_like(total, float("-inf")))
