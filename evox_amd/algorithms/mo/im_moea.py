@@ -90,10 +90,12 @@ class IMMOEA(MOAlgorithm):
             order = torch.argsort(keys, dim=1)[:, :P]                                      # (G, P)
             mask = torch.arange(P, device=dev)[None, :] < share[:, None]
             idx = torch.where(mask, order, torch.zeros_like(order))
-            inf = torch.full((self.k, M), float("inf"), device=dev)
-            where = part[:, None].expand(n, M)
-            lo = inf.scatter_reduce(0, where, obj, reduce="amin")
-            hi = (-inf).scatter_reduce(0, where, obj, reduce="amax")
+            # extremes per sub-population as masked reductions (k is small): atomic min / max of all rows onto k
+            # addresses serialise
+            own = (part[None, :] == torch.arange(self.k, device=dev)[:, None])[:, :, None]  # (k, n, 1)
+            inf = torch.full((), float("inf"), device=dev)
+            lo = torch.where(own, obj[None], inf).amin(1)                                   # (k, M)
+            hi = torch.where(own, obj[None], -inf).amax(1)
             f_lo, f_hi = 1.5 * lo - 0.5 * hi, 1.5 * hi - 0.5 * lo                          # (k, M)
             a, b = f_lo[gk, m_of], f_hi[gk, m_of]                                          # (G,)
             t = torch.arange(P, device=dev)[None, :] / (share[:, None] - 1).clamp_min(1)

@@ -41,6 +41,17 @@ def _scatter_best(values, target, n_sub, current):
     return best, torch.where(winner < big, winner, torch.full_like(winner, -1))
 
 
+def two_distinct(key, n: int, t: int):
+    """For each of ``n`` rows two different positions in ``[0, t)``, uniform over the ordered pairs — the first two
+    entries of a random permutation of the row (what the reference draws, ``moead.py:88-92``) without sorting ``t``
+    random keys per row."""
+    k1, k2 = rnd.split(key)
+    first = rnd.randint(k1, (n,), 0, t)
+    second = rnd.randint(k2, (n,), 0, max(t - 1, 1))
+    second = second + (second >= first).to(second.dtype) if t > 1 else second
+    return first, second
+
+
 class MOEAD(MOAlgorithm):
     def __init__(self, lb, ub, n_objs, pop_size, func_name="pbi", mutation_op=None, crossover_op=None):
         self._init_mo(lb, ub, n_objs, pop_size, mutation_op,
@@ -63,8 +74,8 @@ class MOEAD(MOAlgorithm):
     def ask(self, state):
         key, k_perm, k_x, k_mut = rnd.split(state.key, 4)
         n, t = state.neighbors.shape
-        order = torch.argsort(rnd.bits(k_perm, (n, t)), dim=1)
-        parent = torch.gather(state.neighbors, 1, order)
+        first, second = two_distinct(k_perm, n, t)
+        parent = torch.gather(state.neighbors, 1, torch.stack([first, second], dim=1))
         mates = torch.cat([state.population[parent[:, 0]], state.population[parent[:, 1]]], dim=0)
         nxt = self._vary(k_x, k_mut, mates)
         return nxt, state.replace(next_generation=nxt, key=key)

@@ -16,7 +16,7 @@ from ...ops import nds as _nds
 from ...ops.distance import cdist as _cdist
 from ...utils.common import AggregationFunction, cos_dist
 from .common import MOAlgorithm, rank_crowding_truncate
-from .moead import _scatter_best
+from .moead import _scatter_best, two_distinct
 
 
 class EAGMOEAD(MOAlgorithm):
@@ -66,8 +66,8 @@ class EAGMOEAD(MOAlgorithm):
         d = s / s.sum() + 0.002
         d = d / d.sum()
         _, loc = self.selection(k_sel, state.inner_pop, 1.0 / d)
-        Bp = torch.gather(state.B, 1, torch.argsort(rnd.bits(k_perm, (n, t)), dim=1))
-        parent = Bp[loc][:, :2]
+        first, second = two_distinct(k_perm, n, t)               # the first two of a random permutation of each row of B
+        parent = torch.gather(state.B, 1, torch.stack([first, second], dim=1))[loc]
         mates = torch.cat([state.inner_pop[parent[:, 0]], state.inner_pop[parent[:, 1]]], dim=0)
         nxt = self._vary(k_x, k_mut, mates)
         return nxt, state.replace(next_generation=nxt, offspring_loc=loc, key=key)
