@@ -271,8 +271,7 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
                                                              float* __restrict__ rowmin, int* __restrict__ nn,
                                                              int* __restrict__ ctrl, const int* __restrict__ s_list,
                                                              const float* __restrict__ list_d, const int* __restrict__ list_i) {
-  __shared__ float l_d[kK * kList];
-  __shared__ int l_i[kK * kList];
+  __shared__ int2 l_e[kK * kList];                        // neighbour lists: (index, bits of the distance)
   __shared__ int s_idx[kK];
   __shared__ int s_order[kK];
   __shared__ unsigned s_gone[kMaxPoints / 32];            // one bit per point: removed in this round
@@ -285,8 +284,7 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
   for (int w = threadIdx.x; w < (n + 31) / 32; w += 256) s_gone[w] = 0u;
   for (int e = threadIdx.x; e < kK * kList; e += 256) {
     const bool have = e / kList < cnt;
-    l_d[e] = have ? list_d[e] : INFINITY;
-    l_i[e] = have ? list_i[e] : -1;
+    l_e[e] = have ? make_int2(list_i[e], __float_as_int(list_d[e])) : make_int2(-1, 0x7F800000);
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
@@ -315,18 +313,14 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
     for (int q = 1; q < kPerLane; ++q) lk = min(lk, key[q]);
     const int wk = wave_min_dpp(lk);
     if (wk >= kInfKey) break;                               // S is used up
+    // equal distances are the rule (both points of a closest pair): the smaller index goes, and it names x right away
+    int cand = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < kPerLane; ++q) cand = key[q] == wk ? min(cand, id[q]) : cand;
+    const int x = wave_min_dpp(cand);
     unsigned long long hit[kPerLane];
-    int hits = 0;
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) { hit[q] = __ballot(key[q] == wk); hits += __popcll(hit[q]); }
-    if (hits > 1) {                                         // equal distances (every closest pair): the smaller index goes
-      int cand = 0x7fffffff;
-#pragma unroll
-      for (int q = 0; q < kPerLane; ++q) cand = key[q] == wk ? min(cand, id[q]) : cand;
-      const int wi = wave_min_dpp(cand);
-#pragma unroll
-      for (int q = 0; q < kPerLane; ++q) hit[q] = __ballot(key[q] == wk && id[q] == wi);
-    }
+    for (int q = 0; q < kPerLane; ++q) hit[q] = __ballot(key[q] == wk && id[q] == x);
     int q_sel = 0;
     unsigned long long h = hit[0];
 #pragma unroll
@@ -334,7 +328,6 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
       if (hit[q] != 0) { q_sel = q; h = hit[q]; }           // scalar
     const int src = (int)__builtin_ctzll(h);
     const int x_slot = q_sel * 64 + src;
-    const int x = s_idx[x_slot];
     if (wk > tau_key || (wk == tau_key && x >= t_idx)) break;   // no longer below T: a point outside S may be next
 #pragma unroll
     for (int q = 0; q < kPerLane; ++q) f[q] = (q == q_sel && lane == src) ? INFINITY : f[q];
@@ -347,13 +340,21 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
     for (int q = 0; q < kPerLane; ++q) {
       if (nb[q] == x && f[q] < INFINITY) {
         const int slot = lane + 64 * q;
-        int p = ptr[q], c = -1;
+        int p = ptr[q], c = -1, dbits = 0;
         while (p < kList) {
-          c = l_i[slot * kList + p];
-          if (c < 0 || !((s_gone[c >> 5] >> (c & 31)) & 1u)) break;
+          // two entries and their bitmap words per round trip; x itself is gone without asking the bitmap
+          const int2 e0 = l_e[slot * kList + p];
+          const int2 e1 = l_e[slot * kList + min(p + 1, kList - 1)];
+          const int c0 = e0.x, c1 = p + 1 < kList ? e1.x : -1;
+          const unsigned w0 = c0 >= 0 ? s_gone[c0 >> 5] : 0u, w1 = c1 >= 0 ? s_gone[c1 >> 5] : 0u;
+          const bool gone0 = c0 >= 0 && (c0 == x || ((w0 >> (c0 & 31)) & 1u));
+          const bool gone1 = c1 >= 0 && (c1 == x || ((w1 >> (c1 & 31)) & 1u));
+          if (!gone0) { c = c0; dbits = e0.y; break; }      // a live entry, or the end of a short list (c0 < 0)
+          ++p;
+          if (!gone1) { c = c1; dbits = e1.y; break; }
           ++p;
         }
-        if (p < kList && c >= 0) { f[q] = l_d[slot * kList + p]; nb[q] = c; ptr[q] = p; }
+        if (p < kList && c >= 0) { f[q] = __int_as_float(dbits); nb[q] = c; ptr[q] = p; }
         else out = true;                                    // the list ran out: this member waits for the rescan
       }
     }
