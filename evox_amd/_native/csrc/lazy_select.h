@@ -67,26 +67,26 @@ __device__ __forceinline__ int block_count_below(const unsigned (&key)[E], unsig
 // τ with count(key < τ) ≤ K, as large as a short search finds: count(lo) ≤ K < count(hi) throughout.  Keys only grow from
 // round to round, so the previous round's τ is still a valid lower end, and the distance it moved last time is a good
 // first step from there.  `tie`: the search ran out with fewer than K/2 members below τ — more than K/2 share the key τ.
-template <int E>
+template <int E, int K = kK>
 __device__ __forceinline__ unsigned find_tau(const unsigned (&key)[E], unsigned tau_prev, unsigned step, int (*s_cnt)[kSel / 64],
                                              int& flip, int& bisections, int& below, bool& tie) {
   unsigned lo = tau_prev, hi = kDeadKey;
   below = 0;
   if (lo != 0) { below = block_count_below<E>(key, lo, s_cnt[flip]); flip ^= 1; ++bisections; }
-  while (step != 0 && below < kK / 2) {
+  while (step != 0 && below < K / 2) {
     const unsigned cand = lo + step;
     if (cand < lo || cand >= kDeadKey) break;
     const int c = block_count_below<E>(key, cand, s_cnt[flip]); flip ^= 1;
     ++bisections;
-    if (c <= kK) { lo = cand; below = c; step = step < 0x40000000u ? step * 2 : step; } else { hi = cand; break; }
+    if (c <= K) { lo = cand; below = c; step = step < 0x40000000u ? step * 2 : step; } else { hi = cand; break; }
   }
-  while (hi - lo > 1 && below < kK / 2) {
+  while (hi - lo > 1 && below < K / 2) {
     const unsigned mid = lo + (hi - lo) / 2;
     const int c = block_count_below<E>(key, mid, s_cnt[flip]); flip ^= 1;
-    if (c <= kK) { lo = mid; below = c; } else hi = mid;
+    if (c <= K) { lo = mid; below = c; } else hi = mid;
     ++bisections;
   }
-  tie = below < kK / 2;
+  tie = below < K / 2;
   return lo;
 }
 

@@ -21,6 +21,8 @@ using namespace evox::lazy;
 namespace {
 
 constexpr int kList = 8;            // neighbours listed per member of S
+constexpr int kKS = 512;            // points a round plays through: the play loop has no per-member arithmetic, so a
+constexpr int kPerLaneS = kKS / 64; // larger S than IBEA's costs little per removal and halves the number of rounds
 constexpr int kMaxPoints = 65536;   // the play launch keeps one bit per point in LDS
 
 enum { kRemoved = 0, kRounds = 1, kRoundCount = 2, kSCount = 3, kTauBits = 4, kTIdx = 5, kTau = 6, kTauStep = 7,
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void spea2_finish_kernel(const int* __restrict
   }
 }
 
-// S and T of a round.  Thread t owns the points t·E … t·E + E − 1.  s_list: out (kK) indices of S.
+// S and T of a round.  Thread t owns the points t·E … t·E + E − 1.  s_list: out (kKS) indices of S.
 template <int E>
 __global__ __launch_bounds__(kSel) void spea2_lazy_select_kernel(const float* __restrict__ rowmin, int n, int n_remove,
                                                                  int* __restrict__ ctrl, int* __restrict__ s_list) {
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kSel) void spea2_lazy_select_kernel(const float* __
   unsigned tau = kDeadKey;
   int below = live;
   bool tie = false;
-  if (live > kK) tau = find_tau<E>(key, tau_prev, step_prev, s_cnt, flip, bisections, below, tie);
+  if (live > kKS) tau = find_tau<E, kKS>(key, tau_prev, step_prev, s_cnt, flip, bisections, below, tie);
 #pragma unroll
   for (int e = 0; e < E; ++e)
     if (key[e] < tau) s_list[atomicAdd(&s_n, 1)] = tid * E + e;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(kSel) void spea2_lazy_select_kernel(const float* __
     __syncthreads();
     int pos = incl - mine;
     for (int w = 0; w < (tid >> 6); ++w) pos += s_scan[w];
-    const int room = kK - below;
+    const int room = kKS - below;
 #pragma unroll
     for (int e = 0; e < E; ++e)
       if (key[e] == tau) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kSel) void spea2_lazy_select_kernel(const float* __
   }
   __syncthreads();
   if (tid == 0) {
-    ctrl[kSCount] = tie ? kK : s_n;
+    ctrl[kSCount] = tie ? kKS : s_n;
     ctrl[kFlagged] = 0;
     ctrl[kTauBits] = (int)tau;
     ctrl[kTIdx] = s_tidx;
@@ -271,9 +273,9 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
                                                              float* __restrict__ rowmin, int* __restrict__ nn,
                                                              int* __restrict__ ctrl, const int* __restrict__ s_list,
                                                              const float* __restrict__ list_d, const int* __restrict__ list_i) {
-  __shared__ int2 l_e[kK * kList];                        // neighbour lists: (index, bits of the distance)
-  __shared__ int s_idx[kK];
-  __shared__ int s_order[kK];
+  __shared__ int2 l_e[kKS * kList];                        // neighbour lists: (index, bits of the distance)
+  __shared__ int s_idx[kKS];
+  __shared__ int s_order[kKS];
   __shared__ unsigned s_gone[kMaxPoints / 32];            // one bit per point: removed in this round
   const int lane = threadIdx.x & 63;
   const int cnt = ctrl[kSCount];
@@ -282,17 +284,17 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
   const int budget = n_remove - done;
   // the whole workgroup sets the stage, its first wave plays
   for (int w = threadIdx.x; w < (n + 31) / 32; w += 256) s_gone[w] = 0u;
-  for (int e = threadIdx.x; e < kK * kList; e += 256) {
+  for (int e = threadIdx.x; e < kKS * kList; e += 256) {
     const bool have = e / kList < cnt;
     l_e[e] = have ? make_int2(list_i[e], __float_as_int(list_d[e])) : make_int2(-1, 0x7F800000);
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
   constexpr int kInfKey = 0x7F800000;
-  float f[kPerLane];
-  int id[kPerLane], nb[kPerLane], ptr[kPerLane];
+  float f[kPerLaneS];
+  int id[kPerLaneS], nb[kPerLaneS], ptr[kPerLaneS];
 #pragma unroll
-  for (int q = 0; q < kPerLane; ++q) {
+  for (int q = 0; q < kPerLaneS; ++q) {
     const int slot = lane + 64 * q;
     id[q] = slot < cnt ? s_list[slot] : 0x7fffffff;
     f[q] = slot < cnt ? rowmin[id[q]] : INFINITY;
@@ -305,39 +307,39 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
   int removed = 0;
   bool short_list = false;
   while (removed < budget) {
-    int key[kPerLane];
+    int key[kPerLaneS];
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) key[q] = __float_as_int(f[q]);
+    for (int q = 0; q < kPerLaneS; ++q) key[q] = __float_as_int(f[q]);
     int lk = key[0];
 #pragma unroll
-    for (int q = 1; q < kPerLane; ++q) lk = min(lk, key[q]);
+    for (int q = 1; q < kPerLaneS; ++q) lk = min(lk, key[q]);
     const int wk = wave_min_dpp(lk);
     if (wk >= kInfKey) break;                               // S is used up
     // equal distances are the rule (both points of a closest pair): the smaller index goes, and it names x right away
     int cand = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) cand = key[q] == wk ? min(cand, id[q]) : cand;
+    for (int q = 0; q < kPerLaneS; ++q) cand = key[q] == wk ? min(cand, id[q]) : cand;
     const int x = wave_min_dpp(cand);
-    unsigned long long hit[kPerLane];
+    unsigned long long hit[kPerLaneS];
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) hit[q] = __ballot(key[q] == wk && id[q] == x);
+    for (int q = 0; q < kPerLaneS; ++q) hit[q] = __ballot(key[q] == wk && id[q] == x);
     int q_sel = 0;
     unsigned long long h = hit[0];
 #pragma unroll
-    for (int q = 1; q < kPerLane; ++q)
+    for (int q = 1; q < kPerLaneS; ++q)
       if (hit[q] != 0) { q_sel = q; h = hit[q]; }           // scalar
     const int src = (int)__builtin_ctzll(h);
     const int x_slot = q_sel * 64 + src;
     if (wk > tau_key || (wk == tau_key && x >= t_idx)) break;   // no longer below T: a point outside S may be next
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) f[q] = (q == q_sel && lane == src) ? INFINITY : f[q];
+    for (int q = 0; q < kPerLaneS; ++q) f[q] = (q == q_sel && lane == src) ? INFINITY : f[q];
     if (lane == 0) atomicOr(&s_gone[x >> 5], 1u << (x & 31));   // no read on the critical path
     s_order[removed] = x_slot;
     ++removed;
     // members of S that lose their neighbour take the next live entry of their list
     bool out = false;
 #pragma unroll
-    for (int q = 0; q < kPerLane; ++q) {
+    for (int q = 0; q < kPerLaneS; ++q) {
       if (nb[q] == x && f[q] < INFINITY) {
         const int slot = lane + 64 * q;
         int p = ptr[q], c = -1, dbits = 0;
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void spea2_lazy_play_kernel(int n, int n_remov
     alive[x] = 0; rowmin[x] = INFINITY; nn[x] = -1;
   }
 #pragma unroll
-  for (int q = 0; q < kPerLane; ++q)
+  for (int q = 0; q < kPerLaneS; ++q)
     if (f[q] < INFINITY) { rowmin[id[q]] = f[q]; nn[id[q]] = nb[q]; }
   if (lane == 0) {
     ctrl[kRemoved] = done + removed;
@@ -411,7 +413,7 @@ int launch_rounds(const float* obj, int n, uint8_t* alive, float* rowmin, int* n
   }
   for (int r = 0; r < rounds; ++r) {
     launch_select_any(rowmin, n, n_remove, ctrl, s_list, st);
-    spea2_lazy_list_kernel<M><<<kK, 256, 0, st>>>(obj, n, alive, ctrl, s_list, list_d, list_i);
+    spea2_lazy_list_kernel<M><<<kKS, 256, 0, st>>>(obj, n, alive, ctrl, s_list, list_d, list_i);
     spea2_lazy_play_kernel<<<1, 256, 0, st>>>(n, n_remove, alive, rowmin, nn, ctrl, s_list, list_d, list_i);
     rescan(0);
   }
@@ -422,9 +424,9 @@ int launch_rounds(const float* obj, int n, uint8_t* alive, float* rowmin, int* n
 
 EVOX_API int64_t evox_hip_spea2_lazy_max(int m) { return m >= 1 && m <= 8 ? kMaxPoints : 0; }
 EVOX_API int64_t evox_hip_spea2_lazy_ctrl_words() { return kCtrlWords; }
-// int32 words of the scratch for n points: best (n 64-bit words, first: alignment) + flagged (n) + S (kK) + neighbour
-// indices (kK · kList) + neighbour distances (kK · kList floats)
-EVOX_API int64_t evox_hip_spea2_lazy_scratch_words(int n) { return 3 * (int64_t)n + kK + 2 * kK * kList; }
+// int32 words of the scratch for n points: best (n 64-bit words, first: alignment) + flagged (n) + S (kKS) + neighbour
+// indices (kKS · kList) + neighbour distances (kKS · kList floats)
+EVOX_API int64_t evox_hip_spea2_lazy_scratch_words(int n) { return 3 * (int64_t)n + kKS + 2 * kKS * kList; }
 
 // obj: (n, m) fp32 points, all live on entry when reset != 0 (alive is then expected to hold ones; rowmin and nn are
 // computed here).  Issues `rounds` rounds; rounds after the n_remove-th removal do nothing.  alive: in/out bytes.
@@ -438,8 +440,8 @@ EVOX_API int evox_hip_spea2_lazy_rounds(const float* obj, int n, int m, uint8_t*
   unsigned long long* best = reinterpret_cast<unsigned long long*>(scratch);
   int* flagged = scratch + 2 * (int64_t)n;
   int* s_list = flagged + n;
-  int* list_i = s_list + kK;
-  float* list_d = reinterpret_cast<float*>(list_i + kK * kList);
+  int* list_i = s_list + kKS;
+  float* list_d = reinterpret_cast<float*>(list_i + kKS * kList);
   switch (m) {
     case 1: return launch_rounds<1>(obj, n, alive, rowmin, nn, n_remove, ctrl, s_list, list_d, list_i, flagged, best, reset, rounds, st);
     case 2: return launch_rounds<2>(obj, n, alive, rowmin, nn, n_remove, ctrl, s_list, list_d, list_i, flagged, best, reset, rounds, st);

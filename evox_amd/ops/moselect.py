@@ -275,6 +275,7 @@ def spea2_truncate_reference(obj, mask, n_remove: int) -> torch.Tensor:
 
 
 _SPEA2_LAZY_MIN_N = 2048         # from here on the truncation runs in chip-wide rounds
+_SPEA2_LAZY_K = 512              # points a round plays through (``csrc/spea2_lazy.hip::kKS``)
 
 
 def _spea2_lazy(n: int, m: int) -> bool:
@@ -284,9 +285,9 @@ def _spea2_lazy(n: int, m: int) -> bool:
 
 def spea2_truncate_rounds(points, n_remove: int, stats: dict = None) -> torch.Tensor:
     """SPEA2 truncation of ``points`` (n, m), all of them candidates, in rounds (``csrc/spea2_lazy.hip``): nearest-neighbour
-    distances only grow while points are removed, so the 256 points with the smallest distance are played through on one
-    wave (each with the list of its 8 nearest live neighbours, collected by 256 workgroups at once) while their smallest
-    stays below the 257th of the round's start; every live point whose neighbour went is then rescanned chip-wide.  No
+    distances only grow while points are removed, so the 512 points with the smallest distance are played through on one
+    wave (each with the list of its 8 nearest live neighbours, collected by 512 workgroups at once) while their smallest
+    stays below the 513th of the round's start; every live point whose neighbour went is then rescanned chip-wide.  No
     n × n distance matrix is formed, and the survivors are those of the one-at-a-time loop.  Returns the survivor mask."""
     n, m = points.shape
     n_remove = int(n_remove)
@@ -299,7 +300,7 @@ def spea2_truncate_rounds(points, n_remove: int, stats: dict = None) -> torch.Te
     nn = torch.empty(n, dtype=torch.int32, device=dev)
     ctrl = torch.empty(int(hip().evox_hip_spea2_lazy_ctrl_words()), dtype=torch.int32, device=dev)
     scratch = torch.empty(int(hip().evox_hip_spea2_lazy_scratch_words(n)) // 2 + 1, dtype=torch.int64, device=dev)
-    rounds = min(_IBEA_LAZY_CHUNK, max(4, int(n_remove / (0.5 * _IBEA_LAZY_K)) + 2))
+    rounds = min(_IBEA_LAZY_CHUNK, max(4, int(n_remove / (0.35 * _SPEA2_LAZY_K)) + 2))
     reset, done, issued = 1, 0, 0
     while True:
         check(hip().evox_hip_spea2_lazy_rounds(points.data_ptr(), n, m, alive.data_ptr(), rowmin.data_ptr(), nn.data_ptr(),

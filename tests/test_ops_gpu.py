@@ -1718,7 +1718,7 @@ def _spea2_points(n, m, seed, kind):
     d = torch.randn(n, m, generator=g).abs()
     d = d / d.norm(dim=1, keepdim=True)
     if kind == "clones":                                 # distance zero among many points: tie rounds, lists run out
-        d[n // 3: n // 3 + n // 8] = d[5]
+        d[n // 3: n // 3 + n // 4] = d[5]                # (more of them than a round plays through)
     elif kind == "grid":                                 # many exactly equal distances
         d = (d * 16).round() / 16
     elif kind == "line":                                 # equidistant points: every nearest-neighbour distance is the same
@@ -1730,7 +1730,7 @@ def _spea2_points(n, m, seed, kind):
 @pytest.mark.parametrize("n,m,kind", [(2100, 3, "front"), (6000, 2, "front"), (5000, 5, "front"), (13000, 3, "front"),
                                       (4000, 3, "clones"), (5000, 3, "grid"), (3000, 2, "line")])
 def test_spea2_round_wise_truncation_equals_one_at_a_time_loop(n, m, kind, monkeypatch):
-    """Truncation in rounds (the 256 points with the closest neighbour played through on one wave with lists of their 8
+    """Truncation in rounds (the 512 points with the closest neighbour played through on one wave with lists of their 8
     nearest live neighbours, then a chip-wide rescan of every point whose neighbour went) keeps exactly the points the
     one-at-a-time loop over the distance matrix keeps: nearest-neighbour distances only grow during the loop, and the
     distances are computed with the expression of the matrix.  Equal distances (closest pairs, grids, clones, a line of

@@ -12,7 +12,7 @@ def front(n, m, seed, kind):
     d = torch.randn(n, m, generator=g).abs()
     d = d / d.norm(dim=1, keepdim=True)
     if kind == "clones":
-        d[n // 3: n // 3 + n // 8] = d[5]
+        d[n // 3: n // 3 + n // 4] = d[5]
     elif kind == "grid":
         d = (d * 16).round() / 16
     return d.to(dev)
