@@ -35,9 +35,18 @@ __global__ __launch_bounds__(256) void cdist_small_kernel(const float* __restric
   if (j >= r) return;
   const int rows = min(kRows, p - i0);
   for (int i = 0; i < rows; ++i) {
-    float acc = 0.f;
+    float acc;
+    if (mode <= 1) {
+      // (squared) Euclidean: the fixed rounding sequence that the streaming nearest-neighbour kernels share
+      float ai[M];
 #pragma unroll
-    for (int k = 0; k < M; ++k) acc = accumulate(acc, at[i][k] - bj[k], mode);
+      for (int k = 0; k < M; ++k) ai[k] = at[i][k];
+      acc = squared_distance<M>(ai, bj);
+    } else {
+      acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < M; ++k) acc = accumulate(acc, at[i][k] - bj[k], mode);
+    }
     out[(int64_t)(i0 + i) * r + j] = mode == 0 ? sqrtf(acc) : acc;
   }
 }

@@ -39,6 +39,22 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// Squared Euclidean distance of two short vectors with a FIXED rounding sequence: the first square is rounded on its own,
+// every further one is fused into the running sum.  Written out because `acc + d * d` leaves it to the compiler which
+// of two products it fuses, and kernels that must agree bit for bit on a distance (a distance matrix here, a streaming
+// nearest-neighbour scan there) would then differ in the last place now and then.
+template <int M>
+__device__ __forceinline__ float squared_distance(const float (&a)[M], const float (&b)[M]) {
+  float d = a[0] - b[0];
+  float acc = __fmul_rn(d, d);
+#pragma unroll
+  for (int k = 1; k < M; ++k) {
+    d = a[k] - b[k];
+    acc = fmaf(d, d, acc);
+  }
+  return acc;
+}
+
 // Remap a linear workgroup id so that each XCD (which owns a private L2) receives a
 // contiguous chunk of the tile space.  Workgroups are dealt round-robin over the 8 XCDs,
 // so ids congruent mod 8 share an L2.  Bijective for any nwg.

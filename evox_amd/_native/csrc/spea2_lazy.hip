@@ -30,13 +30,7 @@ enum { kRemoved = 0, kRounds = 1, kRoundCount = 2, kSCount = 3, kTauBits = 4, kT
 
 template <int M>
 __device__ __forceinline__ float dist(const float (&a)[M], const float (&b)[M]) {
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < M; ++k) {
-    const float d = a[k] - b[k];
-    acc = acc + d * d;
-  }
-  return sqrtf(acc);
+  return sqrtf(squared_distance<M>(a, b));                // the rounding sequence of distance.hip::cdist_small_kernel
 }
 
 // Rescan: the nearest live neighbour (distance, index; smallest index among equals) of every live point whose recorded

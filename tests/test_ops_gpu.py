@@ -1721,6 +1721,8 @@ def _spea2_points(n, m, seed, kind):
         d[n // 3: n // 3 + n // 4] = d[5]                # (more of them than a round plays through)
     elif kind == "grid":                                 # many exactly equal distances
         d = (d * 16).round() / 16
+    elif kind == "twelfths":                             # coordinates that are not exact in binary: a distance must round the
+        d = (torch.rand(n, m, generator=g) * 12).round() / 12   # same way in the matrix and in the streaming kernels
     elif kind == "line":                                 # equidistant points: every nearest-neighbour distance is the same
         d = torch.stack([torch.arange(n, dtype=torch.float32) / 8] + [torch.zeros(n)] * (m - 1), dim=1)
     return d.cuda()
@@ -1728,7 +1730,7 @@ def _spea2_points(n, m, seed, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,m,kind", [(2100, 3, "front"), (6000, 2, "front"), (5000, 5, "front"), (13000, 3, "front"),
-                                      (4000, 3, "clones"), (5000, 3, "grid"), (3000, 2, "line")])
+                                      (4000, 3, "clones"), (5000, 3, "grid"), (3000, 2, "line"), (9000, 4, "twelfths")])
 def test_spea2_round_wise_truncation_equals_one_at_a_time_loop(n, m, kind, monkeypatch):
     """Truncation in rounds (the 512 points with the closest neighbour played through on one wave with lists of their 8
     nearest live neighbours, then a chip-wide rescan of every point whose neighbour went) keeps exactly the points the
@@ -1739,7 +1741,7 @@ def test_spea2_round_wise_truncation_equals_one_at_a_time_loop(n, m, kind, monke
 
     pts = _spea2_points(n, m, n + m, kind)
     mask = torch.ones(n, dtype=torch.bool, device="cuda")
-    n_remove = n // 2 + 7
+    n_remove = n // 2 + 7 if kind != "twelfths" else (3 * n) // 4
     monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "0")
     want = moselect.spea2_truncate(pts, mask, n_remove)
     monkeypatch.setenv("EVOX_AMD_SPEA2_LAZY", "1")
