@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from evox_amd.ops import moselect as sel, _nds_hip
 
 dev = torch.device("cuda")
-g = torch.Generator().manual_seed(1234)
+g = torch.Generator().manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
 bad = 0
 
 
