@@ -162,9 +162,15 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
         if chunk_rate < (_IBEA_LAZY_MIN_RATE if min_rate is None else min_rate) and n <= int(hip().evox_hip_ibea_remove_obj_max(int(m))):
             # rounds that remove only a handful each (everyone's fitness rises together, e.g. tight clusters of
             # near-copies) cost more than the one-at-a-time loop: it finishes the job from the current fitness values
-            alive = torch.empty(n, dtype=torch.uint8, device=obj.device)
-            check(hip().evox_hip_ibea_remove_obj(obj.data_ptr(), n, m, C.data_ptr(), float(kappa), work.data_ptr(),
-                                                 n_remove - done, alive.data_ptr(), stream_of(obj)), "ibea_remove_obj")
+            # (only the members still there go along: the loop's cost per removal grows with the number it holds)
+            left = torch.nonzero(work < float("inf")).squeeze(1)
+            sub_obj, sub_c, sub_fit = obj[left].contiguous(), C[left].contiguous(), work[left].contiguous()
+            sub_alive = torch.empty(left.numel(), dtype=torch.uint8, device=obj.device)
+            check(hip().evox_hip_ibea_remove_obj(sub_obj.data_ptr(), left.numel(), m, sub_c.data_ptr(), float(kappa),
+                                                 sub_fit.data_ptr(), n_remove - done, sub_alive.data_ptr(), stream_of(obj)),
+                  "ibea_remove_obj")
+            alive = torch.zeros(n, dtype=torch.uint8, device=obj.device)
+            alive[left] = sub_alive
             fallback = True
             break
         per_round = max(1.0, done / max(1, state[1]))
