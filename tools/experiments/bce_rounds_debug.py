@@ -24,9 +24,11 @@ prob = problems.numerical.DTLZ2(d=12, m=3)
 algo = getattr(A, name)(torch.zeros(12, device=dev), torch.ones(12, device=dev), 3, pop)
 wf = workflows.StdWorkflow(algo, prob)
 state = wf.init(ex.PRNGKey(1).to(dev))
-for g in range(12):
+gens = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+every = max(1, gens // 8)
+for g in range(gens):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     state = wf.step(state)
     torch.cuda.synchronize()
-    print(g, "gen ms", round((time.perf_counter() - t0) * 1e3, 2), log[-2:] if g % 3 == 0 else "", flush=True)
+    print(g, "gen ms", round((time.perf_counter() - t0) * 1e3, 2), log[-1:] if g % every == 0 else "", flush=True)
     log.clear()
