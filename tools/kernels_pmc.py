@@ -122,5 +122,10 @@ for _ in range(2):
     fit20k, c20k = moselect.ibea_fitness(front, 0.05)
     keep = moselect.ibea_remove_rounds(front, fit20k, c20k, 0.05, 10000)                  # ibea_lazy_select / apply kernels
     keep = moselect.spea2_truncate_rounds(front, 10000)                                   # spea2_lazy_* / flag / scan / finish kernels
+# the one-launch two-objective sort and the three-state knee suppression
+from evox_amd.ops import _nds_hip as _nh
+for _ in range(2):
+    r2d = _nh.rank(torch.rand(20000, 2, device=dev), 10000)                               # nds2_scan_kernel
+    kp2 = moselect.knee_suppress(front, torch.randperm(20000, device=dev), torch.full((3,), 0.01, device=dev))   # knee_state / knee_tail
 torch.cuda.synchronize()
 print("done")
