@@ -24,7 +24,8 @@ def pts(n, m, style):
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 for case in range(n_cases):
-    n = int(torch.randint(2100, 15000, (1,), generator=g)); m = int(torch.randint(2, 6, (1,), generator=g))
+    m = int(torch.randint(2, 9, (1,), generator=g))
+    n = int(torch.randint(2100, 15000 if m <= 4 else 8100, (1,), generator=g))      # sizes the one-at-a-time IBEA kernel takes
     style = case % 4
     x = pts(n, m, style)
     obj = (x - x.min()) / (x.max() - x.min())
