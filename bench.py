@@ -35,7 +35,83 @@ def _self_launch(n: int) -> int:
     return mod.launch_ranks(__file__, sys.argv[1:], n)
 
 
+def _secondary(dev):
+    """The other benchmark configurations on the same GPU, timed like the headline (synchronise, K generations,
+    synchronise).  Each entry is measured on its own; a failure is recorded in place of its numbers."""
+    import torch
+
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    def timed(wf, state, steps, warmup):
+        for _ in range(warmup):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        return state, time.perf_counter() - t0
+
+    def nsga2():
+        pop, d, steps = 100000, 12, 30
+        algo = algorithms.NSGA2(lb=torch.zeros(d, device=dev), ub=torch.ones(d, device=dev), n_objs=3, pop_size=pop)
+        wf = workflows.StdWorkflow(algo, problems.numerical.DTLZ2(m=3))
+        state, dt = timed(wf, wf.init(ex.PRNGKey(2).to(dev)), steps, 10)
+        return {"config": f"NSGA-II pop={pop} DTLZ2 m=3 d={d}", "gens_per_sec": steps / dt, "ms_per_step": 1e3 * dt / steps,
+                "evals_per_sec": pop * steps / dt, "steps": steps, "warmup": 10}
+
+    def shade():
+        pop, d, steps = 50000, 20, 200
+        algo = algorithms.SHADE(lb=torch.full((d,), -100.0, device=dev), ub=torch.full((d,), 100.0, device=dev), pop_size=pop)
+        wf = workflows.StdWorkflow(algo, problems.numerical.CEC2022TestSuit.create(1))
+        state, dt = timed(wf, wf.init(ex.PRNGKey(4).to(dev)), steps, 30)
+        return {"config": f"SHADE pop={pop} CEC2022-F1 d={d} (one island)", "gens_per_sec": steps / dt,
+                "ms_per_step": 1e3 * dt / steps, "evals_per_sec": pop * steps / dt, "steps": steps, "warmup": 30,
+                "best": float(state.get_child_state("algorithm").fitness.min())}
+
+    def openes():
+        from evox_amd.models import MLP
+        from evox_amd.problems.neuroevolution import SyntheticLocomotion, TensorEnvProblem
+
+        obs_dim, act_dim, pop, horizon, steps = 244, 17, 4096, 50, 5
+        net = MLP([obs_dim, 1024, 720, act_dim])
+        prob = TensorEnvProblem(net.batched_apply, SyntheticLocomotion(obs_dim, act_dim, seed=4), max_episode_length=horizon,
+                                num_episodes=1)
+        algo = algorithms.OpenES(net.init(ex.PRNGKey(0)).to(dev), pop_size=pop, learning_rate=0.01, noise_stdev=0.05,
+                                 optimizer="adam", mirrored_sampling=True)
+        wf = workflows.StdWorkflow(algo, prob, opt_direction="max")
+        state, dt = timed(wf, wf.init(ex.PRNGKey(3).to(dev)), steps, 2)
+        return {"config": f"OpenES MLP {net.sizes} ({net.n_params} params) pop={pop}, synthetic locomotion obs={obs_dim}, "
+                          f"episode_length={horizon}, fp32 parameters", "evals_per_sec": pop * steps / dt,
+                "env_steps_per_sec": pop * horizon * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 2}
+
+    out = {}
+    for name, fn in (("nsga2_dtlz2_pop100k", nsga2), ("shade_cec2022_f1_pop50k", shade), ("openes_mlp_1m_pop4096", openes)):
+        try:
+            out[name] = fn()
+        except Exception as e:               # the headline above stands on its own
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
+    try:
+        _main()
+    except SystemExit:
+        raise
+    except BaseException as e:                 # the driver reads one JSON line whatever happens
+        import traceback
+
+        traceback.print_exc()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "evaluations/sec, CMA-ES pop=10k dim=1k Ackley", "value": None,
+                              "error": f"{type(e).__name__}: {e}"}), flush=True)
+        raise SystemExit(1)
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -63,6 +139,9 @@ def main():
     ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
                     help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
                          "rehearses the multi-rank path on a single GPU")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary configurations (NSGA-II 10^5, SHADE 50k, OpenES 4096) measured after the "
+                         "headline on a single GPU")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -73,14 +152,19 @@ def main():
 
     import torch
 
-    import evox_amd as ex
-    from evox_amd import algorithms, problems, workflows
-    from evox_amd.core import distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     on_gpu = args.device == "cuda"
+    # counting devices does not initialise one: a job with more ranks than GPUs ends here, before any rank touches a device
+    if on_gpu and (args.backend or "nccl") == "nccl" and world > 1 and world > torch.cuda.device_count():
+        raise RuntimeError(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible: RCCL needs one GPU per "
+                           "rank (use --backend gloo to rehearse several ranks on one GPU)")
+
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+    from evox_amd.core import distributed as dist
+
     if world > 1:
         dist.init_process_group(args.backend or ("nccl" if on_gpu else "gloo"))
     rank = dist.get_process_id()
@@ -104,7 +188,7 @@ def main():
 
         wf = ShardedWorkflow(algo, problem, resync_every=args.resync_every)
     else:
-        wf = workflows.StdWorkflow(algo, problem, graph_step=args.graph)
+        wf = workflows.StdWorkflow(algo, problem, graph_step=args.graph, graph_mode="ring")
     state = wf.init(key)
     # One-time setup, the counterpart of a tracing compiler's compilation: the first generations time the candidate
     # GEMM algorithms of every shape (plans are cached afterwards) and let the factorisation's iteration control settle
@@ -164,13 +248,18 @@ def main():
                        "parallelism": f"dp{world} (row-sharded sampling/evaluation/covariance, replicated factorisation)",
                        "decomp_per_iter": algo.decomp_per_iter, "decomposition": args.decomp, "mu": algo.mu, "graph": bool(args.graph),
                        "setup_generations_before_warmup": args.prime,
-                       "precision": ("bf16 operands in the sampling and covariance GEMMs; fp32 accumulation, state, "
-                                     "fitness and factorisation" if args.precision == "bf16" else "fp32 throughout")},
+                       "precision": ("bf16 operands in the sampling and covariance GEMMs and, as split hi+lo planes, in the "
+                                     "Newton-Schulz factorisation products; fp32 accumulation, state and fitness"
+                                     if args.precision == "bf16" else "fp32 throughout")},
             "sigma_end": sigma,
             "best_fitness_end": best,
             "factorisation": ns_report,
             "factorisation_residual": getattr(getattr(algo, "_ns", None), "last_residual", None),
         }
+        if world == 1 and on_gpu and not args.no_secondary:
+            del state, wf, algo
+            torch.cuda.empty_cache()
+            out["secondary"] = _secondary(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as td

@@ -64,13 +64,23 @@ def init_process_group(backend: Optional[str] = None, device: Optional[torch.dev
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.
 
     Picks ``nccl`` (RCCL) when a GPU is visible, else ``gloo``; binds this process to
-    ``cuda:LOCAL_RANK``.  Safe to call when already initialised.
+    ``cuda:LOCAL_RANK``.  Safe to call when already initialised.  The rendezvous and every collective get a finite
+    time limit (``timeout=`` as a ``datetime.timedelta`` or seconds; default ``EVOX_AMD_DIST_TIMEOUT`` or 300 s), so
+    a peer that never arrives ends in an error instead of a hang.
     """
+    import datetime
+
     d = _dist()
     if d.is_initialized():
         return
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    timeout = kw.pop("timeout", None)
+    if timeout is None:
+        timeout = float(os.environ.get("EVOX_AMD_DIST_TIMEOUT", "300"))
+    if not isinstance(timeout, datetime.timedelta):
+        timeout = datetime.timedelta(seconds=float(timeout))
+    kw["timeout"] = timeout
     if backend == "nccl":
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local if device is None else device)

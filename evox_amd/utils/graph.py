@@ -98,6 +98,11 @@ class GraphedStep:
                     out_state = out[0] if isinstance(out, tuple) else out
                     new = [l for l in _tree.tree_leaves(out_state) if isinstance(l, torch.Tensor)]
                     pairs = [(d, s) for d, s in zip(feedback_to, new) if d is not s and d.data_ptr() != s.data_ptr()]
+                    # A state that shifts fields over generations (prev2 <- prev1 <- cur) hands back, as the new value
+                    # of one leaf, the static input buffer of another leaf.  That buffer is itself a destination of
+                    # this copy, so it is read from a snapshot: the result then does not depend on the leaf order.
+                    static_ptrs = {d.data_ptr() for d in feedback_to}
+                    pairs = [(d, s.clone() if s.data_ptr() in static_ptrs else s) for d, s in pairs]
                     if pairs:
                         torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
         except GraphCaptureError:

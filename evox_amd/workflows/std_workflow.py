@@ -60,7 +60,7 @@ class StdWorkflow(Workflow):
         num_objectives: Optional[int] = None,
         migrate_helper=None,
         graph_step: bool = False,
-        graph_mode: str = "ring",
+        graph_mode: str = "copy",
     ):
         """
         algorithm, problem      the two halves of the loop.
@@ -82,9 +82,12 @@ class StdWorkflow(Workflow):
                                 stays eager); the timings end up in ``graph_choice``.  Replays win where a generation
                                 is many small kernels; a generation that already keeps the GPU busy (full-matrix
                                 CMA-ES) is faster issued eagerly.
-        graph_mode              "ring": pointer-stable replay, the state tensors handed out are the recordings' own
-                                buffers (valid for one further step; clone what must live longer); "copy": value
-                                semantics, every replay copies the state in and clones it out (``utils.graph``).
+        graph_mode              "copy" (default): value semantics like the reference's compiled step — every replay
+                                copies the state in and clones it out, so a state the caller keeps (a history list, a
+                                best-so-far snapshot, a deferred checkpoint) stays what it was.  "ring": pointer-stable
+                                replay for benchmarks and tight loops — the state tensors handed out are the recordings'
+                                own buffers, valid for one further step (clone what must live longer); monitors with
+                                ``post_tell`` / ``post_step`` hooks are handed a snapshot (``utils.graph``).
         """
         super().__init__()
         self.algorithm = algorithm
@@ -371,10 +374,15 @@ class StdWorkflow(Workflow):
             m.post_eval(new_state, aux["cands"], aux["tcands"], aux["fitness"])
         for m in hooks["pre_tell"]:
             m.pre_tell(new_state, aux["cands"], aux["tcands"], aux["fitness"], aux["tfitness"])
+        seen = new_state
+        if self.graph_mode == "ring" and (hooks["post_tell"] or hooks["post_step"]):
+            # ring replay hands out the recordings' own buffers, overwritten one step later: a monitor that keeps
+            # what it is shown (PopMonitor's history) gets a snapshot instead
+            seen = _tree.tree_map(lambda t: t.clone() if isinstance(t, torch.Tensor) else t, new_state)
         for m in hooks["post_tell"]:
-            m.post_tell(new_state)
+            m.post_tell(seen)
         for m in hooks["post_step"]:
-            m.post_step(new_state)
+            m.post_step(seen)
         return new_state
 
     # ------------------------------------------------------------------------------------

@@ -233,6 +233,64 @@ def test_graph_step_replays_match_eager(cuda, algo_name, mode):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["ring", "copy"])
+def test_pop_monitor_history_under_graph_replay(cuda, mode):
+    """A monitor that keeps what it is shown (PopMonitor) must end up with the eager run's histories: ring replay hands
+    out the recordings' own buffers, so the workflow shows such monitors a snapshot."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+    from evox_amd.monitors import PopMonitor
+
+    def run(graph):
+        lb, ub = -torch.ones(16, device=cuda) * 5, torch.ones(16, device=cuda) * 5
+        mon = PopMonitor()
+        wf = workflows.StdWorkflow(algorithms.PSO(lb=lb, ub=ub, pop_size=128), problems.numerical.Rastrigin(), monitors=[mon],
+                                   graph_step=graph, graph_mode=mode)
+        state = wf.init(ex.PRNGKey(4))
+        kept = []
+        for _ in range(9):
+            state = wf.step(state)
+            if mode == "copy":
+                kept.append(state.get_child_state("algorithm").population)   # value semantics: may be kept as is
+        torch.cuda.synchronize()
+        return mon, kept
+
+    me, ke = run(False)
+    mg, kg = run(True)
+    assert len(me.fitness_history) == len(mg.fitness_history) == 9
+    for a, b in zip(me.fitness_history, mg.fitness_history):
+        assert torch.equal(a, b)
+    for a, b in zip(me.population_history, mg.population_history):
+        assert torch.equal(a, b)
+    for a, b in zip(ke, kg):
+        assert torch.equal(a, b)
+    assert len({t.data_ptr() for t in mg.population_history}) == 9
+
+
+def test_ring_replay_with_a_two_generation_history_field(cuda):
+    """A step that shifts fields (prev2 <- prev1 <- cur) returns, as one leaf's new value, another leaf's buffer: the
+    end-of-ring copy into the static inputs must not depend on the order of the leaves."""
+    from evox_amd.core.state import State
+    from evox_amd.utils.graph import GraphedStep
+
+    def step(s):
+        cur = s.cur * 1.5 + s.prev2
+        return State(cur=cur, prev1=s.cur, prev2=s.prev1)
+
+    def fresh():
+        return State(cur=torch.arange(8, dtype=torch.float32, device=cuda), prev1=torch.ones(8, device=cuda),
+                     prev2=torch.full((8,), 2.0, device=cuda))
+
+    for ring in (1, 2, 3):
+        se, sg = fresh(), fresh()
+        g = GraphedStep(step, mode="ring", ring=ring)
+        for i in range(11):
+            se, sg = step(se), g(sg)
+            torch.cuda.synchronize()
+            for name in ("cur", "prev1", "prev2"):
+                assert torch.equal(getattr(se, name), getattr(sg, name)), (ring, i, name)
+
+
 @pytest.mark.parametrize("n,m", [(11, 2), (700, 2), (1024, 4), (3000, 3), (2500, 5), (1500, 8), (4096, 2), (4000, 8),
                                  (5000, 3)])
 def test_nd_sort_kernel_matches_reference(cuda, n, m):

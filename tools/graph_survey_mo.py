@@ -27,7 +27,7 @@ def run(name, args, dev, graph):
     prob = problems.numerical.DTLZ2(m=3)
     lb, ub = torch.zeros(prob.d, device=dev), torch.ones(prob.d, device=dev)
     algo = A.LMOCSO(3, lb, ub, args.pop) if name == "LMOCSO" else getattr(A, name)(lb, ub, 3, args.pop)
-    wf = workflows.StdWorkflow(algo, prob, graph_step=graph)
+    wf = workflows.StdWorkflow(algo, prob, graph_step=graph, graph_mode="ring")
     state = wf.init(ex.PRNGKey(5).to(dev))
     for _ in range(args.warmup):
         state = wf.step(state)
