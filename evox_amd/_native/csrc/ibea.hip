@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void knee_round_kernel(const float* __restrict
 template <int M>
 __global__ __launch_bounds__(256) void knee_state_kernel(const float* __restrict__ f, const float* __restrict__ R, int n,
                                                          const int64_t* __restrict__ todo, int n_todo,
-                                                         const uint8_t* __restrict__ state_in, uint8_t* __restrict__ state_out,
+                                                         const uint8_t* state_in, uint8_t* state_out,   // one buffer when suppress_only
                                                          int suppress_only) {
   __shared__ float tile[M][256];
   __shared__ uint8_t tstate[256];

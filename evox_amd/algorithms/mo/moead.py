@@ -155,9 +155,10 @@ class MOEADDRA(MOAlgorithm):
         nxt = torch.clamp(nxt, self.lb, self.ub)
         return nxt, state.replace(next_generation=nxt, choosed_p=choosed, key=key, I_all=I_all)
 
-    # recorded generations: the counter only decides which generations refresh the utilities (every tenth)
+    # recorded generations: the counter only decides which generations refresh the utilities (every tenth); it stays
+    # the generation count (advanced on the host at replay), the branch is named by ``graph_variant``
     def graph_host_counters(self):
-        return (("gen", 10),)
+        return ("gen",)
 
     def graph_variant(self, state):
         return (state.gen + 1) % 10 == 0

@@ -72,10 +72,10 @@ class EAGMOEAD(MOAlgorithm):
         nxt = self._vary(k_x, k_mut, mates)
         return nxt, state.replace(next_generation=nxt, offspring_loc=loc, key=key)
 
-    # a recorded generation: ``gen`` only selects the column of the success history it rewrites, so it may wrap at LGs,
-    # and every column has its own recording
+    # a recorded generation: ``gen`` only selects the column of the success history it rewrites: every column has its
+    # own recording (``graph_variant``), and the counter itself stays the generation count, advanced on the host
     def graph_host_counters(self):
-        return (("gen", self.LGs),)
+        return ("gen",)
 
     def graph_variant(self, state):
         return (state.gen + 1) % self.LGs

@@ -56,8 +56,7 @@ class RVEA(MOAlgorithm):
 
     # recorded generations: the host counter only decides which generations adapt the reference vectors
     def graph_host_counters(self):
-        period = round(1 / self.fr)
-        return (("gen", period),) if period > 0 else ("gen",)
+        return ("gen",)                 # stays the generation count; the adapting generations are a variant of their own
 
     def graph_variant(self, state):
         period = round(1 / self.fr)

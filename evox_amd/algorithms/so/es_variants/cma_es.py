@@ -461,7 +461,18 @@ class CMAES(Algorithm):
             packed = reduced.wait()
             overflow = packed[nn + self.dim]
             consts["calls"] += 1
-            if consts["calls"] % 64 == 0 and float(overflow) > 0:
+            # The diagnosis without a host synchronisation: the flag word of every generation is copied into pinned host
+            # memory asynchronously and looked at by the following calls — an overflow (which has already poisoned the
+            # update on every rank) is reported one or two generations later, whenever the copy has landed.
+            if pop.is_cuda and not torch.cuda.is_current_stream_capturing():
+                seen = consts.get("overflow_host")
+                if seen is None:
+                    seen = consts["overflow_host"] = torch.zeros(1, dtype=torch.float32).pin_memory()
+                if float(seen[0]) > 0:
+                    raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(seen[0])} rank(s): "
+                                       "the update was poisoned (NaN) on every rank")
+                seen.copy_(overflow.reshape(1), non_blocking=True)
+            elif consts["calls"] % 64 == 0 and float(overflow) > 0:
                 raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(overflow)} rank(s)")
             gram = packed[:nn] if native else packed[:nn].view(self.dim, self.dim)
             if native and ws is not None:

@@ -126,6 +126,21 @@ def ibea_remove_streaming_fits(n: int, m: int) -> bool:
             or _ibea_multi(int(n), int(m)))
 
 
+def _remove_bad_first(n_remove: int, bad: torch.Tensor, n_bad: int, run_good) -> torch.Tensor:
+    """Survivor mask of a removal among members some of which hold non-finite values (``bad``).  No round can select
+    such a member and none counts it as removed, so a mask taken from the rounds would have the wrong size in either
+    direction.  They are the worst members by definition and go first (highest index first when more are bad than must
+    go); the rest of the removal is done among the good members by ``run_good(index, count)``."""
+    keep = ~bad
+    if n_bad >= n_remove:
+        idx = torch.nonzero(bad).squeeze(1)
+        keep[idx[:n_bad - n_remove]] = True               # more bad members than removals: the first ones stay
+        return keep
+    good = torch.nonzero(keep).squeeze(1)
+    keep[good] = run_good(good, n_remove - n_bad)
+    return keep
+
+
 def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, flags: int = 0,
                        min_rate: float = None) -> torch.Tensor:
     """The removal loop in rounds (``csrc/ibea_lazy.hip``): fitness values only grow while members are removed, so the
@@ -143,6 +158,11 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
         return work < float("inf")
     obj = obj.contiguous()
     C = C.contiguous()
+    bad = ~(torch.isfinite(fit) & torch.isfinite(C) & torch.isfinite(obj).all(1))
+    n_bad = int(bad.sum())
+    if n_bad:
+        return _remove_bad_first(n_remove, bad, n_bad, lambda good, k: ibea_remove_streaming(
+            obj[good], fit[good].contiguous(), C[good].contiguous(), kappa, k))
     ctrl = torch.empty(int(hip().evox_hip_ibea_lazy_ctrl_words()), dtype=torch.int32, device=obj.device)
     rem = torch.empty(int(hip().evox_hip_ibea_lazy_rem_floats(m)), dtype=torch.float32, device=obj.device)
     cand = torch.empty(int(hip().evox_hip_ibea_lazy_cand_words()), dtype=torch.int32, device=obj.device)
@@ -178,6 +198,8 @@ def ibea_remove_rounds(obj, fit, C, kappa, n_remove: int, stats: dict = None, fl
     if stats is not None:
         stats.update(removed=state[0], rounds=state[1], tie_rounds=state[3], issued=issued, select_us=state[4] / 100.0,
                      simulate_us=state[5] / 100.0, bisections=state[6], sentinel_rounds=state[9], candidate_rounds=state[13], fallback=fallback)
+    if not fallback and state[0] < min(n_remove, n):
+        raise RuntimeError(f"IBEA removal: the rounds stopped after {state[0]} of {n_remove} removals on finite inputs")
     return alive.bool() if fallback else work < float("inf")
 
 
@@ -302,6 +324,11 @@ def spea2_truncate_rounds(points, n_remove: int, stats: dict = None) -> torch.Te
     alive = torch.ones(n, dtype=torch.uint8, device=dev)
     if n_remove <= 0:
         return alive.bool()
+    bad = ~torch.isfinite(points).all(1)
+    n_bad = int(bad.sum())
+    if n_bad:
+        return _remove_bad_first(n_remove, bad, n_bad, lambda good, k: spea2_truncate(
+            points[good], torch.ones(good.numel(), dtype=torch.bool, device=dev), k))
     rowmin = torch.empty(n, dtype=torch.float32, device=dev)
     nn = torch.empty(n, dtype=torch.int32, device=dev)
     ctrl = torch.empty(int(hip().evox_hip_spea2_lazy_ctrl_words()), dtype=torch.int32, device=dev)
@@ -321,6 +348,8 @@ def spea2_truncate_rounds(points, n_remove: int, stats: dict = None) -> torch.Te
         rounds = min(_IBEA_LAZY_CHUNK, max(4, int(1.25 * (n_remove - done) / per_round) + 1))
     if stats is not None:
         stats.update(removed=state[0], rounds=state[1], tie_rounds=state[8], short_rounds=state[9], issued=issued)
+    if state[0] < min(n_remove, n - 1):                       # the last point has no neighbour and always stays
+        raise RuntimeError(f"SPEA2 truncation: the rounds stopped after {state[0]} of {n_remove} removals on finite inputs")
     return alive.bool()
 
 

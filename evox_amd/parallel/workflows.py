@@ -40,24 +40,27 @@ class ShardedWorkflow(StdWorkflow):
     a few MB every k generations, removes them altogether.
 
     ``monitor_candidates`` (row-sharded mode; in replicated mode every rank holds all candidates anyway):
-    ``"local"`` – the ``post_eval`` / ``pre_tell`` hooks get this rank's rows next to the full fitness
-    (:class:`~evox_amd.monitors.EvalMonitor` then tracks the best among the rows it sees); ``"full"`` – the candidate
-    rows are all-gathered each generation (pop × dim elements) and the hooks get the full set, row-aligned with the
-    fitness.  The option must be the same on every rank: the gather is a collective whether or not a rank has monitors.
+    ``"full"`` – the candidate rows are all-gathered each generation (pop × dim elements) and the ``post_eval`` /
+    ``pre_tell`` hooks get the full set, row-aligned with the fitness, so an
+    :class:`~evox_amd.monitors.EvalMonitor` on rank 0 tracks the best individual of the whole population;
+    ``"local"`` – the hooks get this rank's rows next to the full fitness (a monitor then sees the best among its own
+    rows only); ``"auto"`` (default) – ``"full"`` when ANY rank has a monitor on those hooks, ``"local"`` otherwise:
+    the ranks agree on it with one small all-reduce in ``init`` (the gather is a collective, so every rank has to take
+    part whether or not it has monitors itself).  An explicit value must be the same on every rank.
 
     State fields declared with ``pytree_field(sharding=ShardingType.SHARED_FIRST_DIM)`` in the algorithm's state
     dataclass (or listed in ``algorithm.sharded_fields``) are row-local: ``resync`` leaves them alone and
     ``shard_state`` cuts them to this rank's rows."""
 
     def __init__(self, algorithm, problem, monitors=(), opt_direction="min", candidate_transforms=(),
-                 fitness_transforms=(), resync_every: int = 0, monitor_candidates: str = "local",
+                 fitness_transforms=(), resync_every: int = 0, monitor_candidates: str = "auto",
                  global_fitness_transforms=(), **kwargs):
         super().__init__(algorithm, problem, monitors, opt_direction, candidate_transforms, fitness_transforms, **kwargs)
         self.row_sharded = supports_sharding(algorithm)
         self.pmap_axis_name = dist.POP_AXIS_NAME
         self.resync_every = int(resync_every)
-        if monitor_candidates not in ("local", "full"):
-            raise ValueError("monitor_candidates must be 'local' or 'full'")
+        if monitor_candidates not in ("local", "full", "auto"):
+            raise ValueError("monitor_candidates must be 'auto', 'local' or 'full'")
         self.monitor_candidates = monitor_candidates
         # applied to the gathered (whole-population) fitness on every rank, before ``fitness_transforms``
         self.global_fitness_transforms = list(global_fitness_transforms)
@@ -136,9 +139,21 @@ class ShardedWorkflow(StdWorkflow):
 
     def init(self, key=None, no_state: bool = False):
         state = super().init(key, no_state)
+        self._resolve_monitor_candidates()
         if state is None:
             return None
         return state.replace(rank=dist.get_process_id(), world_size=dist.get_world_size())
+
+    def _resolve_monitor_candidates(self) -> None:
+        if self.monitor_candidates != "auto":
+            return
+        mine = bool(self.registered_hooks["post_eval"] or self.registered_hooks["pre_tell"])
+        if dist.get_world_size() > 1:
+            flag = torch.tensor([1.0 if mine else 0.0])
+            if dist._dist().get_backend() != "gloo":
+                flag = flag.cuda()
+            mine = bool(float(dist.all_reduce(flag, "max")[0]) > 0)
+        self.monitor_candidates = "full" if mine else "local"
 
     # -- checkpoints -----------------------------------------------------------------------
     def _local_keys(self, state):
@@ -174,6 +189,8 @@ class ShardedWorkflow(StdWorkflow):
             return super()._step(state, hooks, aux)
         hooks = self.registered_hooks if hooks is None else hooks
         rank, world = state.rank, state.world_size
+        if self.monitor_candidates == "auto":              # a state that did not come from this object's ``init``
+            self._resolve_monitor_candidates()
         for m in hooks["pre_step"]:
             m.pre_step(state)
         for m in hooks["pre_ask"]:

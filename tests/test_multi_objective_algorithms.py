@@ -54,6 +54,20 @@ def test_sra_reference_coin_mode_still_converges():
     assert float(metrics.IGD(problem.pf())(fit)) < 0.15
 
 
+@pytest.mark.parametrize("name,kw,bound", [("EAGMOEAD", {"aggregation": "weighted_sum"}, 0.25),
+                                           ("HypE", {"tight_sampling": False}, 0.30),
+                                           ("SRA", {"coins": "per_position", "density": "preceding"}, 0.15)])
+def test_reference_forms_stay_available(name, kw, bound):
+    """The three algorithms whose defaults differ from the reference (aggregation of EAG-MOEA/D, sampling box of HypE,
+    coins of SRA) keep the reference's form behind a keyword; it runs and converges, less tightly than the default."""
+    problem = DTLZ2(m=M)
+    state, _ = run(name, kw, 100, problem)
+    fit = state.get_child_state("algorithm").fitness
+    fit = fit[torch.isfinite(fit).all(1)]
+    assert fit.shape[0] >= POP // 2
+    assert float(metrics.IGD(problem.pf())(fit)) < bound
+
+
 def test_all_inventory_covered():
     assert sorted(c[0] for c in CASES) == sorted(algorithms.mo.__all__)
 

@@ -1771,6 +1771,31 @@ def test_ibea_round_wise_removal_edge_counts():
     assert int(few.sum()) == 10
 
 
+@pytest.mark.gpu
+def test_round_wise_removals_keep_their_count_with_non_finite_members():
+    """Members with NaN objectives cannot be selected by any round and are not counted as removed: they go first, and
+    the mask still has exactly ``n - n_remove`` survivors."""
+    from evox_amd.ops import moselect
+
+    n = 3000
+    obj = _ibea_front(n, 3, 11, "front")
+    fit, C = moselect.ibea_fitness(obj, 0.05)
+    bad_rows = torch.tensor([5, 77, 1234, 2999], device="cuda")
+    obj_bad, fit_bad = obj.clone(), fit.clone()
+    obj_bad[bad_rows] = float("nan")
+    fit_bad[bad_rows] = float("nan")
+    for n_remove in (2, 1500):
+        keep = moselect.ibea_remove_rounds(obj_bad, fit_bad, C, 0.05, n_remove)
+        assert int(keep.sum()) == n - n_remove
+        assert not bool(keep[bad_rows[-min(n_remove, 4):]].any())
+    pts = _spea2_points(2500, 3, 3, "front")
+    pts[bad_rows[:3]] = float("nan")
+    for n_remove in (2, 1200):
+        keep = moselect.spea2_truncate_rounds(pts, n_remove)
+        assert int(keep.sum()) == 2500 - n_remove
+        assert not bool(keep[bad_rows[:3][-min(n_remove, 3):]].any())
+
+
 def _spea2_points(n, m, seed, kind):
     g = torch.Generator().manual_seed(seed)
     d = torch.randn(n, m, generator=g).abs()
