@@ -49,6 +49,7 @@ struct Args {
   int ksteps_per_split;          // K steps handled by one workgroup
   int tiles_m, tiles_n;
   int ntiles, splits;            // grid = ntiles * splits * products, one dimension
+  int batch;                     // products of the launch
   int probe;                     // timing experiments only: 1 = stage the first steps only, 2 = skip the multiply, 4 = skip the epilogue
 };
 
@@ -97,17 +98,35 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WM, int WN, int NP, bool UPPER, int STAGES, class Epi>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(Args<NP> g, Epi epi) {
+// A launch may carry SIDE workgroups behind the ones that multiply: a product of n = 1000 has 136 upper tiles of 64 x 64,
+// so 120 of the 256 compute units would idle for its 20 us.  A `Side` functor with kEnabled = true is called by every
+// workgroup whose index lies beyond the product's (side(index, count, lds)): small dependent-free jobs of the caller —
+// matrix-vector products, the Gaussian draws of the next generation — then run in the product's shadow instead of as
+// launches of their own.  The stage memory of such a workgroup is free for the functor's use.
+struct NoSide {
+  static constexpr bool kEnabled = false;
+  __device__ __forceinline__ void operator()(int, int, char*) const {}
+};
+
+template <int BM, int BN, int WM, int WN, int NP, bool UPPER, int STAGES, class Epi, class Side = NoSide>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(Args<NP> g, Epi epi, Side side) {
   using G = Geometry<BM, BN, WM, WN, NP, STAGES>;
   constexpr int NW = G::NW, TM = G::TM, TN = G::TN, NI = G::NI, NJ = G::NJ, STAGE_BYTES = G::STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  int nwg = (int)gridDim.x;
+  if constexpr (Side::kEnabled) {
+    nwg = g.ntiles * g.splits * g.batch;
+    if ((int)blockIdx.x >= nwg) {
+      side((int)blockIdx.x - nwg, (int)gridDim.x - nwg, smem);
+      return;
+    }
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // Workgroups b and b + 8 share an XCD (one private L2): the remap hands each XCD a contiguous range of
   // (product, K split, tile) triples with the tile index fastest, so neighbours in the range share operand rows.
-  const int u = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int u = xcd_remap((int)blockIdx.x, nwg);
   const int z = u / (g.ntiles * g.splits);
   const int split = (u / g.ntiles) % g.splits;
   const int t = u % g.ntiles;
@@ -455,12 +474,15 @@ struct EpiAffine {
 };
 
 // Largest dynamic LDS size is set once per instantiation (sizes above 64 KiB need the attribute).
-template <int BM, int BN, int WM, int WN, int NP, bool UPPER, int STAGES, class Epi>
-int launch(Args<NP> g, const Epi& epi, int ntiles, int splits, int batch, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int NP, bool UPPER, int STAGES, class Epi, class Side = NoSide>
+int launch(Args<NP> g, const Epi& epi, int ntiles, int splits, int batch, hipStream_t st, const Side& side = Side{},
+           int side_wgs = 0) {
   using G = Geometry<BM, BN, WM, WN, NP, STAGES>;
-  auto kern = gemm_nt_kernel<BM, BN, WM, WN, NP, UPPER, STAGES, Epi>;
+  auto kern = gemm_nt_kernel<BM, BN, WM, WN, NP, UPPER, STAGES, Epi, Side>;
   g.ntiles = ntiles;
   g.splits = splits;
+  g.batch = batch;
+  if (side_wgs < 0 || (side_wgs > 0 && !Side::kEnabled)) return (int)hipErrorInvalidValue;
   if (ntiles <= 0 || splits <= 0 || batch <= 0 || batch > MAXB || g.ksteps <= 0 ||
       (long long)(splits - 1) * g.ksteps_per_split >= g.ksteps || g.M <= 0 || g.N <= 0)
     return (int)hipErrorInvalidValue;
@@ -474,7 +496,7 @@ int launch(Args<NP> g, const Epi& epi, int ntiles, int splits, int batch, hipStr
     if (e != hipSuccess) return (int)e;
     configured[dev] = true;
   }
-  kern<<<dim3(ntiles * splits * batch), G::NT, G::LDS_BYTES, st>>>(g, epi);
+  kern<<<dim3(ntiles * splits * batch + side_wgs), G::NT, G::LDS_BYTES, st>>>(g, epi, side);
   return last_launch_status();
 }
 

@@ -24,6 +24,9 @@
 
 #include "bf16_gemm.h"
 #include "hip_common.h"
+#include "ns_scal.h"
+
+using namespace evox::nsk;
 
 namespace {
 
@@ -215,26 +218,6 @@ int gemm(int in_dtype, int transA, int transB, int64_t M, int64_t N, int64_t K, 
 // ---------------------------------------------------------------------------------------
 // Newton–Schulz helper kernels
 // ---------------------------------------------------------------------------------------
-// scal: float[kScalFloats].  [13] scale s, [14] residual, [15] 1 if the guarded outputs were
-// replaced; from [16] on, rows of 256 per-block partial results (no atomics: a thousand waves
-// adding into one address serialise for tens of µs, while every later kernel can re-reduce
-// 256 partials in its prologue for nothing):
-//   rows 0..7 ‖w_j‖² of the power steps, row 8 max row-abs-sum, row 9 Σ diag, row 10 Σ (T−I)²
-constexpr int kMaxPow = 8, kPartRow = 256, kRowInf = 8, kRowDiag = 9, kRowRes = 10;
-constexpr int kScalFloats = 16 + 11 * kPartRow;
-__device__ __forceinline__ float* part_row(float* scal, int k) { return scal + 16 + k * kPartRow; }
-__device__ __forceinline__ const float* part_row(const float* scal, int k) { return scal + 16 + k * kPartRow; }
-
-// every thread of a 256-thread block receives the sum / max of `count` (≤ 256) partials
-__device__ __forceinline__ float block_reduce(const float* parts, int count, bool take_max, float* red) {
-  float v = (int)threadIdx.x < count ? parts[threadIdx.x] : 0.f;
-  v = take_max ? evox::wave_max(v) : evox::wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return take_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
-}
-
 // one wave per row: w = C·(v/‖v‖); the first step also collects ‖C‖∞ and the trace
 __global__ __launch_bounds__(256) void ns_matvec_kernel(const float* __restrict__ C, int n,
                                                         const float* __restrict__ vin, float* __restrict__ vout,
@@ -282,8 +265,6 @@ __global__ __launch_bounds__(256) void ns_matvec_kernel(const float* __restrict_
   }
 }
 
-// 1 + e/2 + 3e²/8 + 5e³/16 + 35e⁴/128 with e = I − M, in powers of M
-constexpr float kP4c0 = 315.f / 128.f, kP4c1 = -420.f / 128.f, kP4c2 = 378.f / 128.f, kP4c3 = -180.f / 128.f, kP4c4 = 35.f / 128.f;
 
 // Y0 = C/s, T = 1.5 I − 0.5 Y0; block 0 also stores s and the normalised power vector.
 // With Q != nullptr (degree-4 first step) T = c0 I + c1 Y0 and Q = c2 I + c3 Y0 instead: the two linear parts
@@ -581,10 +562,6 @@ __global__ __launch_bounds__(256) void ns_scale_planes_kernel(const float* __res
 
 // Residual of a finished factorisation without forming Z Y: |(Z (S v) - v)| / |v| for a fixed pseudo-random probe v.
 // For E = Z S - I and a random direction, E|E v|^2 = |E|_F^2 / n, the quantity the T-based bound measures.
-__device__ __forceinline__ float probe_v(int i) {
-  const uint32_t h = (uint32_t)i * 2654435761u + 0x9E3779B9u;
-  return (float)((h >> 9) & 0xFFFFu) * (1.f / 32768.f) - 1.f;
-}
 
 // one wave per row: y = A x, or with x == nullptr y = A probe
 __global__ __launch_bounds__(256) void ns_probe_mv_kernel(const float* __restrict__ A, int n, const float* __restrict__ x,

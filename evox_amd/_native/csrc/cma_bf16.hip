@@ -391,7 +391,7 @@ EVOX_API int evox_hip_cma_gather_t(const float* pop, int64_t ldpop, const int64_
   gather_t_kernel<<<dim3((n + 63) / 64, rb), 256, 0, st>>>(pop, ldpop, order, mean, rowscale, sigma, (uint16_t*)yt, ldy,
                                                           colsum, mu, n, lam);
   int e = last_launch_status();
-  if (e) return e;
+  if (e || step == nullptr) return e;              // step == nullptr: the caller adds the partial sums up itself
   colsum_reduce_kernel<<<(n + 63) / 64, 256, 0, st>>>(colsum, rb, n, step);
   return last_launch_status();
 }

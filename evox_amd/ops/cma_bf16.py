@@ -68,7 +68,7 @@ class Workspace:
         self._prefetch = None            # (key tensor, rows, row_offset, buffer, event)
         self._side = None
         self.Yt = torch.zeros((n, self.ldmu), dtype=torch.bfloat16, device=device)
-        self.rb = max(1, min(96, (mu + 63) // 64))          # row tiles of the gather that run as separate workgroups
+        self.rb = max(1, min(40, (mu + 63) // 64))          # row-tile groups of the gather that run as separate workgroups (their partial sums are added up later)
         self.colsum = torch.empty((self.rb, n), dtype=torch.float32, device=device)
         self.cov_splits = int(hip().evox_hip_bf16_cov_splits(n, mu)) if (n % 4 == 0) else 0
         self.cov_ws = torch.empty((max(self.cov_splits, 1), n, n), dtype=torch.float32, device=device) if self.cov_splits else None

@@ -11,6 +11,7 @@ factorisation driver, how many iterations) stay with ``ops.cma.NewtonSchulzSqrt.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 import torch
@@ -46,7 +47,13 @@ class _Tell(ctypes.Structure):
                 ("sharded", c_int), ("gram", c_void_p), ("poison", c_void_p), ("gram_packed", c_int)]
 
 
+class _Fast(ctypes.Structure):
+    _fields_ = [("key", c_void_p), ("z_next", c_void_p), ("keys_next", c_void_p), ("count_in", c_void_p),
+                ("count_next", c_void_p), ("row_offset", c_int64), ("rows", c_int), ("wide", c_int)]
+
+
 _native.register_hip_api({
+    "evox_hip_cma_tell_fast": (I, [P, P, P]),
     "evox_hip_rank_sort_scratch": (c_int64, [I]),
     "evox_hip_cma_ask": (I, [P, P]),
     "evox_hip_event_create": (c_void_p, []),
@@ -135,7 +142,11 @@ class Generation:
             t.planes, t.ns_f32 = st["planes"].data_ptr(), st["f32"].data_ptr()
             t.vec4, t.scal, t.scal2 = self.vec4.data_ptr(), self.scal.data_ptr(), self.scal2.data_ptr()
         self._lib = None
-        self._ahead = None               # (key tensor of the next ask, its split, index of the buffer with its draws)
+        self._fast = _Fast()
+        self.fast_calls = 0              # tells served by the folded launch sequence (``csrc/cma_fast.hip``)
+        # (key tensor of the next ask, its split, index of the buffer with its draws, row window, made on the side
+        # stream?, generation counter of the next ask | None)
+        self._ahead = None
         self._side = None
         self._events = None
 
@@ -156,10 +167,12 @@ class Generation:
         dev = mean.device
         out = torch.empty((rows, ws.n), dtype=torch.float32, device=dev)
         ahead, self._ahead = self._ahead, None
+        count_ahead = None
         if ahead is not None and ahead[0] is key and ahead[3] == (rows, row_offset):
             keys_out, zi = ahead[1], ahead[2]
             a.split = a.draw = 0
             a.wait_side = int(ahead[4])
+            count_ahead = ahead[5] if len(ahead) > 5 else None
         else:
             keys_out, zi = torch.empty((2, 2), dtype=torch.int32, device=dev), ws._z_next
             a.split = a.draw = 1
@@ -169,7 +182,10 @@ class Generation:
         a.mean, a.sigma, a.x = mean.data_ptr(), sigma.data_ptr(), out.data_ptr()
         a.rows, a.row_offset = rows, row_offset
         count_out = None
-        if count is not None:
+        if count is not None and count_ahead is not None:
+            count_out = count_ahead              # the tell that drew ahead advanced the counter as well
+            a.count_in = a.count_out = None
+        elif count is not None:
             count_out = torch.empty((), dtype=torch.float32, device=dev)
             a.count_in, a.count_out = count.data_ptr(), count_out.data_ptr()
         else:
@@ -188,6 +204,14 @@ class Generation:
             self._ahead = (next_key, keys_next, zi ^ 1, (rows, row_offset), True)
         check(hip().evox_hip_cma_ask(ctypes.addressof(a), stream_of(mean)), "cma_ask")
         return out, next_key, count_out
+
+    def _use_fast(self, reduced, factor, plan, n: int) -> bool:
+        """The folded launch sequence applies to a single-process generation whose factorisation is ONE fifth-order step
+        of the symmetric two-plane driver with the estimate scaling, from the third call on (the scale is the estimate
+        the previous call left in its record)."""
+        return (reduced is None and bool(factor) and plan is not None and bool(plan["symmetric"]) and plan["used"] == 1
+                and not plan["use_safe"] and plan["calls"] >= 2 and self.ws.ns_planes == 2 and n % 4 == 0
+                and os.environ.get("EVOX_AMD_CMA_FAST", "1") != "0")
 
     def draw_ahead(self, key, rows: int, row_offset: int) -> None:
         """Split ``key`` and draw the Gaussian numbers of the generation that the next ``ask(key, ...)`` will sample —
@@ -260,7 +284,23 @@ class Generation:
                 t.b16_o = None
         else:
             slot = None
-        check(hip().evox_hip_cma_tell(ctypes.addressof(t), stream_of(pop)), "cma_tell")
+        if self._use_fast(reduced, factor, plan, n):
+            f = self._fast
+            f.wide = int(os.environ.get("EVOX_AMD_CMA_WIDE", "1") == "1")
+            f.key = None
+            if not torch.cuda.is_current_stream_capturing() and os.environ.get("EVOX_AMD_CMA_DRAW_AHEAD", "1") != "0":
+                # the next generation's draws and key split ride along with the factorisation's products
+                zi = ws._z_next ^ 1
+                keys_next = torch.empty((2, 2), dtype=torch.int32, device=dev)
+                count_next = torch.empty((), dtype=torch.float32, device=dev)
+                f.key, f.z_next, f.keys_next = state.key.data_ptr(), ws._Z[zi].data_ptr(), keys_next.data_ptr()
+                f.count_in, f.count_next = state.count_iter_dev.data_ptr(), count_next.data_ptr()
+                f.row_offset, f.rows = 0, ws.lam
+                self._ahead = (state.key, keys_next, zi, (ws.lam, 0), False, count_next)
+            self.fast_calls += 1
+            check(hip().evox_hip_cma_tell_fast(ctypes.addressof(t), ctypes.addressof(f), stream_of(pop)), "cma_tell_fast")
+        else:
+            check(hip().evox_hip_cma_tell(ctypes.addressof(t), stream_of(pop)), "cma_tell")
         if slot is not None:
             self.ns.adopt(rec_o, slot)
         sigma = scalars[0]

@@ -243,7 +243,7 @@ def test_pop_monitor_history_under_graph_replay(cuda, mode):
 
     def run(graph):
         lb, ub = -torch.ones(16, device=cuda) * 5, torch.ones(16, device=cuda) * 5
-        mon = PopMonitor()
+        mon = PopMonitor(fitness_name="local_best_fitness")
         wf = workflows.StdWorkflow(algorithms.PSO(lb=lb, ub=ub, pop_size=128), problems.numerical.Rastrigin(), monitors=[mon],
                                    graph_step=graph, graph_mode=mode)
         state = wf.init(ex.PRNGKey(4))
@@ -1291,6 +1291,8 @@ def test_cmaes_native_generation_equals_op_by_op(cuda, decomposition, monkeypatc
     import evox_amd as ex
     from evox_amd import algorithms, problems, workflows
 
+    monkeypatch.setenv("EVOX_AMD_CMA_FAST", "0")       # the launch chain; the folded sequence has a test of its own
+
     def run(native):
         monkeypatch.setenv("EVOX_AMD_CMA_NATIVE", "1" if native else "0")
         algo = algorithms.CMAES(torch.full((96,), 2.0, device=cuda), 1.0, pop_size=320, decomposition=decomposition,
@@ -1310,6 +1312,57 @@ def test_cmaes_native_generation_equals_op_by_op(cuda, decomposition, monkeypatc
         assert a.ns_iters == b.ns_iters and a.ns_calls == b.ns_calls == 25
         assert torch.equal(a.ns_vec, b.ns_vec) and torch.equal(a.ns_res1, b.ns_res1)
         assert algo_a._ns.symmetric_calls == algo_b._ns.symmetric_calls > 0
+
+
+@pytest.mark.parametrize("n,lam,wide", [(256, 1024, "0"), (1000, 4000, "0"), (1000, 4000, "1"), (132, 300, "0")])
+def test_cmaes_folded_tell_matches_launch_chain(cuda, n, lam, wide, monkeypatch):
+    """The folded tell (``csrc/cma_fast.hip``: helper jobs riding along with the products, scale from the previous call's
+    estimate, next generation drawn ahead) against the launch chain on the SAME state and fitness: the O(n) quantities and
+    the covariance agree to rounding, both factorisations satisfy S S = C' and Z S = I in fp64, and the ask that uses the
+    draws and the key split made ahead returns the population of an ask that draws on the spot, bit for bit."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    monkeypatch.setenv("EVOX_AMD_CMA_WIDE", wide)
+    algo = algorithms.CMAES(torch.full((n,), 2.0, device=cuda), 1.0, pop_size=lam, decomposition="newton_schulz", precision="bf16")
+    prob = problems.numerical.Ackley()
+    wf = workflows.StdWorkflow(algo, prob)
+    s = wf.init(ex.PRNGKey(5))
+    for _ in range(30):                       # the iteration count settles at one fifth-order step within two dozen calls
+        s = wf.step(s)
+    gen = next(iter(algo._generations.values()))
+    assert gen.fast_calls >= 5, gen.fast_calls
+    a = s.get_child_state("algorithm")
+    pop, a2 = algo.ask(a)
+    fit, _ = prob.evaluate(None, pop)
+    monkeypatch.setenv("EVOX_AMD_CMA_FAST", "0")
+    slow = algo.tell(a2, fit)
+    monkeypatch.setenv("EVOX_AMD_CMA_FAST", "1")
+    before = gen.fast_calls
+    fast = algo.tell(a2, fit)
+    assert gen.fast_calls == before + 1
+    torch.cuda.synchronize()
+    for k in ("mean", "ps", "pc", "sigma"):
+        assert torch.allclose(getattr(fast, k), getattr(slow, k), rtol=2e-5, atol=1e-6), k
+    assert torch.allclose(fast.C, slow.C, rtol=1e-5, atol=1e-7) and torch.equal(fast.C, fast.C.T)
+    eye = torch.eye(n, device=cuda, dtype=torch.float64)
+    C64 = fast.C.double()
+    for st in (fast, slow):
+        S, Z = st.B.double(), st.invsqrtC.double()
+        assert float((S @ S - C64).norm() / C64.norm()) < 5e-4
+        assert float((Z @ S - eye).norm() / n ** 0.5) < 5e-4
+        assert torch.equal(st.B, st.B.T)
+    assert torch.allclose(fast.B, slow.B, rtol=0, atol=2e-3 * float(slow.B.abs().max()))
+    assert torch.allclose(fast.ns_vec, slow.ns_vec, atol=1e-4)
+    rf, rs = fast.ns_res1.tolist(), slow.ns_res1.tolist()
+    assert rf[6] == 0.0 and rf[5] < 5e-4 and abs(rf[4] / rs[4] - 1) < 0.05            # residual, scale estimate
+    assert rf[0] == pytest.approx(rs[0], rel=0.05) and rf[1] == pytest.approx(rs[1], rel=0.05)
+    # the next ask: draws, key split and counter made ahead against made on the spot
+    assert gen._ahead is not None and gen._ahead[0] is fast.key
+    p1, n1 = algo.ask(fast)
+    gen._ahead = None
+    p2, n2 = algo.ask(fast)
+    assert torch.equal(p1, p2) and torch.equal(n1.key, n2.key) and torch.equal(n1.count_iter_dev, n2.count_iter_dev)
 
 
 def test_newton_schulz_fifth_order_step_alone(cuda):
