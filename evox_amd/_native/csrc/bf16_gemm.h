@@ -378,6 +378,7 @@ struct EpiAffine {
     const float* cin[MAXB];       // optional addend, pitch ldf
     const float* prev[MAXB];      // optional replacement under keep, pitch ldf
     const float* scale[MAXB];     // optional device scalar
+    const float* beta_dev;        // optional device scalar multiplied into beta
     float alpha, beta, gamma;
   };
   Out o[2];
@@ -387,13 +388,17 @@ struct EpiAffine {
   const float* keep;
   struct State {
     float sc[2];
+    float bt[2];
     bool skip;
   };
   __device__ __forceinline__ State init(int z) const {
-    State st{{1.f, 1.f}, false};
+    State st{{1.f, 1.f}, {0.f, 0.f}, false};
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (q < nout && o[q].scale[z] != nullptr) st.sc[q] = o[q].scale[z][0];
+    for (int q = 0; q < 2; ++q) {
+      if (q >= nout) break;
+      if (o[q].scale[z] != nullptr) st.sc[q] = o[q].scale[z][0];
+      st.bt[q] = o[q].beta_dev != nullptr ? o[q].beta * o[q].beta_dev[0] : o[q].beta;
+    }
     if (keep != nullptr) st.skip = keep[0] != 0.f;
     return st;
   }
@@ -425,7 +430,7 @@ struct EpiAffine {
             y = w.prev[z][(long long)m * ldf + n + r];
           } else {
             y = w.alpha * v[r];
-            if (w.cin[z] != nullptr) y = fmaf(w.beta, w.cin[z][(long long)m * ldf + n + r], y);
+            if (w.cin[z] != nullptr) y = fmaf(st.bt[q], w.cin[z][(long long)m * ldf + n + r], y);
             if (m == n + r) y += w.gamma;
             y *= st.sc[q];
           }

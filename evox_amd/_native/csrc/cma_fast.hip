@@ -9,10 +9,10 @@
 //   rank sort -> gather/transpose
 //   -> rank-mu slabs            + side: mean shift from the gather's partial sums, whitening product C^{-1/2} step
 //   -> covariance reduction     prologue: path / step-size update (every workgroup recomputes the n-vectors it needs);
-//                               epilogue: the scaled covariance as bf16 split planes and the two linear parts of the
-//                               fifth-order polynomial — the factorisation's scaling pass
+//                               epilogue: the scaled covariance as bf16 split planes — the factorisation's scaling pass
+//                               (the linear parts of the fifth-order polynomial are formed from C' in the products' epilogues)
 //   -> A2 = Y0 Y0               + side: power-iteration product C' v (next call's scale), draws of the next generation
-//   -> p  = T0 + A2 q           + side: draws
+//   -> p  = (c0 I + c1 Y0) + A2 q + side: draws
 //   -> S  = sqrt(s) Y0 p        + side: C'^{-1/2} probe, C'^{-1/2} v2 (condition estimate), draws
 //   -> residual |S u - probe|   -> verdict, guard, control record, next call's scale, key split
 //
@@ -27,7 +27,7 @@
 #include "philox.h"
 
 extern "C" {
-int evox_hip_rank_sort_sliced(const float* keys, int n, int64_t* order, int64_t* rank_out, int* scratch, void* stream);
+int evox_hip_rank_sort_scalar(const float* keys, int n, int64_t* order, int64_t* rank_out, void* stream);
 int evox_hip_cma_gather_t(const float* pop, int64_t ldpop, const int64_t* order, const float* mean, const float* rowscale,
                           const float* sigma, void* yt, int64_t ldy, float* colsum, int rb, float* step, int mu, int n,
                           int lam, void* stream);
@@ -256,8 +256,7 @@ struct CovFast {
   float *C_o, *mean_o, *ps_o, *pc_o, *scalars;
   uint16_t* y0;             // two bf16 planes of C' / s, pitch ldp, plane stride `plane`
   long long ldp, plane;
-  float *T0, *Q0;           // c0 I + c1 Y0, c2 I + c3 Y0 (fp32, n x n)
-  float* scal;              // [11] 1/sqrt(s), [12] sqrt(s), [13] s
+  float* scal;              // [8] 1/s, [11] 1/sqrt(s), [12] sqrt(s), [13] s
   int n, tiles;
 };
 
@@ -302,11 +301,12 @@ __global__ __launch_bounds__(256) void cov_fast_kernel(CovFast a) {
       a.scal[13] = s;
       a.scal[12] = sqrtf(s);
       a.scal[11] = 1.f / sqrtf(s);
+      a.scal[8] = is;
     }
   }
   auto pc_new = [&](int c) { return c < n ? (1.f - a.k.cc) * a.pc[c] + cb * a.step[c] : 0.f; };
 
-  // ---- C' = alpha C + c1 pc' pc'^T + cmu sum of slabs on the upper 64 x 64 tiles, mirrored; Y0, T0, Q0 alongside ----
+  // ---- C' = alpha C + c1 pc' pc'^T + cmu sum of slabs on the upper 64 x 64 tiles, mirrored; the planes of Y0 = C' / s alongside ----
   int i = 0, rem = blockIdx.x;
   while (rem >= a.tiles - i) {
     rem -= a.tiles - i;
@@ -324,8 +324,6 @@ __global__ __launch_bounds__(256) void cov_fast_kernel(CovFast a) {
     const long long e = (long long)r * n + c;
     const float y = v * is;
     a.C_o[e] = v;
-    a.T0[e] = (r == c ? kP4c0 : 0.f) + kP4c1 * y;
-    a.Q0[e] = (r == c ? kP4c2 : 0.f) + kP4c3 * y;
     const uint32_t b0 = f32_to_bf16_bits(y);
     const uint32_t b1 = f32_to_bf16_bits(y - bf16_bits_to_f32(b0));
     a.y0[(long long)r * a.ldp + c] = (uint16_t)b0;
@@ -364,8 +362,6 @@ __global__ __launch_bounds__(256) void cov_fast_kernel(CovFast a) {
           b1[k] = f32_to_bf16_bits(y[k] - bf16_bits_to_f32(b0[k]));
         }
         *reinterpret_cast<float4*>(a.C_o + e) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(a.T0 + e) = make_float4(kP4c1 * y[0], kP4c1 * y[1], kP4c1 * y[2], kP4c1 * y[3]);
-        *reinterpret_cast<float4*>(a.Q0 + e) = make_float4(kP4c3 * y[0], kP4c3 * y[1], kP4c3 * y[2], kP4c3 * y[3]);
         uint16_t* pl = a.y0 + (long long)r * a.ldp + cc;
         *reinterpret_cast<uint2*>(pl) = make_uint2(b0[0] | (b0[1] << 16), b0[2] | (b0[3] << 16));
         *reinterpret_cast<uint2*>(pl + a.plane) = make_uint2(b1[0] | (b1[1] << 16), b1[2] | (b1[3] << 16));
@@ -549,7 +545,7 @@ template <int WM, int WN>
 static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   const int n = t->n;
   const long long nn = (long long)n * n;
-  int e = evox_hip_rank_sort_sliced(t->fitness, t->lam, t->order, nullptr, t->sort_scratch, st);
+  int e = evox_hip_rank_sort_scalar(t->fitness, t->lam, t->order, nullptr, st);
   if (e) return e;
   e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
                             nullptr, t->mu, n, t->lam, st);
@@ -595,7 +591,8 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   const long long sm = plane * 2;
   uint16_t* planes = (uint16_t*)t->planes;
   uint16_t *Y0 = planes, *A2 = planes + sm, *Qp = planes + 2 * sm, *Pp = planes + 3 * sm;
-  float *T0 = t->ns_f32, *Q0 = t->ns_f32 + nn, *Tf = t->ns_f32 + 2 * nn;
+  float* Tf = t->ns_f32 + 2 * nn;
+  const float* inv_s = t->scal + 8;          // 1 / s, written by the covariance kernel
   const int T64 = (n + 63) / 64;
   {
     CovFast a{};
@@ -605,7 +602,7 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
     a.sigma = t->sigma; a.iter = t->iter_dev; a.prev_rec = t->prev_rec;
     a.k = PathConst{t->consts[0], t->consts[1], t->consts[2], t->consts[3], t->consts[4], t->consts[5], t->consts[6], t->consts[7]};
     a.C_o = t->C_o; a.mean_o = t->mean_o; a.ps_o = t->ps_o; a.pc_o = t->pc_o; a.scalars = t->scalars_o;
-    a.y0 = Y0; a.ldp = t->ldn; a.plane = plane; a.T0 = T0; a.Q0 = Q0; a.scal = t->scal;
+    a.y0 = Y0; a.ldp = t->ldn; a.plane = plane; a.scal = t->scal;
     a.n = n; a.tiles = T64;
     cov_fast_kernel<8><<<upper_tiles(T64), 256, 0, st>>>(a);
     e = last_launch_status();
@@ -634,14 +631,16 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   float* w2 = t->vec4 + 3 * n;          // C'^{-1/2} v2
   float* u = Tf;                        // C'^{-1/2} probe
   {
-    // A2 = Y0 Y0 and q = Q0 + c4 A2 from one product
+    // A2 = Y0 Y0 and q = (c2 I + c3 Y0) + c4 A2 from one product; Y0 = C' / s is read as the fp32 covariance
     auto epi = affine<2>(n, t->ldn);
     epi.nout = 2;
     epi.o[0].alpha = 1.f;
     for (int p = 0; p < 2; ++p) epi.o[0].pl[0][p] = A2 + p * plane;
     epi.o[1].alpha = kP4c4;
-    epi.o[1].beta = 1.f;
-    epi.o[1].cin[0] = Q0;
+    epi.o[1].beta = kP4c3;
+    epi.o[1].beta_dev = inv_s;
+    epi.o[1].gamma = kP4c2;
+    epi.o[1].cin[0] = t->C_o;
     for (int p = 0; p < 2; ++p) epi.o[1].pl[0][p] = Qp + p * plane;
     FastSide side{};
     side.n = n;
@@ -651,16 +650,17 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
     if (e) return e;
   }
   {
-    // p = T0 + A2 q  (= C'^{-1/2} sqrt(s)): planes for the last product, fp32 scaled by 1/sqrt(s) as the output
+    // p = (c0 I + c1 Y0) + A2 q  (= C'^{-1/2} sqrt(s)): planes for the last product, fp32 scaled by 1/sqrt(s) as the output
     auto epi = affine<2>(n, t->ldn);
     epi.nout = 2;
-    epi.o[0].alpha = 1.f;
-    epi.o[0].beta = 1.f;
-    epi.o[0].cin[0] = T0;
+    for (int o = 0; o < 2; ++o) {
+      epi.o[o].alpha = 1.f;
+      epi.o[o].beta = kP4c1;
+      epi.o[o].beta_dev = inv_s;
+      epi.o[o].gamma = kP4c0;
+      epi.o[o].cin[0] = t->C_o;
+    }
     for (int p = 0; p < 2; ++p) epi.o[0].pl[0][p] = Pp + p * plane;
-    epi.o[1].alpha = 1.f;
-    epi.o[1].beta = 1.f;
-    epi.o[1].cin[0] = T0;
     epi.o[1].f32[0] = t->inv_o;
     epi.o[1].scale[0] = t->scal + 11;
     FastSide side{};

@@ -190,6 +190,273 @@ EVOX_API int evox_hip_rank_sort_values(const float* keys, int n, int64_t* order,
   return evox::last_launch_status();
 }
 
+// One-launch counting rank with the compared keys held in SCALAR registers.
+//
+// The kernels above stage the keys in LDS and read them back as broadcasts; every wave-instruction of such a read
+// occupies the LDS pipeline as long as a full-width one, which makes LDS a co-bottleneck of the count.  Here a
+// wavefront keeps its 64 row keys in a vector register (one per lane) and walks over its share of the n keys with a
+// wave-uniform index: the loads are scalar loads (eight or sixteen consecutive keys per instruction, served by the
+// scalar data cache), and a compare takes its second operand straight from a scalar register — two vector
+// instructions per 64 compares and nothing else.  The compares are done on the floats themselves: -0 = +0 as in the
+// integer image used above; a NaN row key (all of its compares are false) gets a second pass that counts every
+// ordered key plus the NaN keys in front of it, taken only by wavefronts that hold such a row.
+// Sixteen wavefronts split the key range, the 64 rows of a workgroup are finished in LDS and scattered directly.
+namespace {
+
+constexpr int kSB = 16;          // keys per scalar load
+
+template <bool TIE_LE>
+__device__ __forceinline__ int count_block(const float (&kj)[kSB], float ki) {
+  int cnt = 0;
+#pragma unroll
+  for (int u = 0; u < kSB; ++u) cnt += TIE_LE ? (int)(kj[u] <= ki) : (int)(kj[u] < ki);
+  return cnt;
+}
+
+__device__ __forceinline__ void load_block(float (&kj)[kSB], const float* __restrict__ p) {
+#pragma unroll
+  for (int u = 0; u < kSB; ++u) kj[u] = p[u];
+}
+
+// keys[a, b) that precede ki (a, b wave-uniform).  Blocks of 16 keys (one scalar load each) are double-buffered: the
+// load of the next block is in flight during the compares of the current one, so the scalar-cache latency is covered by
+// a wavefront's own work and not only by its neighbours on the SIMD.  (The compiler hoists one further load; with 16-key
+// blocks three live blocks still fit the scalar register file.)
+template <bool TIE_LE>
+__device__ __forceinline__ int count_uniform(const float* __restrict__ keys, int a, int b, float ki) {
+  int cnt = 0;
+  int j = a;
+  if (j + kSB <= b) {
+    float bufA[kSB], bufB[kSB];
+    load_block(bufA, keys + j);
+    j += kSB;
+    while (j + 2 * kSB <= b) {
+      load_block(bufB, keys + j);
+      cnt += count_block<TIE_LE>(bufA, ki);
+      load_block(bufA, keys + j + kSB);
+      cnt += count_block<TIE_LE>(bufB, ki);
+      j += 2 * kSB;
+    }
+    if (j + kSB <= b) {
+      load_block(bufB, keys + j);
+      cnt += count_block<TIE_LE>(bufA, ki);
+      cnt += count_block<TIE_LE>(bufB, ki);
+      j += kSB;
+    } else {
+      cnt += count_block<TIE_LE>(bufA, ki);
+    }
+  }
+  for (; j < b; ++j) {
+    const float kj = keys[j];
+    cnt += TIE_LE ? (int)(kj <= ki) : (int)(kj < ki);
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(kThreads) void rank_sort_scalar_kernel(const float* __restrict__ keys, int n,
+                                                                    int64_t* __restrict__ order,
+                                                                    int64_t* __restrict__ rank_out) {
+  __shared__ int partial[kWaves][kRows];
+  const int il = threadIdx.x & 63;
+  const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = blockIdx.x * kRows;
+  const int i = i0 + il;
+  const float ki = keys[min(i, n - 1)];
+  const int per = ((n + kWaves - 1) / kWaves + 15) & ~15;
+  const int ja = min(n, s * per), jb = min(n, ja + per);
+  // keys in front of the workgroup's rows win ties, keys behind them do not, keys among them by their index
+  const int m0 = min(max(i0, ja), jb), m1 = min(max(i0 + kRows, ja), jb);
+  int cnt = count_uniform<true>(keys, ja, m0, ki);
+  if (m0 < m1) {
+    // the workgroup's own rows (at most 64 keys, in one wavefront's share): one vector load, then lane by lane through
+    // a scalar register — a scalar load per key would expose its latency 64 times on the workgroup's critical path
+    const int kv = __float_as_int(keys[min(m0 + il, n - 1)]);
+#pragma unroll 8
+    for (int u = 0; u < m1 - m0; ++u) {
+      const float kj = __int_as_float(__builtin_amdgcn_readlane(kv, u));
+      cnt += (int)(kj < ki) + (int)(kj == ki && m0 + u < i);
+    }
+  }
+  cnt += count_uniform<false>(keys, m1, jb, ki);
+  const bool nan_i = ki != ki;
+  if (__ballot(nan_i) != 0ull) {
+    int c2 = 0;
+    for (int j = ja; j < jb; ++j) {
+      const float kj = keys[j];
+      c2 += (kj == kj) ? 1 : (int)(j < i);
+    }
+    if (nan_i) cnt = c2;
+  }
+  partial[s][il] = cnt;
+  __syncthreads();
+  if (s == 0 && i < n) {
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) r += partial[w][il];
+    order[r] = i;
+    if (rank_out) rank_out[i] = r;
+  }
+}
+
+}  // namespace
+
+// order[r] = index of the r-th smallest key (stable, NaN last, -0 = +0); rank_out (optional) = inverse permutation.
+EVOX_API int evox_hip_rank_sort_scalar(const float* keys, int n, int64_t* order, int64_t* rank_out, void* stream) {
+  if (n <= 0) return 0;
+  rank_sort_scalar_kernel<<<(n + kRows - 1) / kRows, kThreads, 0, (hipStream_t)stream>>>(keys, n, order, rank_out);
+  return evox::last_launch_status();
+}
+
+// One-launch rank by splitters: n log n instead of n^2 compares.
+//
+// Counting every key against every other is 10^8 compare-adds at n = 10^4: 14-17 us however the keys are fed to the
+// compares (LDS broadcasts or scalar registers above).  Here every workgroup first partitions ALL keys — redundantly, in
+// LDS, it costs a few thousand cycles — into 257 buckets bounded by 256 splitters (a sorted regular sample), with the
+// keys of every bucket listed together; the rank of one of its own 64 rows is then the number of keys in the buckets in
+// front plus a count over the members of the row's own bucket only (about n / 257 of them).  Equal keys always share a
+// bucket, so ties go by index exactly as in the stable sort; the result does not depend on the order in which the
+// members of a bucket were listed.  A key vector with few distinct values degenerates to the plain count.
+// Measured at n = 10^4: 21 us — the partition's dependent LDS round trips (eight per binary search) cost more than the
+// compares they save, so the scalar-register count above (17 us) stays the default; this form is kept selectable.
+namespace {
+
+constexpr int kBkSplit = 256;
+
+__device__ __forceinline__ int bucket_of(const uint32_t* spl, uint32_t k) {
+  int c = 0;
+#pragma unroll
+  for (int step = kBkSplit / 2; step >= 1; step >>= 1)
+    if (spl[c + step - 1] < k) c += step;
+  if (c == kBkSplit - 1 && spl[kBkSplit - 1] < k) c = kBkSplit;
+  return c;                                      // number of splitters below k
+}
+
+__global__ __launch_bounds__(kThreads) void rank_sort_bucket_kernel(const float* __restrict__ keys, int n, int npad,
+                                                                    int64_t* __restrict__ order,
+                                                                    int64_t* __restrict__ rank_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bk_smem[];
+  uint32_t* sk = reinterpret_cast<uint32_t*>(bk_smem);            // npad sortable keys
+  uint16_t* members = reinterpret_cast<uint16_t*>(sk + npad);     // npad key indices, bucket by bucket
+  uint32_t* spl = reinterpret_cast<uint32_t*>(members + npad);    // kBkSplit sorted splitters
+  uint32_t* samp = spl + kBkSplit;                                // the sample before it is sorted
+  int* hist = reinterpret_cast<int*>(samp + kBkSplit);            // kBkSplit + 1 bucket sizes
+  int* start = hist + kBkSplit + 4;                               // kBkSplit + 2 bucket starts
+  int* cursor = start + kBkSplit + 4;
+  int* partial = cursor + kBkSplit + 4;                           // kWaves x kRows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  for (int t = tid; t < n; t += kThreads) sk[t] = sortable(keys[t]);
+  if (tid < kBkSplit + 1) { hist[tid] = 0; cursor[tid] = 0; }
+  if (tid < kBkSplit) spl[tid] = 0xFFFFFFFFu;
+  __syncthreads();
+  const int S = min(kBkSplit, n);
+  if (tid < S) samp[tid] = sk[(int)((long long)tid * n / S)];
+  __syncthreads();
+  {
+    // rank of every sample among the samples: four threads per sample, 64 compares each
+    const int t = tid >> 2, q = tid & 3;
+    const uint32_t kt = t < S ? samp[t] : 0u;
+    int c = 0;
+    for (int u = q * (kBkSplit / 4); u < min(S, (q + 1) * (kBkSplit / 4)); ++u) {
+      const uint32_t ku = samp[u];
+      c += (int)(ku < kt) + (int)(ku == kt && u < t);
+    }
+    c += __shfl_xor(c, 1, 64);
+    c += __shfl_xor(c, 2, 64);
+    if (q == 0 && t < S) spl[c] = kt;
+  }
+  __syncthreads();
+  uint16_t bkt[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int t = tid + m * kThreads;
+    if (t < n) {
+      const int b = bucket_of(spl, sk[t]);
+      bkt[m] = (uint16_t)b;
+      atomicAdd(&hist[b], 1);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // exclusive scan of the 257 bucket sizes: five consecutive entries per lane
+    int v[5], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int b = lane * 5 + k;
+      v[k] = b <= kBkSplit ? hist[b] : 0;
+      sum += v[k];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    int run = incl - sum;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int b = lane * 5 + k;
+      if (b <= kBkSplit + 1) start[b] = run;
+      run += v[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int t = tid + m * kThreads;
+    if (t < n) {
+      const int b = bkt[m];
+      members[start[b] + atomicAdd(&cursor[b], 1)] = (uint16_t)t;
+    }
+  }
+  __syncthreads();
+  // the workgroup's own rows: lane = row, the sixteen wavefronts share the members of a row's bucket
+  const int i = blockIdx.x * kRows + lane;
+  const uint32_t ki = i < n ? sk[i] : 0xFFFFFFFEu;
+  const int bi = i < n ? bucket_of(spl, ki) : 0;
+  const int lo = start[bi], hi = i < n ? start[bi + 1] : lo;
+  int cnt = 0;
+  for (int m = lo + wave; m < hi; m += kWaves) {
+    const int j = members[m];
+    const uint32_t kj = sk[j];
+    cnt += (int)(kj < ki) + (int)(kj == ki && j < i);
+  }
+  partial[wave * kRows + lane] = cnt;
+  __syncthreads();
+  if (wave == 0 && i < n) {
+    int r = lo;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) r += partial[w * kRows + lane];
+    order[r] = i;
+    if (rank_out) rank_out[i] = r;
+  }
+}
+
+inline int bucket_lds_bytes(int npad) { return npad * 6 + (2 * kBkSplit + 3 * (kBkSplit + 4) + kWaves * kRows) * 4; }
+
+}  // namespace
+
+// order[r] = index of the r-th smallest key (stable, NaN last, -0 = +0); rank_out (optional) = inverse permutation.
+// n <= 16384.
+EVOX_API int evox_hip_rank_sort_bucket(const float* keys, int n, int64_t* order, int64_t* rank_out, void* stream) {
+  if (n <= 0) return 0;
+  if (n > 16 * kThreads) return (int)hipErrorInvalidValue;
+  const int npad = (n + 7) & ~7;
+  const int lds = bucket_lds_bytes(npad);
+  static bool configured[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16) return (int)hipErrorInvalidDevice;
+  if (!configured[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rank_sort_bucket_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bucket_lds_bytes(16 * kThreads));
+    if (e != hipSuccess) return (int)e;
+    configured[dev] = true;
+  }
+  rank_sort_bucket_kernel<<<(n + kRows - 1) / kRows, kThreads, lds, (hipStream_t)stream>>>(keys, n, npad, order, rank_out);
+  return evox::last_launch_status();
+}
+
 // Partial rank counts of the rows [row_lo, row_lo + rows_n) against all n keys: scratch[s * rows_n + i] for s below the
 // returned number of slices (at most evox_hip_rank_window_slices()); the rank of row i is their sum.  What a process
 // that owns only those rows of a larger population needs: rows_n x n compares instead of a sort of all n keys.

@@ -578,22 +578,38 @@ def test_native_newton_schulz_guard_passes_previous_factors_on(cuda):
     assert torch.equal(s, prev[0]) and torch.equal(zi, prev[1])
 
 
-@pytest.mark.parametrize("n", [1, 7, 64, 65, 1000, 8192, 8193, 10000, 16384])
-def test_rank_sort_kernel_matches_stable_argsort(cuda, n):
+@pytest.mark.parametrize("form", ["bucket", "scalar", "lds"])
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 255, 257, 1000, 8192, 8193, 10000, 16384])
+def test_rank_sort_kernel_matches_stable_argsort(cuda, n, form, monkeypatch):
+    """The rank kernels (by splitters; plain counts with the keys compared out of scalar registers or staged in LDS)
+    against the stable sort: ties, infinities, signed zeros, NaNs (several, in different wavefronts and workgroups),
+    few distinct values, sorted and reversed input."""
     from evox_amd.ops import sort
 
+    monkeypatch.setenv("EVOX_AMD_RANK_SORT", form)
     g = torch.Generator(device="cpu").manual_seed(n)
     keys = torch.randn(n, generator=g)
     keys = (keys * 4).round() / 4 if n > 64 else keys            # many ties: stability is visible
     if n >= 64:
         keys[3], keys[17], keys[40] = float("inf"), float("-inf"), float("nan")
         keys[5], keys[6] = 0.0, -0.0
+    if n >= 1000:
+        keys[41], keys[700], keys[n - 1], keys[n // 2] = float("nan"), float("nan"), float("nan"), float("inf")
     dkeys = keys.to(cuda)
     order, rank = sort.argsort_with_rank(dkeys)
     ref = torch.argsort(keys, stable=True)
     assert torch.equal(order.cpu(), ref)
     assert torch.equal(rank.cpu()[ref], torch.arange(n))
     assert torch.equal(sort.argsort(dkeys).cpu(), ref)
+    if n in (257, 10000):
+        for other in (torch.arange(n, dtype=torch.float32), -torch.arange(n, dtype=torch.float32),
+                      (torch.arange(n) % 3).float(), torch.randn(n, generator=g).exp() * 1e30):
+            assert torch.equal(sort.argsort(other.to(cuda)).cpu(), torch.argsort(other, stable=True))
+    if n in (65, 1000):
+        allnan = torch.full((n,), float("nan"), device=cuda)
+        assert torch.equal(sort.argsort(allnan).cpu(), torch.arange(n))
+        const = torch.full((n,), 2.5, device=cuda)
+        assert torch.equal(sort.argsort(const).cpu(), torch.arange(n))
 
 
 def test_sampling_gemm_with_device_scale_and_bias(cuda):

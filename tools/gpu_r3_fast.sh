@@ -3,7 +3,7 @@
 out=$GRAFT_REPO_ROOT/gpurun_out/r3
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -u -m pytest tests/test_ops_gpu.py -x -q --timeout 120 --timeout-method thread -k "cma or newton" > $out/fast_tests.log 2>&1 || { tail -30 $out/fast_tests.log; exit 1; }
+timeout -k 10 300 python -u -m pytest tests/test_ops_gpu.py -x -q --timeout 120 --timeout-method thread -k "cma or newton or rank_sort" > $out/fast_tests.log 2>&1 || { tail -30 $out/fast_tests.log; exit 1; }
 tail -3 $out/fast_tests.log
 timeout -k 10 200 python bench.py --no-secondary > $out/bench_fast.json 2> $out/bench_fast.err || { tail -20 $out/bench_fast.err; exit 1; }
 cut -c1-330 $out/bench_fast.json
