@@ -166,7 +166,7 @@ def island_shade(args):
     algo = algorithms.SHADE(lb=torch.full((d,), -100.0, device=device), ub=torch.full((d,), 100.0, device=device), pop_size=pop)
     prob = problems.numerical.CEC2022TestSuit.create(1)
     wf = workflows.IslandWorkflow(algo, prob, migrate_every=args.migrate_every, num_migrants=args.migrants,
-                                  graph_step=args.graph)
+                                  graph_step=args.graph, graph_mode="ring")
     state = wf.init(ex.PRNGKey(4).to(device))
     state, dt = _timed(wf, state, args.steps, args.warmup, device)
     _sync(device)

@@ -77,9 +77,9 @@ def rank_sweep(x: torch.Tensor, until: Optional[int] = None, with_info: bool = F
     xf = x.float()
     if m == 2:
         xf = torch.cat([xf, torch.zeros(n, 1, device=dev)], dim=1)
-    order = torch.argsort(xf[:, 2], stable=True)
-    order = order[torch.argsort(xf[order, 1], stable=True)]
-    order = order[torch.argsort(xf[order, 0], stable=True)]
+    from . import sort as _sort
+
+    order = _sort.lexsort_rows(xf)                   # three stable column sorts, last column first (csrc/radix.hip)
     xs = xf[order]
     is_rep = torch.ones(n, dtype=torch.bool, device=dev)
     is_rep[1:] = (xs[1:] != xs[:-1]).any(dim=1)
@@ -150,10 +150,9 @@ def rank_m2_scan(x: torch.Tensor, until: Optional[int] = None, with_info: bool =
     n = x.shape[0]
     dev = x.device
     xf = x.float() + 0.0                                         # -0.0 and 0.0 are one value
-    # one sort on a 64-bit key: the bits of a float, negative values flipped, order like integers
-    bits = xf.contiguous().view(torch.int32)
-    skey = (bits ^ ((bits >> 31) & 0x7FFFFFFF)).to(torch.int64)
-    order = torch.sort(skey[:, 0] * (1 << 32) + (skey[:, 1] + (1 << 31)), stable=True).indices
+    from . import sort as _sort
+
+    order = _sort.lexsort_rows(xf[:, :2])            # stable sort by the second objective, then by the first
     xs = xf[order]
     f1, f2 = xs[:, 0].contiguous(), xs[:, 1].contiguous()
     target = n if until is None else max(1, min(int(until), n))
@@ -203,7 +202,9 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
             return out, (cut, n_before, cut_size)
         return out
     # ascending first objective: a dominator never sits behind the point it dominates
-    order = torch.argsort(x[:, 0].float(), stable=True)
+    from . import sort as _sort
+
+    order = _sort.argsort(x[:, 0].float())
     ld = (n + 15) // 16 * 16
     obj = torch.full((m, ld), float("inf"), dtype=torch.float32, device=dev)          # objective-major, padded columns
     obj[:, :n] = x.float()[order].T
@@ -279,11 +280,13 @@ def crowding(vals: torch.Tensor) -> torch.Tensor:
         for k in range(m):
             check(lib.evox_hip_rank_sort(soa[k].data_ptr(), count, order[k].data_ptr(), rnk[k].data_ptr(), s), "rank_sort")
     else:
-        # fronts beyond the counting sort's range: the library's stable sort per objective, ranks by a scatter
-        ar = torch.arange(count, device=vals.device)
+        # fronts beyond the counting sort's range: the radix sort per objective, order and rank together
         for k in range(m):
-            order[k] = torch.argsort(soa[k], stable=True)
-            rnk[k].scatter_(0, order[k], ar)
+            if _sort.radix_sortable(soa[k]):
+                order[k], rnk[k] = _sort.radix_argsort(soa[k], want_rank=True)
+            else:
+                order[k] = torch.argsort(soa[k], stable=True)
+                rnk[k].scatter_(0, order[k], torch.arange(count, device=vals.device))
     dist = torch.empty(count, dtype=torch.float32, device=vals.device)
     check(lib.evox_hip_crowding(soa.data_ptr(), order.data_ptr(), rnk.data_ptr(), count, m, dist.data_ptr(), s),
           "crowding")

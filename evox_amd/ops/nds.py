@@ -189,7 +189,7 @@ def rank_crowding_select(fit: torch.Tensor, k: int) -> torch.Tensor:
             rank, (cut, n_before, cut_size) = _nds_hip.rank(fit, until=k, with_info=True)
             need = k - n_before
             if 0 < need <= cut_size <= _CROWD_KERNEL_MAX:
-                order = torch.argsort(rank, stable=True)
+                order = _sort.argsort_small_ints(rank, cut + 1)         # front indices: one radix pass per byte
                 head = order[:n_before]
                 members = order[n_before:n_before + cut_size]          # the cut front, in population order
                 dist = _nds_hip.crowding(fit[members])

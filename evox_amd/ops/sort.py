@@ -19,7 +19,66 @@ _native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]),
                           "evox_hip_select_wide_ws": (_native.I64, [I]),
                           "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
+_native.register_hip_api({"evox_hip_radix_ws_words": (_native.I64, [_native.I64]),
+                          "evox_hip_radix_argsort": (I, [P, I, _native.I64, P, I, I, I, P, P, P, P])})
+
 _RANK_SORT_MAX = 16384
+_RADIX_MAX = 1 << 21          # the scatter pass of the radix sort sums a 256 x tiles table per workgroup: tiles <= 512
+
+
+def radix_sortable(keys: torch.Tensor) -> bool:
+    return (keys.is_cuda and keys.dim() == 1 and keys.dtype in (torch.float32, torch.int32)
+            and 0 < keys.shape[0] <= _RADIX_MAX)
+
+
+def radix_argsort(keys: torch.Tensor, perm: torch.Tensor = None, bits=(0, 32), want_rank: bool = False):
+    """Stable ascending argsort of a long 1-D key vector by the hand-written radix sort (``csrc/radix.hip``): fp32 keys
+    (NaN last, -0 = +0; any element stride, e.g. a column of a matrix) or int32 keys.  ``perm`` (int64): the sort
+    permutes this index sequence instead of ``0..n-1`` and gathers the keys through it — the stable sort by a more
+    significant column after a sort by a less significant one (lexicographic and segmented sorts).  ``bits``: the key
+    bits that take part (multiples of 8; for small non-negative integers the low bytes suffice).  Returns ``order``
+    (int64), or ``(order, rank)`` with ``rank[order[r]] = r``."""
+    n = keys.shape[0]
+    dev = keys.device
+    mode = 1 if keys.dtype == torch.float32 else 2
+    if perm is not None:
+        perm = perm.contiguous()
+        if perm.dtype != torch.int64 or perm.shape[0] != n:
+            raise ValueError("perm must be int64 of the keys' length")
+    order = torch.empty(n, dtype=torch.int64, device=dev)
+    rank = torch.empty(n, dtype=torch.int64, device=dev) if want_rank else None
+    ws = torch.empty(int(hip().evox_hip_radix_ws_words(n)), dtype=torch.int32, device=dev)
+    check(hip().evox_hip_radix_argsort(keys.data_ptr(), mode, keys.stride(0), perm.data_ptr() if perm is not None else None,
+                                       n, int(bits[0]), int(bits[1]), order.data_ptr(),
+                                       rank.data_ptr() if want_rank else None, ws.data_ptr(), stream_of(keys)),
+          "radix_argsort")
+    return (order, rank) if want_rank else order
+
+
+def argsort_small_ints(v: torch.Tensor, max_value: int) -> torch.Tensor:
+    """Stable ascending argsort of non-negative integers bounded by ``max_value`` (front indices, group numbers): on
+    the GPU one radix pass per byte of the bound."""
+    n = v.shape[0]
+    if v.is_cuda and v.dim() == 1 and 16 < n <= _RADIX_MAX and 0 <= max_value < (1 << 31):
+        bits = 8 if max_value < (1 << 8) else (16 if max_value < (1 << 16) else (24 if max_value < (1 << 24) else 32))
+        return radix_argsort(v.to(torch.int32), bits=(0, bits))
+    return torch.argsort(v, stable=True)
+
+
+def lexsort_rows(x: torch.Tensor) -> torch.Tensor:
+    """Stable argsort of the rows of ``x`` (n, m) in lexicographic order, first column most significant: a chain of
+    single-column radix sorts from the last column on (the tensor library's three argsorts and gathers otherwise)."""
+    n, m = x.shape
+    if x.is_cuda and x.dtype == torch.float32 and 16 < n <= _RADIX_MAX:
+        order = None
+        for k in range(m - 1, -1, -1):
+            order = radix_argsort(x[:, k], order)
+        return order
+    order = torch.argsort(x[:, m - 1], stable=True)
+    for k in range(m - 2, -1, -1):
+        order = order[torch.argsort(x[order, k], stable=True)]
+    return order
+
 _SLICED_MIN = 2048          # from here on the two-launch sliced count beats the one-launch form
 
 
@@ -57,6 +116,7 @@ def _rank_sort(keys: torch.Tensor, want_rank: bool, form: str = None):
 # the library's top-k 37 / 50 / 222.  A DE generation is a dozen launches, so up to 65 536 keys the single launch wins
 # on the wall clock (SHADE at 50 000: 0.21 ms per generation against 0.26 with either multi-launch form).
 _SELECT_ONE_WG_MAX = 1 << 16
+_SELECT_WIDE_IN_GRAPH_MIN = 8192
 
 
 def select_indices(keys: torch.Tensor, k: int, largest: bool = False) -> torch.Tensor:
@@ -73,7 +133,10 @@ def select_indices(keys: torch.Tensor, k: int, largest: bool = False) -> torch.T
     if keys.is_cuda and keys.dtype == torch.float32 and keys.dim() == 1:
         keys = keys.contiguous()
         out = torch.empty(k, dtype=torch.int64, device=keys.device)
-        if n <= _SELECT_ONE_WG_MAX:
+        # while a generation is being recorded into a graph the host cost of the five launches of the chip-wide form
+        # is paid once, and the single workgroup's 24-84 µs would sit on every replay's critical path
+        wide_in_graph = n > _SELECT_WIDE_IN_GRAPH_MIN and torch.cuda.is_current_stream_capturing()
+        if n <= _SELECT_ONE_WG_MAX and not wide_in_graph:
             check(hip().evox_hip_select(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), stream_of(keys)), "select")
         else:
             ws = torch.zeros((int(hip().evox_hip_select_wide_ws(n)) + 3) // 4, dtype=torch.int32, device=keys.device)
@@ -97,6 +160,8 @@ def argsort(keys: torch.Tensor) -> torch.Tensor:
     """Stable ascending argsort (NaN last)."""
     if _rank_sortable(keys):
         return _rank_sort(keys, False)[0]
+    if radix_sortable(keys):
+        return radix_argsort(keys)
     return torch.argsort(keys, stable=True)
 
 
@@ -116,6 +181,15 @@ def sort_with_rank(keys: torch.Tensor, out: torch.Tensor = None, copy_out: torch
                                               copy_out.data_ptr() if copy_out is not None else None, scratch.data_ptr(),
                                               stream_of(keys)), "rank_sort_values")
         return out, rank
+    if radix_sortable(keys) and keys.dtype == torch.float32 and fits(out) and fits(copy_out):
+        order, rank = radix_argsort(keys, want_rank=True)
+        values = keys[order]
+        if out is not None:
+            out.copy_(values)
+            values = out
+        if copy_out is not None:
+            copy_out.copy_(keys)
+        return values, rank
     values, order = torch.sort(keys, stable=True)
     rank = torch.empty_like(order)
     rank[order] = torch.arange(keys.shape[0], device=keys.device)
@@ -131,6 +205,8 @@ def argsort_with_rank(keys: torch.Tensor):
     """``(order, rank)`` with ``rank[order[r]] = r`` (the position of every key in the sorted order)."""
     if _rank_sortable(keys):
         return _rank_sort(keys, True)
+    if radix_sortable(keys):
+        return radix_argsort(keys, want_rank=True)
     order = torch.argsort(keys, stable=True)
     rank = torch.empty_like(order)
     rank[order] = torch.arange(order.shape[0], device=order.device)

@@ -612,6 +612,42 @@ def test_rank_sort_kernel_matches_stable_argsort(cuda, n, form, monkeypatch):
         assert torch.equal(sort.argsort(const).cpu(), torch.arange(n))
 
 
+@pytest.mark.parametrize("n", [17, 4096, 4097, 16385, 50000, 200000, 1 << 20])
+def test_radix_sort_matches_stable_sort(cuda, n):
+    """The multi-workgroup radix sort against ``torch.sort(stable=True)``: ties, signed zeros, infinities, NaNs, strided
+    columns, integer keys on a byte range, ranks, and a lexicographic sort as a chain of column sorts."""
+    from evox_amd.ops import sort
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    keys = torch.randn(n, generator=g)
+    keys = (keys * 8).round() / 8                                  # many ties: stability is visible
+    keys[3], keys[11], keys[n // 2], keys[n - 1] = float("inf"), float("-inf"), float("nan"), float("nan")
+    keys[5], keys[6] = 0.0, -0.0
+    d = keys.to(cuda)
+    ref = torch.argsort(keys, stable=True)
+    order, rank = sort.radix_argsort(d, want_rank=True)
+    assert torch.equal(order.cpu(), ref)
+    assert torch.equal(rank.cpu()[ref], torch.arange(n))
+    if n > 16384:
+        assert torch.equal(sort.argsort(d).cpu(), ref)              # the public entry points route long keys here
+        vals, rk = sort.sort_with_rank(d)
+        assert torch.equal(rk.cpu(), rank.cpu()) and torch.equal(vals.cpu().nan_to_num(7e30), keys[ref].nan_to_num(7e30))
+    # a strided column and a lexicographic sort of rows
+    x = torch.stack([(torch.rand(n, generator=g) * 6).floor(), (torch.rand(n, generator=g) * 5).floor(),
+                     torch.randn(n, generator=g)], dim=1)
+    xd = x.to(cuda)
+    assert torch.equal(sort.radix_argsort(xd[:, 1]).cpu(), torch.argsort(x[:, 1], stable=True))
+    want = torch.argsort(x[:, 2], stable=True)
+    want = want[torch.argsort(x[want, 1], stable=True)]
+    want = want[torch.argsort(x[want, 0], stable=True)]
+    assert torch.equal(sort.lexsort_rows(xd).cpu(), want)
+    # integer keys: all 32 bits (negative values too), and the low 16 bits of small non-negative ones
+    ik = torch.randint(-1000, 1000, (n,), generator=g, dtype=torch.int32)
+    assert torch.equal(sort.radix_argsort(ik.to(cuda)).cpu(), torch.argsort(ik, stable=True))
+    small = torch.randint(0, 40000, (n,), generator=g, dtype=torch.int32)
+    assert torch.equal(sort.radix_argsort(small.to(cuda), bits=(0, 16)).cpu(), torch.argsort(small, stable=True))
+
+
 def test_sampling_gemm_with_device_scale_and_bias(cuda):
     from evox_amd.ops import blas
 
