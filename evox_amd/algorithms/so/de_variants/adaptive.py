@@ -131,16 +131,6 @@ class SHADE(JaDE):
         return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start, start_index_dev=self._next_start_dev(state),
                              Memory_FCR=memory)
 
-    def migrate(self, state, foreign_population, foreign_fitness):
-        """Island-model hook: the immigrants replace the worst residents they improve on."""
-        k = foreign_fitness.shape[0]
-        worst = _sort.select_indices(state.fitness, k, largest=True)
-        better = foreign_fitness < state.fitness[worst]
-        pop = state.population.index_copy(0, worst, torch.where(better[:, None], foreign_population,
-                                                                state.population[worst]))
-        fit = state.fitness.index_copy(0, worst, torch.where(better, foreign_fitness, state.fitness[worst]))
-        return state.replace(population=pop, fitness=fit, best_index=torch.argmin(fit))
-
 
 # strategy tables: (primary base, secondary base, #difference vectors, crossover)
 _RAND_1_BIN = (RAND, RAND, 1, BIN)

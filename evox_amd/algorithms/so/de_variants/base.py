@@ -79,6 +79,20 @@ class DEBase(Algorithm):
         start = (state.start_index + self.batch_size) % self.pop_size
         return population, fitness, best_index, start, better, parent_fit
 
+    def migrate(self, state, foreign_population, foreign_fitness):
+        """Island-model hook (every DE variant shares the population / fitness / best_index state): the immigrants
+        replace the worst residents they improve on.  The reference only declares the hook
+        (``src/evox/workflows/std_workflow.py:230-244``)."""
+        from ....ops import sort as _sort
+
+        k = foreign_fitness.shape[0]
+        worst = _sort.select_indices(state.fitness, k, largest=True)
+        better = foreign_fitness < state.fitness[worst]
+        pop = state.population.index_copy(0, worst, torch.where(better[:, None], foreign_population,
+                                                                state.population[worst]))
+        fit = state.fitness.index_copy(0, worst, torch.where(better, foreign_fitness, state.fitness[worst]))
+        return state.replace(population=pop, fitness=fit, best_index=torch.argmin(fit))
+
     def tell(self, state, trial_fitness):
         population, fitness, best_index, start, _, _ = self._select(state, state.trial_vectors, trial_fitness)
         return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,

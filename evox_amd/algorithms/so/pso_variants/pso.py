@@ -50,6 +50,27 @@ class PSO(Algorithm):
     def ask(self, state):
         return state.population, state
 
+    def migrate(self, state, foreign_population, foreign_fitness):
+        """Island-model hook: an immigrant takes the place of one of the particles with the worst personal best when it
+        improves on that best — position and personal best become the immigrant's, the velocity starts from zero — and
+        the swarm's best is refreshed."""
+        from ....ops import sort as _sort
+
+        k = foreign_fitness.shape[0]
+        worst = _sort.select_indices(state.local_best_fitness, k, largest=True)
+        better = foreign_fitness < state.local_best_fitness[worst]
+        pick = lambda new, old: torch.where(better.reshape((-1,) + (1,) * (old.dim() - 1)), new, old)
+        pop = state.population.index_copy(0, worst, pick(foreign_population, state.population[worst]))
+        lbl = state.local_best_location.index_copy(0, worst, pick(foreign_population, state.local_best_location[worst]))
+        lbf = state.local_best_fitness.index_copy(0, worst, pick(foreign_fitness, state.local_best_fitness[worst]))
+        vel = state.velocity.index_copy(0, worst, pick(torch.zeros_like(foreign_population), state.velocity[worst]))
+        b = torch.argmin(lbf)
+        improves = lbf[b] < state.global_best_fitness.reshape(())
+        gbl = torch.where(improves, lbl[b], state.global_best_location)
+        gbf = torch.where(improves, lbf[b], state.global_best_fitness.reshape(())).reshape(state.global_best_fitness.shape)
+        return state.replace(population=pop, velocity=vel, local_best_location=lbl, local_best_fitness=lbf,
+                             global_best_location=gbl, global_best_fitness=gbf)
+
     def tell(self, state, fitness):
         key, k_move = rnd.split(state.key)
         pop, vel, pbest, pbest_fit, gbest, gbest_fit = _swarm.pso_step(

@@ -254,11 +254,26 @@ class IslandWorkflow(StdWorkflow):
             return None
         return state.replace(rank=rank)
 
+    # names of the state fields that hold the individuals an island offers and how good they are
+    _MIGRANT_FIELDS = (("population", "fitness"), ("local_best_location", "local_best_fitness"))
+
     def _migrate(self, state):
+        """One migration: every island's ``num_migrants`` best individuals in one all-gather of ``k x (dim + 1)`` floats
+        (the peer-to-peer one-shot form when it is switched on: one put and one collect launch), the immigrants of an
+        island chosen from the other islands' packets by the hand-written radix select (``ops.sort.select_indices``: one
+        launch, no sort)."""
+        from ..ops import sort as _sort
+
         alg = state.get_child_state("algorithm")
         k = self.num_migrants
-        best = torch.topk(alg.fitness, k, largest=False).indices
-        packet = torch.cat([alg.population[best], alg.fitness[best, None]], dim=1)       # (k, dim + 1)
+        for pop_name, fit_name in self._MIGRANT_FIELDS:
+            if pop_name in alg and fit_name in alg:
+                pop, fit = getattr(alg, pop_name), getattr(alg, fit_name)
+                break
+        else:
+            raise TypeError(f"{type(self.algorithm).__name__}'s state has no population / fitness pair to migrate from")
+        best = _sort.select_indices(fit, k)
+        packet = torch.cat([pop[best], fit[best, None]], dim=1)                          # (k, dim + 1)
         world = dist.get_world_size()
         everyone = dist.all_gather(packet, dist.POP_AXIS_NAME, axis=0, tiled=True).reshape(world, k, -1)
         rank = dist.get_process_id()
@@ -267,7 +282,7 @@ class IslandWorkflow(StdWorkflow):
         else:
             keep = [r for r in range(world) if r != rank] or [rank]
             flat = everyone[keep].reshape(-1, everyone.shape[-1])
-            src = flat[torch.topk(flat[:, -1], min(k, flat.shape[0]), largest=False).indices]
+            src = flat if flat.shape[0] <= k else flat[_sort.select_indices(flat[:, -1].contiguous(), k)]
         return use_state(self.algorithm.migrate)(state, src[:, :-1].contiguous(), src[:, -1].contiguous())
 
     def step(self, state):

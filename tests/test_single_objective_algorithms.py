@@ -136,3 +136,32 @@ def test_asebo_population_larger_than_gradient_history_stays_finite():
         state = wf.step(state)
     a = state.get_child_state("algorithm")
     assert torch.isfinite(a.center).all() and torch.isfinite(a.alpha)
+
+
+@pytest.mark.parametrize("name", ["DE", "ODE", "CoDE", "SaDE", "JaDE", "SHADE", "PSO"])
+def test_migrate_hook_replaces_the_worst_residents(name):
+    """Every DE variant and PSO take immigrants (``IslandWorkflow`` calls ``algorithm.migrate``): an immigrant that
+    improves on one of the worst residents takes its place, one that does not is dropped."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    lb, ub = torch.full((6,), -5.0), torch.full((6,), 5.0)
+    algo = getattr(algorithms, name)(lb, ub, 40) if name != "PSO" else algorithms.PSO(lb=lb, ub=ub, pop_size=40)
+    wf = workflows.StdWorkflow(algo, problems.numerical.Sphere())
+    state = wf.init(ex.PRNGKey(2))
+    for _ in range(3):
+        state = wf.step(state)
+    a = state.get_child_state("algorithm")
+    fit_name = "local_best_fitness" if name == "PSO" else "fitness"
+    before = getattr(a, fit_name).clone()
+    foreign = torch.zeros(3, 6)
+    foreign[2] = 100.0                                       # two perfect immigrants and a hopeless one
+    ffit = (foreign ** 2).sum(1)
+    b = algo.migrate(a, foreign, ffit)
+    after = getattr(b, fit_name)
+    assert int((after == 0).sum()) == 2 and float(after.max()) <= float(before.max())
+    assert float(after.sum()) < float(before.sum())
+    if name == "PSO":
+        assert float(b.global_best_fitness) == 0.0 and float(b.global_best_location.abs().max()) == 0.0
+    else:
+        assert float(b.fitness[b.best_index]) == 0.0
