@@ -24,11 +24,16 @@ from ....core.state import State
 from ....ops import cma as _cma
 
 
-def _batched_eigh(C: torch.Tensor):
-    """Eigenvectors and eigenvalues of a stack of symmetric matrices (upper triangles are read).  Small matrices on a
-    GPU take the host round trip, for the reason given at ``evox_amd.ops.cma._host_max``: one LAPACK loop over the stack
-    beats the device solver's per-matrix latency by an order of magnitude."""
+def _batched_eigh(C: torch.Tensor, B_prev: Optional[torch.Tensor] = None):
+    """Eigenvectors and eigenvalues of a stack of symmetric matrices (upper triangles are read).  On a GPU the stack goes
+    to the batched Jacobi kernel — one workgroup per matrix, all of them at once, warm-started from the previous
+    eigenvectors (``ops/linalg_small.py``); with that switched off, small matrices take the host round trip."""
     C = torch.triu(C) + torch.triu(C, 1).transpose(-1, -2)
+    from ....ops import linalg_small as _ls
+
+    if _ls.device_linalg(C, C.shape[-1]):
+        evals, B = _ls.eigh_small(C, B_prev)
+        return B.contiguous(), evals
     if C.is_cuda and C.shape[-1] <= _cma._host_max():
         evals, B = torch.linalg.eigh(C.cpu())
         return B.to(C.device, non_blocking=True), evals.to(C.device, non_blocking=True)
@@ -150,7 +155,7 @@ class BatchedCMAES(Algorithm):
         rank_mu = torch.bmm((y * self.weights[None, :, None]).transpose(1, 2), y)
         C = alpha[:, None, None] * state.C + self.c1 * pc[:, :, None] * pc[:, None, :] + self.cmu * rank_mu
         if state.count_iter % self.decomp_per_iter == 0:
-            B, evals = _batched_eigh(C)
+            B, evals = _batched_eigh(C, state.B)
             D = torch.sqrt(evals.clamp_min(1e-30))
             invsqrtC = torch.bmm(B / D[:, None, :], B.transpose(1, 2))
             count_eigen = state.count_eigen + 1

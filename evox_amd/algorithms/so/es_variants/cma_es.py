@@ -177,8 +177,8 @@ class CMAES(Algorithm):
         """State fields that only count on the host (a recorded step may advance them without
         replaying host code).  Valid when every generation takes the same branch, i.e. the
         factorisation runs every generation, and the device work reads ``count_iter_dev``."""
-        if self.decomp_per_iter == 1 and self._ns is not None and self._sqrt_w is not None:
-            return ("count_iter", "count_eigen", "ns_calls")
+        if self.decomp_per_iter == 1:
+            return ("count_iter", "count_eigen") + (("ns_calls",) if self._ns is not None else ())
         return ()
 
     def graph_check(self) -> bool:
@@ -596,7 +596,13 @@ class IPOPCMAES(CMAES):
 
     def setup(self, key):
         s = super().setup(key)
-        return s.replace(best_fitness=float("inf"), restarts=0, stagnation_count=0, pop_size=self.original_pop_size)
+        dev = self.center_init.device
+        # best fitness and the stagnation counter live on the device: a generation without a restart then has no host
+        # value that changes, and can be recorded; the restart decision reads the counter (every generation when
+        # issued eagerly, at the workflow's polls — ``graph_retune`` — while replaying)
+        return s.replace(best_fitness=torch.full((), float("inf"), device=dev),
+                         stagnation_count=torch.zeros((), dtype=torch.int32, device=dev), restarts=0,
+                         pop_size=self.original_pop_size)
 
     def _variant(self, pop_size) -> CMAES:
         return CMAES(pop_size=pop_size, **self._ctor)
@@ -612,19 +618,35 @@ class IPOPCMAES(CMAES):
     def tell(self, state, fitness):
         algo = self if state.pop_size == self.pop_size else self._variant(state.pop_size)
         state = CMAES.tell(algo, state, fitness)
-        current = float(fitness.min())
-        if current < state.best_fitness:
-            return state.replace(best_fitness=current, stagnation_count=0)
-        stagnation = state.stagnation_count + 1
-        if stagnation < self.stagnation_threshold:
-            return state.replace(stagnation_count=stagnation)
+        current = fitness.min()
+        improved = current < state.best_fitness
+        state = state.replace(best_fitness=torch.minimum(current, state.best_fitness),
+                              stagnation_count=torch.where(improved, torch.zeros_like(state.stagnation_count),
+                                                           state.stagnation_count + 1))
+        if state.stagnation_count.is_cuda and torch.cuda.is_current_stream_capturing():
+            return state                                   # recorded generation: the workflow polls ``graph_retune``
+        return self._restart_if_stagnant(state)
+
+    def graph_retune(self, state):
+        """Polled by the workflow while it replays recorded generations: the restart that eager issue decides every
+        generation (one scalar read-back) is decided here; a restart changes the population size, so the workflow
+        records afresh."""
+        fresh = self._restart_if_stagnant(state)
+        return None if fresh is state else fresh
+
+    def graph_variant(self, state):
+        return state.pop_size
+
+    def _restart_if_stagnant(self, state):
+        if int(state.stagnation_count) < self.stagnation_threshold:
+            return state
         restarts = state.restarts + 1
         new_pop = self._next_pop_size(state, restarts)
         key, sub = rnd.split(state.key)
         fresh = self._variant(new_pop).setup(sub)
         fields = {k: getattr(fresh, k) for k in fresh.keys()}
-        fields.update(key=key, best_fitness=state.best_fitness, restarts=restarts, stagnation_count=0,
-                      pop_size=new_pop)
+        fields.update(key=key, best_fitness=state.best_fitness, restarts=restarts,
+                      stagnation_count=torch.zeros_like(state.stagnation_count), pop_size=new_pop)
         return state.replace(**fields)
 
 

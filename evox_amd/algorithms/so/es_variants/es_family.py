@@ -20,6 +20,29 @@ from ....core.module import Stateful, use_state
 from ....core.state import State
 from ....ops import es as _es
 from ....ops.cma import small_svd_vt as _small_svd_vt
+from ....ops import linalg_small as _ls
+
+
+def _matrix_exp(A):
+    """exp(A): on the GPU the fixed-parameter scaling-and-squaring kernel for n ≤ 110 (the library routine reads a norm
+    back to the host to choose its parameters, which a recorded generation cannot do)."""
+    if _ls.device_linalg(A, A.shape[-1]) and _ls.expm_fits(A.shape[-1]):
+        return _ls.expm_small(A)
+    return torch.linalg.matrix_exp(A)
+
+
+def _thin_q(A):
+    """Q (m, k) of the thin QR factorisation (device kernel for small k on a GPU)."""
+    m, k = A.shape
+    if _ls.device_linalg(A, k) and _ls.qr_fits(m, k):
+        return _ls.qr_q_small(A)
+    return torch.linalg.qr(A)[0]
+
+
+def _cholesky(A):
+    if _ls.device_linalg(A, A.shape[-1]):
+        return _ls.cholesky_small(A)
+    return torch.linalg.cholesky(A)
 from ....utils import optimizers as optim
 
 
@@ -534,7 +557,7 @@ class XNES(Algorithm):
         grad_B = grad_M - grad_sigma * eye
         mean = state.mean + self.learning_rate_mean * state.sigma * (state.B @ grad_delta)
         sigma = state.sigma * torch.exp(self.learning_rate_var / 2 * grad_sigma)
-        B = state.B @ torch.linalg.matrix_exp(self.learning_rate_B / 2 * grad_B)
+        B = state.B @ _matrix_exp(self.learning_rate_B / 2 * grad_B)
         return state.replace(mean=mean, sigma=sigma, B=B)
 
 
@@ -568,7 +591,7 @@ class GuidedES(_ESBase):
         c = state.sigma * math.sqrt((1.0 - self.alpha) / self.subspace_dims)
         eps_full = _es.noise_rows(k_full, h, self.dim)
         eps_sub = rnd.normal(k_sub, (h, self.subspace_dims))
-        q, _ = torch.linalg.qr(state.grad_subspace.T)                     # (dim, subspace)
+        q = _thin_q(state.grad_subspace.T)                                # (dim, subspace)
         return a * eps_full + c * (eps_sub @ q.T)
 
     def ask(self, state):
@@ -610,6 +633,13 @@ class ASEBO(_ESBase):
                      sigma=torch.tensor(float(self.sigma), device=dev), alpha=torch.tensor(0.1, device=dev),
                      UUT=zeros, UUT_ort=zeros, population=torch.zeros((self.pop_size, self.dim), device=dev))
 
+    # recorded generations: the counter only decides whether the gradient history is full (one recording per answer)
+    def graph_host_counters(self):
+        return ("gen_counter",)
+
+    def graph_variant(self, state):
+        return state.gen_counter > self.subspace_dims
+
     def ask(self, state):
         key, k_noise = rnd.split(state.key)
         h = self.pop_size // 2
@@ -624,7 +654,7 @@ class ASEBO(_ESBase):
         # lets it leave that range, after which its Cholesky factor is NaN)
         alpha = torch.clamp(state.alpha, 1e-3, 1.0)
         cov = state.sigma * (alpha / self.dim) * eye + ((1 - alpha) / h) * UUT
-        chol = torch.linalg.cholesky(cov)
+        chol = _cholesky(cov)
         z = rnd.normal(k_noise, (h, self.dim)) @ chol.T
         z = z / torch.linalg.vector_norm(z, dim=-1, keepdim=True)
         x = torch.cat([state.center + z, state.center - z], dim=0)

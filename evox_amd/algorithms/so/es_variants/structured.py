@@ -163,17 +163,17 @@ class RMES(CMAES):
                          p_sigma=torch.zeros(self.dim, device=dev))
 
     def _update_P(self, P, p_sigma, t_gap, gen):
+        """``gen``: the generation number as a 0-d device tensor.  The oldest path leaves the memory when all paths are
+        at least ``t_uncorr`` generations apart (or the memory is still filling), otherwise the newer one of the closest
+        pair — decided on the device (a column gather), so the step has no host read."""
         m = self.memory_size
         gaps = t_gap[1:] - t_gap[:-1]
-        push = bool(gaps.min() > self.t_uncorr) or gen < m
-        if push:
-            P = torch.cat([P[:, 1:], p_sigma[:, None]], dim=1)
-            t_gap = torch.cat([t_gap[1:], t_gap.new_tensor([float(gen)])])
-        else:
-            i_min = int(torch.argmin(gaps))
-            keep = [i for i in range(m) if i != i_min]
-            P = torch.cat([P[:, keep], p_sigma[:, None]], dim=1)
-            t_gap = torch.cat([t_gap[keep], t_gap.new_tensor([float(gen)])])
+        push = (gaps.min() > self.t_uncorr) | (gen < m)
+        drop = torch.where(push, torch.zeros((), dtype=torch.int64, device=P.device), torch.argmin(gaps))
+        idx = torch.arange(m - 1, device=P.device)
+        keep = idx + (idx >= drop).to(idx.dtype)
+        P = torch.cat([P[:, keep], p_sigma[:, None]], dim=1)
+        t_gap = torch.cat([t_gap[keep], gen.reshape(1).to(t_gap.dtype)])
         return P, t_gap
 
     def _rank_success(self, state, sorted_fitness):
@@ -205,7 +205,7 @@ class RMES(CMAES):
             B, D, invsqrtC = state.B, state.D, state.invsqrtC
         p_sigma = (1 - self.c_sigma) * state.p_sigma + math.sqrt(self.c_sigma * (2 - self.c_sigma) * self.mueff) * (
             mean - state.mean) / state.sigma
-        P, t_gap = self._update_P(state.P, state.p_sigma, state.t_gap, state.count_iter)
+        P, t_gap = self._update_P(state.P, state.p_sigma, state.t_gap, state.count_iter_dev)
         return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma, B=B, D=D, invsqrtC=invsqrtC, p_sigma=p_sigma,
                              P=P, t_gap=t_gap, s_rank_rate=self._rank_success(state, fitness[order]),
                              fitness_archive=fitness[order])
@@ -216,8 +216,22 @@ _TIMESCALES = (1, 3, 10, 30, 50, 100, 250, 500, 750, 1000, 1250, 1500, 2000)
 
 
 def tanh_timestamp(x) -> torch.Tensor:
+    """``x``: generation number — a Python number, or a 0-d device tensor (the embedding is then computed on its device)."""
+    if isinstance(x, torch.Tensor):
+        t = torch.tensor(_TIMESCALES, dtype=torch.float32, device=x.device) if x.device.type == "cpu" else _timescales_on(x.device)
+        return torch.tanh(x.to(torch.float32) / t - 1.0)
     t = torch.tensor(_TIMESCALES, dtype=torch.float32)
     return torch.tanh(float(x) / t - 1.0)
+
+
+_TS_CACHE = {}
+
+
+def _timescales_on(device) -> torch.Tensor:
+    t = _TS_CACHE.get(device)
+    if t is None:
+        t = _TS_CACHE[device] = torch.tensor(_TIMESCALES, dtype=torch.float32, device=device)
+    return t
 
 
 def _dense(p, x):
@@ -281,7 +295,12 @@ class LES(Algorithm):
         return State(key=key, noise_key=key, sigma=torch.full((self.num_dims,), float(self.sigma_init), device=dev),
                      mean=self.center_init, path_c=zeros, path_sigma=zeros.clone(),
                      best_fitness=torch.tensor(torch.finfo(torch.float32).max, device=dev),
-                     best_member=self.center_init, gen_counter=0)
+                     best_member=self.center_init, gen_counter=0,
+                     # the same counter on the device: the time embedding of a recorded generation follows it
+                     gen_counter_dev=torch.zeros((), device=dev))
+
+    def graph_host_counters(self):
+        return ("gen_counter",)
 
     def ask(self, state):
         key, noise_key = rnd.split(state.key)
@@ -314,7 +333,7 @@ class LES(Algorithm):
         ts = self.timescales
         path_c = (1 - ts) * state.path_c + (1 - ts) * weight_diff[:, None]
         path_sigma = (1 - ts) * state.path_sigma + (1 - ts) * weight_noise[:, None]
-        time_embed = tanh_timestamp(state.gen_counter).to(dev)
+        time_embed = tanh_timestamp(state.gen_counter_dev)
         X = torch.cat([path_c, path_sigma, time_embed[None, :].expand(self.num_dims, -1)], dim=1)
         mlp = p["lrate_modulation"]
         hidden = torch.relu(_dense(mlp["hidden"], X))
@@ -326,4 +345,4 @@ class LES(Algorithm):
         sigma = torch.clamp(state.sigma + lr_sigma * (weighted_sigma - state.sigma), min=0)
         best_fitness = torch.minimum(fitness.min(), state.best_fitness)
         return state.replace(mean=mean, sigma=sigma, path_c=path_c, path_sigma=path_sigma, best_fitness=best_fitness,
-                             gen_counter=state.gen_counter + 1)
+                             gen_counter=state.gen_counter + 1, gen_counter_dev=state.gen_counter_dev + 1)

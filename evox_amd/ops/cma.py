@@ -90,8 +90,27 @@ def _host_max() -> int:
     return int(os.environ.get("EVOX_AMD_HOST_LINALG_MAX", "384"))
 
 
-def eigh_reference(C) -> Tuple[torch.Tensor, torch.Tensor]:
+def _device_jacobi(C) -> bool:
+    """Orders whose symmetric eigendecomposition runs in the one-workgroup Jacobi kernel (``csrc/linalg_small.hip``): up
+    to ``EVOX_AMD_DEVICE_EIGH_MAX`` (default 192) — and up to 384 while a generation is being recorded into a graph,
+    where the host round trip of the alternative is not possible."""
+    from . import linalg_small as _ls
+
+    n = C.shape[-1]
+    if not _ls.device_linalg(C, n):
+        return False
+    return n <= int(os.environ.get("EVOX_AMD_DEVICE_EIGH_MAX", "192")) or torch.cuda.is_current_stream_capturing()
+
+
+def eigh_reference(C, B_prev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``(B, evals)`` of the symmetric ``C``.  ``B_prev``: eigenvectors of a nearby matrix (warm start of the device
+    kernel; ignored by the library routes)."""
     C = torch.triu(C) + torch.triu(C, 1).T
+    if _device_jacobi(C):
+        from . import linalg_small as _ls
+
+        evals, B = _ls.eigh_small(C, B_prev)
+        return B.contiguous(), evals
     if C.is_cuda and C.shape[-1] <= _host_max():
         evals, B = torch.linalg.eigh(C.cpu())
         return B.to(C.device, non_blocking=True), evals.to(C.device, non_blocking=True)
@@ -100,7 +119,12 @@ def eigh_reference(C) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def small_svd_vt(X: torch.Tensor) -> torch.Tensor:
-    """``Vᵀ`` of the thin SVD of ``X``; small problems on a GPU go through the host (see ``_host_max``)."""
+    """``Vᵀ`` of the thin SVD of ``X`` (k, m): one-sided Jacobi on the device for k ≤ 384 ≤ m-independent sizes
+    (``csrc/linalg_small.hip``), the library otherwise (small problems through the host, see ``_host_max``)."""
+    from . import linalg_small as _ls
+
+    if X.dim() == 2 and X.shape[0] <= X.shape[1] and _ls.device_linalg(X, X.shape[0]):
+        return _ls.svd_vt_small(X)[0]
     if X.is_cuda and max(X.shape) <= _host_max():
         return torch.linalg.svd(X.cpu(), full_matrices=False)[2].to(X.device, non_blocking=True)
     return torch.linalg.svd(X, full_matrices=False)[2]
@@ -112,8 +136,10 @@ def decompose(C, B_prev: Optional[torch.Tensor] = None, method: Optional[str] = 
 
     This is the exact-semantics path of the reference (``algorithms/so/es_variants/cma_es.py:143-166``); it costs
     tens of milliseconds at n = 1000 on the GPU, which is why CMA-ES defaults to :class:`NewtonSchulzSqrt` there.
-    ``B_prev`` and ``method`` are accepted for call compatibility and ignored."""
-    B, evals = eigh_reference(C)
+    Small orders on a GPU run in the one-workgroup Jacobi kernel, warm-started from ``B_prev`` (the previous
+    generation's eigenvectors: the covariance moves slowly, one or two sweeps suffice).  ``method`` is accepted for call
+    compatibility and ignored."""
+    B, evals = eigh_reference(C, B_prev)
     D = torch.sqrt(evals.clamp_min(1e-30))
     invsqrtC = (B / D) @ B.T
     return B, D, invsqrtC

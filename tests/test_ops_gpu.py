@@ -2049,3 +2049,76 @@ def test_graph_step_auto_measures_and_keeps_the_faster_way():
     wx, sx = run("auto", lambda: algorithms.XNES(init_mean=torch.zeros(10, device=dev), init_covar=torch.eye(10, device=dev), pop_size=32))
     assert wx.graph_choice["mode"] == "eager" and wx.graph_step is False and "reason" in wx.graph_choice
     assert int(sx.generation) == 60
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 130, 200, 384])
+def test_small_eigh_jacobi_against_fp64(cuda, n):
+    """One-workgroup Jacobi eigendecomposition (LDS-resident up to n = 135, from memory beyond) against
+    ``torch.linalg.eigh`` in fp64: eigenvalues to 1e-5 relative to the largest, ``‖B D Bᵀ − C‖`` to 1e-5, orthonormal
+    eigenvectors; a warm start from the eigenvectors of a nearby matrix gives the same answer; a batch of matrices is
+    decomposed by one launch."""
+    from evox_amd.ops import linalg_small as ls
+
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n, 3 * n, generator=g, dtype=torch.float64)
+    C64 = a @ a.T / (3 * n) + 0.1 * torch.diag(torch.rand(n, generator=g, dtype=torch.float64))
+    C = C64.float().to(cuda)
+    ev, B = ls.eigh_small(C)
+    ref = torch.linalg.eigvalsh(C64)
+    Bd = B.double().cpu()
+    tol = 1e-5 if n <= 130 else 3e-5                       # fp32 rotations: the error grows like eps * sqrt(n)
+    assert torch.allclose(ev.double().cpu(), ref, atol=tol * float(ref.max()))
+    assert float((Bd @ torch.diag(ev.double().cpu()) @ Bd.T - C64).norm() / C64.norm()) < tol
+    assert float((Bd.T @ Bd - torch.eye(n, dtype=torch.float64)).abs().max()) < 5e-5
+    # warm start: a matrix that moved by a percent, starting from the eigenvectors above
+    d = torch.randn(n, n, generator=g, dtype=torch.float64) * 0.01
+    C2_64 = C64 + 0.5 * (d + d.T) * float(C64.diagonal().mean())
+    ev2, B2 = ls.eigh_small(C2_64.float().to(cuda), B0=B)
+    assert torch.allclose(ev2.double().cpu(), torch.linalg.eigvalsh(C2_64), atol=2 * tol * float(ref.max()))
+    B2d = B2.double().cpu()
+    assert float((B2d @ torch.diag(ev2.double().cpu()) @ B2d.T - C2_64).norm() / C2_64.norm()) < 2 * tol
+    if n <= 130:
+        stack = torch.stack([C, 2 * C + torch.eye(n, device=cuda), C.flip(0).flip(1)])
+        evs, Bs = ls.eigh_small(stack)
+        for s in range(3):
+            want = torch.linalg.eigvalsh(stack[s].double().cpu())
+            assert torch.allclose(evs[s].double().cpu(), want, atol=2e-5 * float(want.max()))
+            Bq = Bs[s].double().cpu()
+            assert float((Bq @ torch.diag(evs[s].double().cpu()) @ Bq.T - stack[s].double().cpu()).norm()) < 2e-5 * float(stack[s].norm())
+
+
+@pytest.mark.parametrize("k,m", [(1, 50), (8, 100), (50, 100), (50, 2000), (120, 384)])
+def test_small_svd_cholesky_qr_expm_against_fp64(cuda, k, m):
+    from evox_amd.ops import linalg_small as ls
+
+    g = torch.Generator().manual_seed(k * 1000 + m)
+    X64 = torch.randn(k, m, generator=g, dtype=torch.float64) * torch.logspace(0, -2, k, dtype=torch.float64)[:, None]
+    X = X64.float().to(cuda)
+    Vt, s = ls.svd_vt_small(X)
+    sref = torch.linalg.svdvals(X64)
+    assert torch.allclose(s.double().cpu(), sref, atol=1e-5 * float(sref[0]))
+    V = Vt.double().cpu()
+    assert float((V @ V.T - torch.eye(k, dtype=torch.float64)).abs().max()) < 5e-5
+    # X = U S Vt: the rows of Vt span the row space, and projecting X on them reproduces its singular values
+    assert float((X64 - (X64 @ V.T) @ V).norm() / X64.norm()) < 1e-5
+    assert torch.allclose((X64 @ V.T).norm(dim=0), sref, atol=2e-5 * float(sref[0]))
+    # thin QR of X^T (m x k)
+    Q = ls.qr_q_small(X.T)
+    Qd = Q.double().cpu()
+    assert float((Qd.T @ Qd - torch.eye(k, dtype=torch.float64)).abs().max()) < 5e-5
+    R = Qd.T @ X64.T
+    assert float((Qd @ R - X64.T).norm() / X64.norm()) < 1e-5 and float(torch.tril(R, -1).abs().max()) < 1e-4 * float(R.abs().max())
+    assert bool((R.diagonal() > 0).all())
+    n = min(m, 300)
+    a = torch.randn(n, n + 10, generator=g, dtype=torch.float64)
+    A64 = a @ a.T / n + 0.05 * torch.eye(n, dtype=torch.float64)
+    L = ls.cholesky_small(A64.float().to(cuda)).double().cpu()
+    assert float((L @ L.T - A64).norm() / A64.norm()) < 1e-5 and float(torch.triu(L, 1).abs().max()) == 0.0
+    bad = A64.float().to(cuda).clone()
+    bad[n // 2, n // 2] = -1.0
+    assert bool(torch.isnan(ls.cholesky_small(bad)).any())
+    ne = min(m, 100)
+    S = torch.randn(ne, ne, generator=g, dtype=torch.float64) * (2.0 / ne ** 0.5)
+    E = ls.expm_small(S.float().to(cuda)).double().cpu()
+    Eref = torch.linalg.matrix_exp(S)
+    assert float((E - Eref).norm() / Eref.norm()) < 2e-5
