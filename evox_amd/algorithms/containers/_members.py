@@ -4,7 +4,7 @@ from __future__ import annotations
 import copy
 
 from ...core.algorithm import has_init_ask, has_init_tell
-from ...core.module import ModuleStack, Stateful, use_state
+from ...core.module import ModuleStack, Stateful, clone_module, use_state
 
 
 def as_stack(base, count=None, stacked=False) -> ModuleStack:
@@ -20,7 +20,7 @@ def as_stack(base, count=None, stacked=False) -> ModuleStack:
     if stacked and dataclasses.is_dataclass(base):
         return ModuleStack([tree_map(lambda x: x[i], base) for i in range(count)])
     if isinstance(base, Stateful) and count is not None:
-        return ModuleStack([copy.copy(base) for _ in range(count)])
+        return ModuleStack([clone_module(base) for _ in range(count)])
     raise TypeError(f"cannot build a module stack from {type(base)}")
 
 
@@ -77,8 +77,10 @@ def widen(base, times: int):
 
     import torch
 
-    if not getattr(type(base), "dimension_separable", False):
+    if not getattr(base, "dimension_separable", False):
         return None
+    if callable(getattr(base, "widened", None)):
+        return base.widened(times)
 
     def tile(v):
         return v.repeat(times) if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == base.dim else v

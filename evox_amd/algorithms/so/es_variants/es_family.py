@@ -102,6 +102,27 @@ class _ESBase(Algorithm):
         self.center_init = torch.as_tensor(center_init, dtype=torch.float32)
         self.dim = self.center_init.shape[0]
 
+    # A strategy whose update treats every decision variable on its own given the fitness (isotropic or diagonal search
+    # distribution, per-variable optimizer) declares ``dimension_separable``: ``times`` copies of it over blocks of
+    # variables that are all told the same fitness ARE one instance over the concatenated vector, which is how the
+    # decomposition containers run it (one set of kernels for all blocks).  Hyper-parameters derived from the block
+    # dimension at construction keep their values.
+    dimension_separable = False
+
+    def widened(self, times: int):
+        """This strategy over ``times`` concatenated copies of its decision vector (see ``dimension_separable``)."""
+        import copy
+
+        wide = copy.copy(self)
+        wide.center_init = self.center_init.repeat(times)
+        wide.dim = self.dim * times
+        opt = getattr(self, "optimizer", None)
+        if isinstance(opt, optim.OptaxWrapper):
+            wide.optimizer = optim.OptaxWrapper(opt.optimizer, wide.center_init)
+        elif opt is not None:
+            raise TypeError(f"{type(opt).__name__} couples the decision variables: not separable")
+        return wide
+
     # Row-sharded protocol shared by the strategies whose update is "per-row weights from the whole fitness vector,
     # then weighted sums of the noise rows" (ARS, DES, SNES; OpenES and PGPE carry specialised forms).  The noise is
     # regenerated from its key, so a rank perturbs and later re-reads only its rows [r·N/W, (r+1)·N/W) of the logical
@@ -137,6 +158,8 @@ class OpenES(_ESBase):
     """OpenAI-ES (Salimans et al. 2017).  ``optimizer="adam"`` applies Adam to the estimated
     gradient (the reference passes the parameters instead of the gradient to Adam,
     ``open_es.py:80``; the gradient is used here)."""
+
+    dimension_separable = True
 
     def __init__(self, center_init, pop_size, learning_rate, noise_stdev, optimizer=None, mirrored_sampling=True):
         if not (noise_stdev > 0 and learning_rate > 0 and pop_size > 0):
@@ -203,6 +226,10 @@ class OpenES(_ESBase):
 
 class PGPE(_ESBase):
     """Parameter-exploring policy gradients with symmetric sampling (Sehnke et al. 2010)."""
+
+    @property
+    def dimension_separable(self):
+        return isinstance(self.optimizer, optim.OptaxWrapper)      # ClipUp caps the norm of the whole update vector
 
     def __init__(self, pop_size, center_init, optimizer: Union[str, Stateful, optim.GradientTransformation],
                  stdev_init=0.1, center_learning_rate=0.15, stdev_learning_rate=0.1, stdev_max_change=0.2):
@@ -283,6 +310,8 @@ class ARS(_ESBase):
     """Augmented random search (Mania et al. 2018): mirrored directions, only the best
     ``elite_ratio`` of the direction pairs contribute, step normalised by the reward spread."""
 
+    dimension_separable = True
+
     def __init__(self, pop_size, center_init, elite_ratio=0.1, optimizer="adam", lr=0.05, sigma=0.03):
         if pop_size % 2 or not 0 <= elite_ratio <= 1:
             raise ValueError("pop_size must be even and elite_ratio in [0, 1]")
@@ -336,6 +365,8 @@ class DES(_ESBase):
     """Discovered evolution strategy (Lange et al. 2023): rank-softmax recombination of mean
     and per-coordinate standard deviation."""
 
+    dimension_separable = True
+
     def __init__(self, pop_size, center_init, temperature=12.5, sigma_init=0.1, mean_decay=0.0):
         self._center(center_init)
         self.popsize = self.pop_size = pop_size
@@ -383,6 +414,8 @@ class DES(_ESBase):
 class ESMC(_ESBase):
     """ES with a baseline individual (Merchant et al. 2021): odd population = the unperturbed
     centre plus mirrored pairs; pair differences are clipped at the baseline fitness."""
+
+    dimension_separable = True
 
     def __init__(self, pop_size, center_init, optimizer="adam", lrate_decay=1.0, lrate_limit=0.001, sigma_decay=1.0,
                  sigma_limit=0.01, lr=0.05, sigma=0.03, init_min=0.0, init_max=0.0, clip_min=None, clip_max=None):
@@ -433,6 +466,8 @@ def get_temp_weights(popsize: int, temperature: float):
 
 class SNES(_ESBase):
     """Separable natural evolution strategy (Wierstra et al. 2014)."""
+
+    dimension_separable = True
 
     def __init__(self, pop_size, center_init, sigma=1.0, lrate_mean=1.0, temperature=0.0, init_min=0.0, init_max=0.0):
         self._center(center_init)
@@ -682,6 +717,8 @@ class Noise_reuse_es(_ESBase):
     """Noise-reuse ES (Li et al. 2023) for unrolled computation graphs: the same perturbation
     is kept for a whole inner episode of length ``T`` (advanced ``K`` steps per generation)."""
 
+    dimension_separable = True
+
     def __init__(self, pop_size, center_init, optimizer="adam", lr=0.05, sigma=0.03, T=100, K=10, lrate_decay=1.0,
                  lrate_limit=0.001, sigma_decay=1.0, sigma_limit=0.01, sigma_lrate=0.2, init_min=0.0, init_max=0.0,
                  clip_min=None, clip_max=None):
@@ -729,6 +766,8 @@ class Noise_reuse_es(_ESBase):
 class PersistentES(_ESBase):
     """Persistent ES (Vicol et al. 2021): unbiased gradients for truncated unrolls by
     accumulating the perturbations applied so far within an episode."""
+
+    dimension_separable = True
 
     def __init__(self, pop_size, center_init, optimizer="adam", lr=0.05, sigma=0.03, T=100, K=10, lrate_decay=1.0,
                  lrate_limit=0.001, sigma_decay=1.0, sigma_limit=0.01, sigma_lrate=0.2, sigma_max_change=0.2,

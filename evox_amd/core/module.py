@@ -194,6 +194,18 @@ class Stateful:
         return len(_tree.tree_leaves(self)[0])
 
 
+def clone_module(module):
+    """A copy of ``module`` with its own node ids: the module and every sub-module below it are shallow-copied (tensors
+    and other hyper-parameters stay shared).  A plain ``copy.copy`` would share the sub-module objects, and with them
+    their node ids, between the copies."""
+    import copy
+
+    new = copy.copy(module)
+    for name, sub, _ in module._submodules():
+        object.__setattr__(new, name, clone_module(sub))
+    return new
+
+
 def _stack_leaves(xs, axis: int = 0):
     x0 = xs[0]
     if isinstance(x0, torch.Tensor):
@@ -203,17 +215,16 @@ def _stack_leaves(xs, axis: int = 0):
 
 class ModuleStack(Stateful):
     """An ordered group of modules initialised as children ``m0, m1, …`` (each with its own
-    PRNG key and state).  A module object listed twice is shallow-copied so that every member
-    has its own node id."""
+    PRNG key and state).  A module object listed twice is copied (with its sub-modules) so that every member
+    has its own node ids."""
 
     def __init__(self, members):
         super().__init__()
-        import copy
         seen = set()
         self._names = []
         for i, m in enumerate(members):
             if id(m) in seen:
-                m = copy.copy(m)
+                m = clone_module(m)
             seen.add(id(m))
             name = f"m{i:04d}"
             setattr(self, name, m)
