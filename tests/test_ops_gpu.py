@@ -2046,7 +2046,12 @@ def test_graph_step_auto_measures_and_keeps_the_faster_way():
     assert torch.equal(a.population, e.population) and torch.equal(a.fitness, e.fitness)
     assert int(sa.generation) == int(se.generation) == 60
     # a step that reads back to the host cannot be recorded: eager, and said so
-    wx, sx = run("auto", lambda: algorithms.XNES(init_mean=torch.zeros(10, device=dev), init_covar=torch.eye(10, device=dev), pop_size=32))
+    class HostReadingPSO(algorithms.PSO):
+        def tell(self, state, fitness):
+            float(fitness.min())                       # device -> host read in the middle of the step
+            return super().tell(state, fitness)
+
+    wx, sx = run("auto", lambda: HostReadingPSO(lb, ub, 64))
     assert wx.graph_choice["mode"] == "eager" and wx.graph_step is False and "reason" in wx.graph_choice
     assert int(sx.generation) == 60
 
