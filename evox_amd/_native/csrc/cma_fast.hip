@@ -250,6 +250,8 @@ struct PathConst { float cs, cc, mueff, cm, damps, chiN, c1, cmu; };
 struct CovFast {
   const float* ws;          // K-split slabs of the rank-mu product
   int splits;
+  const float* packed;      // or: the rank-mu term summed already, as tile-packed upper triangle (row-sharded generation)
+  const float* poison;      // optional, one float: positive = some process dropped selected rows, the result becomes NaN
   const float *C, *mean, *step, *whitened, *ps, *pc, *sigma, *iter;
   const float* prev_rec;    // record of the previous factorisation: [4] = its scale estimate for this call
   PathConst k;
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256) void cov_fast_kernel(CovFast a) {
   const float s_in = a.prev_rec[4];
   const float s = (s_in > 0.f && s_in < 3.0e38f) ? s_in : 1.f;
   const float is = 1.f / s;
+  const bool bad = a.poison != nullptr && a.poison[0] > 0.f;
   if (blockIdx.x == 0) {
     const float sigma_new = sg * expf((a.k.cs / a.k.damps) * (norm / a.k.chiN - 1.f));
     for (int c = threadIdx.x; c < n; c += 256) {
@@ -335,23 +338,29 @@ __global__ __launch_bounds__(256) void cov_fast_kernel(CovFast a) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (r < n && cc < n) {                          // n is a multiple of 4: the quad is inside or outside as a whole
       const long long e = (long long)r * n + cc;
-      float4 g[MAXS];
+      float4 sum;
+      if (a.packed != nullptr) {
+        sum = *reinterpret_cast<const float4*>(a.packed + (long long)blockIdx.x * 4096 + rl * 64 + 4 * q);
+      } else {
+        float4 g[MAXS];
 #pragma unroll
-      for (int t = 0; t < MAXS; ++t)
-        g[t] = t < a.splits ? *reinterpret_cast<const float4*>(a.ws + t * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int t = MAXS; t < a.splits; ++t) {
-        const float4 u = *reinterpret_cast<const float4*>(a.ws + t * slab + e);
-        g[0].x += u.x; g[0].y += u.y; g[0].z += u.z; g[0].w += u.w;
+        for (int t = 0; t < MAXS; ++t)
+          g[t] = t < a.splits ? *reinterpret_cast<const float4*>(a.ws + t * slab + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = MAXS; t < a.splits; ++t) {
+          const float4 u = *reinterpret_cast<const float4*>(a.ws + t * slab + e);
+          g[0].x += u.x; g[0].y += u.y; g[0].z += u.z; g[0].w += u.w;
+        }
+        sum = g[0];
+#pragma unroll
+        for (int t = 1; t < MAXS; ++t) { sum.x += g[t].x; sum.y += g[t].y; sum.z += g[t].z; sum.w += g[t].w; }
       }
       const float4 cv = *reinterpret_cast<const float4*>(a.C + e);
-      float4 sum = g[0];
-#pragma unroll
-      for (int t = 1; t < MAXS; ++t) { sum.x += g[t].x; sum.y += g[t].y; sum.z += g[t].z; sum.w += g[t].w; }
       const float pr = pc_new(r);
       v[0] = fmaf(alpha, cv.x, fmaf(a.k.c1, pr * pcc[0], a.k.cmu * sum.x));
       v[1] = fmaf(alpha, cv.y, fmaf(a.k.c1, pr * pcc[1], a.k.cmu * sum.y));
       v[2] = fmaf(alpha, cv.z, fmaf(a.k.c1, pr * pcc[2], a.k.cmu * sum.z));
       v[3] = fmaf(alpha, cv.w, fmaf(a.k.c1, pr * pcc[3], a.k.cmu * sum.w));
+      if (bad) v[0] = v[1] = v[2] = v[3] = __builtin_nanf("");
       if (i != j) {
         float y[4];
         uint32_t b0[4], b1[4];
@@ -493,6 +502,12 @@ __global__ __launch_bounds__(256) void finish_kernel(Finish f) {
   }
 }
 
+// Side jobs on their own (row-sharded generation: the whitening product has no rank-mu launch to ride along with).
+__global__ __launch_bounds__(1024) void side_only_kernel(FastSide side) {
+  extern __shared__ __attribute__((aligned(16))) char side_smem[];
+  side((int)blockIdx.x, (int)gridDim.x, side_smem);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------------------------
@@ -545,7 +560,21 @@ template <int WM, int WN>
 static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   const int n = t->n;
   const long long nn = (long long)n * n;
-  int e = evox_hip_rank_sort_scalar(t->fitness, t->lam, t->order, nullptr, st);
+  int e = 0;
+  int splits = 0;
+  if (t->sharded) {
+    // the selected rows were reduced on every process and summed already: only the whitening product of the summed
+    // mean shift is left of the front part
+    FastSide side{};
+    side.n = n;
+    const int wgs = 48;
+    side.mv[0] = SideMatvec{t->invsqrtC, t->step, nullptr, nullptr, t->whitened, nullptr, 0, 0, wgs};
+    const size_t smem = (size_t)(((n + 63) & ~63) + 128) * sizeof(float);
+    side_only_kernel<<<wgs, 1024, smem, st>>>(side);
+    e = last_launch_status();
+    if (e) return e;
+  } else {
+  e = evox_hip_rank_sort_scalar(t->fitness, t->lam, t->order, nullptr, st);
   if (e) return e;
   e = evox_hip_cma_gather_t(t->pop, t->ldpop, t->order, t->mean, t->rowscale, t->sigma, t->yt, t->ldmu, t->colsum, t->rb,
                             nullptr, t->mu, n, t->lam, st);
@@ -556,7 +585,7 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   // side job (mean shift + whitening product: it wants three dozen of them) leaves
   const int ks = ksteps_of(t->mu);
   const int T128 = (n + 127) / 128;
-  int splits = (kNumCU - 36) / upper_tiles(T128);
+  splits = (kNumCU - 36) / upper_tiles(T128);
   {
     const int most = evox_hip_bf16_cov_splits(n, t->mu);       // what the work space is sized for
     splits = splits > most ? most : (splits < 1 ? 1 : splits);
@@ -585,6 +614,7 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
     e = launch<128, 128, 2, 4, 1, true, 3, EpiSlab, FastSide>(g, epi, upper_tiles(T), splits, 1, st, side, side_wgs);
     if (e) return e;
   }
+  }
 
   // ---- covariance, paths, scaled planes ----
   const long long plane = (long long)n * t->ldn;
@@ -598,6 +628,10 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
     CovFast a{};
     a.ws = t->cov_ws;
     a.splits = splits;
+    if (t->sharded) {
+      a.packed = t->gram;
+      a.poison = t->poison;
+    }
     a.C = t->C; a.mean = t->mean; a.step = t->step; a.whitened = t->whitened; a.ps = t->ps; a.pc = t->pc;
     a.sigma = t->sigma; a.iter = t->iter_dev; a.prev_rec = t->prev_rec;
     a.k = PathConst{t->consts[0], t->consts[1], t->consts[2], t->consts[3], t->consts[4], t->consts[5], t->consts[6], t->consts[7]};
@@ -700,16 +734,19 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
   return last_launch_status();
 }
 
-// The folded tell.  Preconditions (the caller falls back to evox_hip_cma_tell otherwise): single-process generation,
+// The folded tell.  Preconditions (the caller falls back to evox_hip_cma_tell otherwise): a single-process generation, or
+// the part of a row-sharded one that follows the all-reduce (summed mean shift in `step`, tile-packed summed rank-mu term);
 // factorisation by the symmetric two-plane driver with ONE fifth-order step, estimate-scaled (not the safe norm bound),
 // n a multiple of 4, and a previous record whose scale entry is valid (any earlier call of either driver).
 EVOX_API int evox_hip_cma_tell_fast(const CmaTell* t, const CmaFast* f, void* stream) {
-  if (t == nullptr || f == nullptr || t->sharded || !t->factor || !t->ns_symmetric || t->ns_iters != 1 || t->ns_safe ||
+  if (t == nullptr || f == nullptr || !t->factor || !t->ns_symmetric || t->ns_iters != 1 || t->ns_safe ||
       t->ns_planes != 2 || (t->n & 3) || t->n <= 0 || t->b16_o == nullptr || t->prev_rec == nullptr ||
       t->ctrl_vec == nullptr)
     return (int)hipErrorInvalidValue;
   if (t->ldn < (int64_t)((t->n + 63) / 64) * 64 || (t->ldn & 7) || ((uintptr_t)t->planes & 15) || ((uintptr_t)t->b16_o & 15) ||
       ((uintptr_t)t->ns_f32 & 15) || ((uintptr_t)t->C & 15) || ((uintptr_t)t->C_o & 15))
+    return (int)hipErrorInvalidValue;
+  if (t->sharded && (t->gram == nullptr || !t->gram_packed || ((uintptr_t)t->gram & 15) || t->step == nullptr))
     return (int)hipErrorInvalidValue;
   if (f->key != nullptr && (f->z_next == nullptr || f->keys_next == nullptr || ((uintptr_t)f->z_next & 7))) return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;

@@ -177,16 +177,30 @@ __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __res
                                                             int64_t* __restrict__ order_out, float* __restrict__ w_out,
                                                             float* __restrict__ overflow) {
   // wavefront w owns the rows [w·per, (w+1)·per): 64 consecutive rows per step (coalesced), selected rows counted and
-  // placed with ballots; one barrier for the offsets of the sixteen wavefronts
+  // placed with ballots; one barrier for the offsets of the sixteen wavefronts.  Up to 16 steps per wavefront (16 384
+  // rows) the ranks are loaded once, all loads in flight together, and kept in registers for the placement.
   __shared__ int s_tot[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int per = ((local + 15) / 16 + 63) / 64 * 64;
   const int first = min(w * per, local), last = min(first + per, local);
+  constexpr int kHeld = 16;
+  const bool held = per <= kHeld * 64;
+  int rk[kHeld];
   int cnt = 0;
-  for (int i0 = first; i0 < last; i0 += 64) {
-    const int i = i0 + lane;
-    const bool sel = i < last && local_rank(ranking, partial, slices, lo, local, i) < mu;
-    cnt += __popcll(__ballot(sel));
+  if (held) {
+#pragma unroll
+    for (int u = 0; u < kHeld; ++u) {
+      const int i = first + u * 64 + lane;
+      rk[u] = i < last ? local_rank(ranking, partial, slices, lo, local, i) : mu;
+    }
+#pragma unroll
+    for (int u = 0; u < kHeld; ++u) cnt += __popcll(__ballot(rk[u] < mu));
+  } else {
+    for (int i0 = first; i0 < last; i0 += 64) {
+      const int i = i0 + lane;
+      const bool sel = i < last && local_rank(ranking, partial, slices, lo, local, i) < mu;
+      cnt += __popcll(__ballot(sel));
+    }
   }
   if (lane == 0) s_tot[w] = cnt;
   __syncthreads();
@@ -195,14 +209,27 @@ __global__ __launch_bounds__(1024) void select_local_kernel(const int64_t* __res
     if (q < w) pos += s_tot[q];
     total += s_tot[q];
   }
-  for (int i0 = first; i0 < last; i0 += 64) {
-    const int i = i0 + lane;
-    const int r = i < last ? local_rank(ranking, partial, slices, lo, local, i) : mu;
-    const bool sel = r < mu;
-    const unsigned long long m = __ballot(sel);
-    const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
-    if (sel && at < keep) { order_out[at] = i; w_out[at] = sqrt_w_padded[r]; }
-    pos += __popcll(m);
+  if (held) {
+#pragma unroll
+    for (int u = 0; u < kHeld; ++u) {
+      const int i = first + u * 64 + lane;
+      const int r = rk[u];
+      const bool sel = r < mu;
+      const unsigned long long m = __ballot(sel);
+      const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+      if (sel && at < keep) { order_out[at] = i; w_out[at] = sqrt_w_padded[r]; }
+      pos += __popcll(m);
+    }
+  } else {
+    for (int i0 = first; i0 < last; i0 += 64) {
+      const int i = i0 + lane;
+      const int r = i < last ? local_rank(ranking, partial, slices, lo, local, i) : mu;
+      const bool sel = r < mu;
+      const unsigned long long m = __ballot(sel);
+      const int at = pos + __popcll(m & ((1ull << lane) - 1ull));
+      if (sel && at < keep) { order_out[at] = i; w_out[at] = sqrt_w_padded[r]; }
+      pos += __popcll(m);
+    }
   }
   for (int k = total + (int)threadIdx.x; k < keep; k += 1024) { order_out[k] = 0; w_out[k] = 0.f; }
   if (threadIdx.x < 4) overflow[threadIdx.x] = (threadIdx.x == 0 && total > keep) ? 1.f : 0.f;   // the message's four trailing floats

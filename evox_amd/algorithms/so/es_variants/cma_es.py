@@ -27,7 +27,7 @@ from ....ops import sort as _sort
 class CMAES(Algorithm):
     def __init__(self, center_init, init_stdev, pop_size: Optional[int] = None, recombination_weights=None, cm=1,
                  decomp_per_iter: Optional[int] = None, precision: str = "fp32", eigh_method: Optional[str] = None,
-                 decomposition: str = "eigh"):
+                 decomposition: str = "eigh", deterministic: bool = False, deterministic_blocks: int = 8):
         """
         center_init            initial mean, shape (dim,); its device is where the run lives.
         init_stdev             initial step size σ > 0.
@@ -38,6 +38,12 @@ class CMAES(Algorithm):
         precision              "fp32" or "bf16" inputs of the sampling / covariance GEMMs
                                (accumulation is always fp32).
         eigh_method            see ``evox_amd.ops.cma.decompose``.
+        deterministic          row-sharded runs (``ShardedWorkflow``) give the same bits for every number of
+                               processes that divides ``deterministic_blocks``: the population is handled in
+                               that many fixed row blocks, whichever process owns them (sampling, selection
+                               and the partial sums of the update per block; the blocks' sums are gathered and
+                               added in block order).  Costs a larger message (one partial covariance per
+                               block instead of one all-reduced sum) and smaller kernels.
         decomposition          "eigh": ``B``/``D`` are eigenvectors / sqrt-eigenvalues of ``C`` (the
                                tutorial's formulation).  "newton_schulz": the two matrix functions
                                the algorithm consumes, ``C^{1/2}`` (sampling) and ``C^{-1/2}``
@@ -56,6 +62,9 @@ class CMAES(Algorithm):
         self.cm = cm
         self.precision = precision
         self.eigh_method = eigh_method
+        # row-sharded runs: the same bits whatever the number of processes (see ``_tell_sharded_blocks``)
+        self.deterministic = bool(deterministic)
+        self.deterministic_blocks = int(deterministic_blocks)
         if decomposition not in ("eigh", "newton_schulz"):
             raise ValueError("decomposition must be 'eigh' or 'newton_schulz'")
         self.decomposition = decomposition
@@ -366,12 +375,76 @@ class CMAES(Algorithm):
             ws = self._workspace(local, min(consts["keep"], local))
             population, key, count = self._generation(ws).ask(state.key, self._factor_bf16(state, ws), state.mean, state.sigma,
                                                               local, rank * local, False, count=state.count_iter_dev)
+        elif self.deterministic:
+            # library GEMMs choose their kernels (and with them the order of summation) by shape: every block is sampled
+            # by a call of its own, of the same shape on any number of processes
+            blk, mine = self._det_blocks(world)
+            key, sample_key = self._keys(state)
+            population = torch.cat([self._sample(state, key, sample_key, blk, row_offset=rank * local + j * blk,
+                                                 mu=min(self._shard_consts(blk, state.mean.device)["keep"], blk))
+                                    for j in range(mine)])
+            count = state.count_iter_dev + 1
         else:
             key, sample_key = self._keys(state)
             population = self._sample(state, key, sample_key, local, row_offset=rank * local, mu=min(consts["keep"], local))
             count = state.count_iter_dev + 1
         return population, state.replace(population=population, count_iter=state.count_iter + 1,
                                          count_iter_dev=count, key=key)
+
+    def _det_blocks(self, world: int):
+        nb = self.deterministic_blocks
+        if nb <= 0 or self.pop_size % nb or nb % world:
+            raise ValueError(f"deterministic=True: pop_size {self.pop_size} must be a multiple of deterministic_blocks {nb}, "
+                             f"and that a multiple of the number of processes {world}")
+        return self.pop_size // nb, nb // world
+
+    def _tell_sharded_blocks(self, state, fitness, rank: int, world: int):
+        """The row-sharded tell with a summation order that does not depend on the number of processes: every fixed row
+        block contributes its own partial mean shift and rank-mu term (computed by calls of one shape), the partial sums
+        of all blocks are all-gathered and added in block order on every process, and the rest is replicated work on
+        identical inputs."""
+        from ....core import distributed as dist
+
+        blk, mine = self._det_blocks(world)
+        local = self.pop_size // world
+        pop = state.population
+        dev, n = pop.device, self.dim
+        ranking = _sort.argsort_with_rank(fitness)[1]
+        native = self._native_calls and self._bf16_kernels and pop.is_cuda and self._sqrt_w is not None and n % 4 == 0
+        nn = _b16.packed_upper_floats(n) if native else n * n
+        length = -(-(nn + n + 4) // 4) * 4                      # rows of the message stay 16-byte aligned
+        msgs = torch.zeros((mine, length), dtype=torch.float32, device=dev)
+        consts = self._shard_consts(blk, dev)
+        keep = min(consts["keep"], blk)
+        ws = self._workspace(blk, keep) if native else None
+        padded = None
+        for j in range(mine):
+            lo, rows, m = rank * local + j * blk, pop[j * blk:(j + 1) * blk], msgs[j]
+            if native:
+                from ....ops import cma_native as _nat
+                order, sqrt_w = _nat.select_local(ranking, lo, blk, self.mu, keep, consts["sqrt_w_padded"], m[nn + n:nn + n + 4])
+                _b16.elite_factor_t(rows, order, state.mean, state.sigma, sqrt_w, ws, out=m[nn:nn + n])
+                _b16.gram_packed(ws, m[:nn])
+            else:
+                if padded is None:
+                    padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)]).to(dev)
+                w_b = padded[ranking[lo:lo + blk]]
+                d = rows - state.mean
+                y = d / state.sigma
+                m[nn:nn + n] = w_b @ d
+                m[:nn] = ((y * w_b[:, None]).T @ y).reshape(-1)
+        full = dist.all_gather(msgs, dist.POP_AXIS_NAME, axis=0, tiled=True) if world > 1 else msgs
+        packed = full[0].clone()
+        for b in range(1, full.shape[0]):
+            packed += full[b]
+        if native:
+            return self._tell_native(state, None, reduced=(packed[nn:nn + n], packed[:nn], packed[nn + n:nn + n + 4]), ws=ws)
+        step_sum, gram = packed[nn:nn + n], packed[:nn].view(n, n)
+        mean = state.mean + self.cm * step_sum
+        ps, pc, hsig, sigma = self._paths(state, mean)
+        alpha = (1 - self.c1 - self.cmu) + self.c1 * (1 - hsig) * self.cc * (2 - self.cc)
+        C = alpha * state.C + self.c1 * torch.outer(pc, pc) + self.cmu * gram
+        return self._finish_tell(state, mean, ps, pc, C, sigma, None)
 
     def _shard_consts(self, local: int, device):
         """Per-process constants of the sharded tell (built once): sqrt of the recombination weights
@@ -392,6 +465,8 @@ class CMAES(Algorithm):
         themselves) — spares the sort of the whole gathered fitness vector."""
         from ....core import distributed as dist
 
+        if self.deterministic:
+            return self._tell_sharded_blocks(state, fitness, rank, world)
         local = self.pop_size // world
         pop = state.population
         ws = None

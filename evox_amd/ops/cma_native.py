@@ -147,6 +147,7 @@ class Generation:
         # (key tensor of the next ask, its split, index of the buffer with its draws, row window, made on the side
         # stream?, generation counter of the next ask | None)
         self._ahead = None
+        self._window = None              # (rows, row offset) of the latest ask
         self._side = None
         self._events = None
 
@@ -181,6 +182,7 @@ class Generation:
         a.key, a.keys_out, a.z, a.s16 = key.data_ptr(), keys_out.data_ptr(), ws._Z[zi].data_ptr(), s16.data_ptr()
         a.mean, a.sigma, a.x = mean.data_ptr(), sigma.data_ptr(), out.data_ptr()
         a.rows, a.row_offset = rows, row_offset
+        self._window = (rows, row_offset)
         count_out = None
         if count is not None and count_ahead is not None:
             count_out = count_ahead              # the tell that drew ahead advanced the counter as well
@@ -206,10 +208,13 @@ class Generation:
         return out, next_key, count_out
 
     def _use_fast(self, reduced, factor, plan, n: int) -> bool:
-        """The folded launch sequence applies to a single-process generation whose factorisation is ONE fifth-order step
-        of the symmetric two-plane driver with the estimate scaling, from the third call on (the scale is the estimate
-        the previous call left in its record)."""
-        return (reduced is None and bool(factor) and plan is not None and bool(plan["symmetric"]) and plan["used"] == 1
+        """The folded launch sequence applies to a generation (single-process, or the part of a row-sharded one behind the
+        all-reduce when the rank-mu term arrives tile-packed) whose factorisation is ONE fifth-order step of the symmetric
+        two-plane driver with the estimate scaling, from the third call on (the scale is the estimate the previous call
+        left in its record)."""
+        if reduced is not None and (reduced[1].dim() != 1 or os.environ.get("EVOX_AMD_CMA_FAST_SHARDED", "1") == "0"):
+            return False
+        return (bool(factor) and plan is not None and bool(plan["symmetric"]) and plan["used"] == 1
                 and not plan["use_safe"] and plan["calls"] >= 2 and self.ws.ns_planes == 2 and n % 4 == 0
                 and os.environ.get("EVOX_AMD_CMA_FAST", "1") != "0")
 
@@ -287,16 +292,25 @@ class Generation:
         if self._use_fast(reduced, factor, plan, n):
             f = self._fast
             f.wide = int(os.environ.get("EVOX_AMD_CMA_WIDE", "1") == "1")
-            f.key = None
-            if not torch.cuda.is_current_stream_capturing() and os.environ.get("EVOX_AMD_CMA_DRAW_AHEAD", "1") != "0":
+            f.key = f.count_in = f.count_next = None
+            window = (ws.lam, 0) if reduced is None else self._window
+            ahead = self._ahead
+            if torch.cuda.is_current_stream_capturing() or os.environ.get("EVOX_AMD_CMA_DRAW_AHEAD", "1") == "0" or window is None:
+                pass
+            elif ahead is not None and ahead[0] is state.key and ahead[3] == window and len(ahead) == 5 and not ahead[4]:
+                # the draws were issued underneath the all-reduce already: only the generation counter is left to advance
+                count_next = torch.empty((), dtype=torch.float32, device=dev)
+                f.count_in, f.count_next = state.count_iter_dev.data_ptr(), count_next.data_ptr()
+                self._ahead = ahead + (count_next,)
+            elif ahead is None:
                 # the next generation's draws and key split ride along with the factorisation's products
                 zi = ws._z_next ^ 1
                 keys_next = torch.empty((2, 2), dtype=torch.int32, device=dev)
                 count_next = torch.empty((), dtype=torch.float32, device=dev)
                 f.key, f.z_next, f.keys_next = state.key.data_ptr(), ws._Z[zi].data_ptr(), keys_next.data_ptr()
                 f.count_in, f.count_next = state.count_iter_dev.data_ptr(), count_next.data_ptr()
-                f.row_offset, f.rows = 0, ws.lam
-                self._ahead = (state.key, keys_next, zi, (ws.lam, 0), False, count_next)
+                f.rows, f.row_offset = window
+                self._ahead = (state.key, keys_next, zi, window, False, count_next)
             self.fast_calls += 1
             check(hip().evox_hip_cma_tell_fast(ctypes.addressof(t), ctypes.addressof(f), stream_of(pop)), "cma_tell_fast")
         else:

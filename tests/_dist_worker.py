@@ -32,9 +32,13 @@ def main():
     c = torch.full((dim,), 3.0, device=dev)
     lb, ub = torch.full((dim,), -10.0, device=dev), torch.full((dim,), 10.0, device=dev)
     result = {}
-    if case in ("cmaes", "cmaes_resync", "cmaes_wide", "openes", "pgpe", "pso_replicated", "pso", "ars", "des", "snes", "sepcmaes", "maes"):
+    if case in ("cmaes", "cmaes_det", "cmaes_det_wide", "cmaes_resync", "cmaes_wide", "openes", "pgpe", "pso_replicated", "pso", "ars", "des", "snes", "sepcmaes", "maes"):
         algo = {"cmaes_resync": lambda: A.CMAES(c, 1.0, pop_size=16),
                 "cmaes": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh")),
+                "cmaes_det": lambda: A.CMAES(c, 1.0, pop_size=16, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh"),
+                                             deterministic=True),
+                "cmaes_det_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh"),
+                                                  precision=os.environ.get("EVOX_TEST_PRECISION", "fp32"), deterministic=True),
                 # local shares wide enough that only the rank-ordered head of the local rows is processed
                 "cmaes_wide": lambda: A.CMAES(c, 1.0, pop_size=2048, decomposition=os.environ.get("EVOX_TEST_DECOMP", "eigh"),
                                               precision=os.environ.get("EVOX_TEST_PRECISION", "fp32")),
@@ -56,11 +60,11 @@ def main():
                 a = state.get_child_state("algorithm")
                 state = state.replace_child("algorithm", a.replace(C=a.C * 1.001, sigma=a.sigma * 1.001))
         alg = state.get_child_state("algorithm")
-        vec = alg.mean if case in ("cmaes", "cmaes_resync", "cmaes_wide", "sepcmaes", "maes") else (alg.global_best_location if case == "pso" else (alg.population[0] if case == "pso_replicated" else alg.center))
+        vec = alg.mean if case in ("cmaes", "cmaes_det", "cmaes_det_wide", "cmaes_resync", "cmaes_wide", "sepcmaes", "maes") else (alg.global_best_location if case == "pso" else (alg.population[0] if case == "pso_replicated" else alg.center))
         result = {"vec": vec.tolist(), "world": state.world_size, "rank": state.rank,
                   "row_sharded": wf.row_sharded, "best": float(mon.get_best_fitness()),
-                  "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_resync", "cmaes_wide", "sepcmaes") else None,
-                  "cov": alg.C.reshape(-1).tolist() if case == "cmaes_resync" else None,
+                  "local_rows": int(alg.population.shape[0]) if case in ("cmaes", "cmaes_det", "cmaes_det_wide", "cmaes_resync", "cmaes_wide", "sepcmaes") else None,
+                  "cov": alg.C.reshape(-1).tolist() if case in ("cmaes_resync", "cmaes_det") else None,
                   "rows": alg.population.tolist() if case == "pso" else None}
     elif case == "sharded_ckpt":
         path = os.environ["EVOX_TEST_CKPT"]

@@ -1417,6 +1417,51 @@ def test_cmaes_folded_tell_matches_launch_chain(cuda, n, lam, wide, monkeypatch)
     assert torch.equal(p1, p2) and torch.equal(n1.key, n2.key) and torch.equal(n1.count_iter_dev, n2.count_iter_dev)
 
 
+@pytest.mark.parametrize("n,lam", [(1000, 4000), (256, 1024)])
+def test_cmaes_row_sharded_tell_takes_the_folded_tail(cuda, n, lam, monkeypatch):
+    """The part of a row-sharded tell behind the all-reduce (whitening product, paths, covariance from the tile-packed
+    summed rank-mu term, factorisation) runs the folded launch sequence too: same state as the launch chain on the same
+    reduced message, the single-process tell's state to rounding, the next ask's draws made ahead bit-equal to draws made
+    on the spot, and a poisoned message (rows dropped somewhere) turns the covariance into NaNs."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems
+    from evox_amd.workflows import ShardedWorkflow
+
+    algo = algorithms.CMAES(torch.full((n,), 2.0, device=cuda), 1.0, pop_size=lam, decomposition="newton_schulz", precision="bf16")
+    prob = problems.numerical.Ackley()
+    wf = ShardedWorkflow(algo, prob)
+    s = wf.init(ex.PRNGKey(5))
+    for _ in range(30):
+        s = wf.step(s)
+    gens = list(algo._generations.values())
+    assert sum(g.fast_calls for g in gens) >= 5
+    a = s.get_child_state("algorithm")
+    pop, a2 = algo.ask_sharded(a, 0, 1)
+    fit, _ = prob.evaluate(None, pop)
+    monkeypatch.setenv("EVOX_AMD_CMA_FAST_SHARDED", "0")
+    slow = algo.tell_sharded(a2, fit, 0, 1)
+    monkeypatch.setenv("EVOX_AMD_CMA_FAST_SHARDED", "1")
+    before = sum(g.fast_calls for g in gens)
+    fast = algo.tell_sharded(a2, fit, 0, 1)
+    assert sum(g.fast_calls for g in gens) == before + 1
+    single = algo.tell(a2, fit)
+    torch.cuda.synchronize()
+    for other, tol in ((slow, 2e-5), (single, 1e-4)):
+        for k in ("mean", "ps", "pc", "sigma"):
+            assert torch.allclose(getattr(fast, k), getattr(other, k), rtol=tol, atol=1e-6), k
+        assert torch.allclose(fast.C, other.C, rtol=tol, atol=1e-6)
+    assert torch.equal(fast.C, fast.C.T) and torch.equal(fast.B, fast.B.T)
+    eye = torch.eye(n, device=cuda, dtype=torch.float64)
+    C64, S, Z = fast.C.double(), fast.B.double(), fast.invsqrtC.double()
+    assert float((S @ S - C64).norm() / C64.norm()) < 5e-4 and float((Z @ S - eye).norm() / n ** 0.5) < 5e-4
+    gen = next(g for g in gens if g._ahead is not None)
+    assert gen._ahead[0] is fast.key
+    p1, n1 = algo.ask_sharded(fast, 0, 1)
+    gen._ahead = None
+    p2, n2 = algo.ask_sharded(fast, 0, 1)
+    assert torch.equal(p1, p2) and torch.equal(n1.key, n2.key) and torch.equal(n1.count_iter_dev, n2.count_iter_dev)
+
+
 def test_newton_schulz_fifth_order_step_alone(cuda):
     """iters = 1: the fifth-order first step is the whole factorisation (covariances close to a multiple of the
     identity); the residual then comes from a probe vector and the guard still passes previous factors on."""
