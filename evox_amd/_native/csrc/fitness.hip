@@ -32,14 +32,34 @@ template <int LPR> __device__ __forceinline__ float group_prod(float v) {
 
 struct Acc { float s0, s1; };
 
+// cos(2 pi x): x is reduced exactly to r = x - rint(x) in [-1/2, 1/2], folded to s in [0, 1/4] (cos(2 pi r) =
+// -cos(2 pi (1/2 - |r|)) beyond a quarter turn), and the even Taylor polynomial through theta^12 is summed on theta in
+// [0, pi/2]: truncation below 7e-9, a dozen instructions instead of the general routine's two dozen (this evaluation is
+// what bounds the Ackley / Rastrigin passes, not the memory traffic).
+__device__ __forceinline__ float cos2pi(float x) {
+  const float r = x - rintf(x);
+  const float a = fabsf(r);
+  const bool flip = a > 0.25f;
+  const float sft = flip ? 0.5f - a : a;
+  const float u = 39.47841760435743f * sft * sft;          // theta^2
+  float p = 2.08767569878681e-9f;                           // 1 / 12!
+  p = fmaf(p, u, -2.755731922398589e-7f);                   // -1 / 10!
+  p = fmaf(p, u, 2.48015873015873e-5f);                     // 1 / 8!
+  p = fmaf(p, u, -1.388888888888889e-3f);                   // -1 / 6!
+  p = fmaf(p, u, 4.166666666666666e-2f);                    // 1 / 4!
+  p = fmaf(p, u, -0.5f);
+  p = fmaf(p, u, 1.0f);
+  return flip ? -p : p;
+}
+
 template <int FUNC> __device__ __forceinline__ void accumulate(Acc& a, float x, float xnext, int j, bool has_next) {
   if constexpr (FUNC == kSphere) {
     a.s0 = fmaf(x, x, a.s0);
   } else if constexpr (FUNC == kAckley) {
     a.s0 = fmaf(x, x, a.s0);
-    a.s1 += cospif(2.0f * x);          // generic c handled by the caller when c != 2*pi
+    a.s1 += cos2pi(x);                 // generic c handled by the caller when c != 2*pi
   } else if constexpr (FUNC == kRastrigin) {
-    a.s0 += fmaf(x, x, -10.0f * cospif(2.0f * x));
+    a.s0 += fmaf(x, x, -10.0f * cos2pi(x));
   } else if constexpr (FUNC == kRosenbrock) {
     if (has_next) {
       const float t = xnext - x * x, u = x - 1.0f;
@@ -76,12 +96,25 @@ __global__ __launch_bounds__(256) void so_fitness_kernel(const T* __restrict__ x
       if (vec4) {
         if constexpr (sizeof(T) == 4 && FUNC != kRosenbrock) {
           const float4* rp4 = reinterpret_cast<const float4*>(rp);
-          for (int j = sub; j < (dim >> 2); j += LPR) {
-            const float4 v = rp4[j];
-            accumulate<FUNC>(a, v.x, 0.f, 4 * j, false);
-            accumulate<FUNC>(a, v.y, 0.f, 4 * j + 1, false);
-            accumulate<FUNC>(a, v.z, 0.f, 4 * j + 2, false);
-            accumulate<FUNC>(a, v.w, 0.f, 4 * j + 3, false);
+          const int nq = dim >> 2;
+          // four loads of the row in flight before the first transcendental (4 KiB per wavefront)
+          for (int j0 = 0; j0 < nq; j0 += 4 * LPR) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u * LPR + sub;
+              v[u] = j < nq ? rp4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int j = j0 + u * LPR + sub;
+              if (j < nq) {
+                accumulate<FUNC>(a, v[u].x, 0.f, 4 * j, false);
+                accumulate<FUNC>(a, v[u].y, 0.f, 4 * j + 1, false);
+                accumulate<FUNC>(a, v[u].z, 0.f, 4 * j + 2, false);
+                accumulate<FUNC>(a, v[u].w, 0.f, 4 * j + 3, false);
+              }
+            }
           }
         }
       } else if constexpr (FUNC == kAckley) {
@@ -128,7 +161,7 @@ int launch(const T* x, float* out, int64_t n, int dim, int64_t pitch, float p0, 
   if (dim >= 128) {
     const int64_t waves = n;
     int grid = (int)((waves + 3) / 4);
-    if (grid > kNumCU * 16) grid = kNumCU * 16;
+    if (grid > kNumCU * 8) grid = kNumCU * 8;           // every wavefront resident at once (eight per SIMD)
     so_fitness_kernel<FUNC, 64, T><<<grid, block, 0, st>>>(x, out, n, dim, pitch, p0, p1, p2);
   } else if (dim >= 12) {
     const int64_t waves = (n + 3) / 4;
