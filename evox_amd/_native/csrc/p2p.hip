@@ -17,6 +17,10 @@
 // after it has seen every peer's flag for s, and a peer raises its flag for s only after its own
 // stream has finished consuming slot (s−1)&1 — the slot that s+1 overwrites.
 //
+// The sequence number lives on the device: every kernel of a collective derives it from the same counter word, and the
+// last workgroup of the collective's final kernel advances the counter.  No launch argument changes from one collective
+// to the next, so a recorded HIP graph that contains collectives replays correctly (every process replays in step).
+//
 // Waiting is bounded: the wait kernel polls a limited number of times, then records a time-out in
 // an error word (device copy and a host-visible copy), fills its share of the output with NaNs and finishes, so a
 // missing peer can never leave waves spinning on the GPU nor hand uninitialised memory to the caller.  After a
@@ -34,6 +38,25 @@ constexpr unsigned int kNaNBits = 0x7FC00000u;
 // which = slot (messages, first phase) or 2 + slot (reduced chunks, second phase)
 __device__ __forceinline__ unsigned int* flag_ptr(char* base, int which, int rank) {
   return reinterpret_cast<unsigned int*>(base) + which * kMaxWorld + rank;
+}
+
+// sequence number of the collective in flight (0 is the flags' initial value and never used) and its slot
+__device__ __forceinline__ unsigned int next_seq(const unsigned int* seq_dev) {
+  const unsigned int s = *seq_dev + 1u;
+  return s == 0u ? 2u : s;                               // wrap-around keeps the slots alternating
+}
+
+// The last workgroup of a collective's final kernel: advance the device-side sequence number (stream order puts the next
+// collective's first kernel behind this one).
+__device__ __forceinline__ void advance_seq(unsigned int* seq_dev, unsigned int seq, unsigned int* done_c) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int finished = atomicAdd(done_c, 1u) + 1u;
+    if (finished == gridDim.x) {
+      *done_c = 0u;
+      *seq_dev = seq;
+    }
+  }
 }
 
 // Threads 0..W-1 of a block poll the W flags (bounded); returns true on every thread when one of them gave up.
@@ -64,9 +87,12 @@ __device__ __forceinline__ void report_timeout(int* err, int* err_host) {
 // [p·chunk_words, min((p+1)·chunk_words, total))) into peer p's slot and, once every block of the column has
 // finished, publishes the sequence number there.
 __global__ __launch_bounds__(256) void p2p_put_kernel(const unsigned int* __restrict__ src, int64_t n_words,
-                                                      char* const* __restrict__ peer_base, int rank, int slot,
-                                                      int64_t slot_stride, int64_t max_bytes, unsigned int seq,
+                                                      char* const* __restrict__ peer_base, int rank,
+                                                      int64_t slot_stride, int64_t max_bytes,
+                                                      const unsigned int* __restrict__ seq_dev,
                                                       unsigned int* __restrict__ done, int64_t chunk_words) {
+  const unsigned int seq = next_seq(seq_dev);
+  const int slot = (int)(seq & 1u);
   const int p = blockIdx.y;
   char* base = peer_base[p];
   unsigned int* dst = reinterpret_cast<unsigned int*>(base + kHeaderBytes + slot * slot_stride + (int64_t)rank * max_bytes);
@@ -98,18 +124,22 @@ __global__ __launch_bounds__(256) void p2p_put_kernel(const unsigned int* __rest
 
 // Every block waits (bounded) for the W flags of this rank's slot, then takes part in the copy-out.
 // reduce == 0: out[r·n_words + i] = slot[r][i] (all-gather); reduce == 1: out[i] = Σ_r slot[r][i] as fp32.
-__global__ __launch_bounds__(256) void p2p_collect_kernel(char* __restrict__ base, int world, int slot,
+__global__ __launch_bounds__(256) void p2p_collect_kernel(char* __restrict__ base, int world,
                                                           int64_t slot_stride, int64_t max_bytes, int64_t n_words,
-                                                          unsigned int seq, unsigned int* __restrict__ out, int reduce,
+                                                          unsigned int* __restrict__ seq_dev, unsigned int* __restrict__ done_c,
+                                                          unsigned int* __restrict__ out, int reduce,
                                                           long long max_polls, int* __restrict__ err,
                                                           int* __restrict__ err_host) {
   __shared__ int timed_out;
+  const unsigned int seq = next_seq(seq_dev);
+  const int slot = (int)(seq & 1u);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (wait_flags(base, slot, world, seq, max_polls, &timed_out)) {
     // this block's share of the output is poisoned, never left uninitialised; the host raises
     report_timeout(err, err_host);
     const int64_t total = reduce ? n_words : n_words * world;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) out[i] = kNaNBits;
+    advance_seq(seq_dev, seq, done_c);
     return;
   }
   __threadfence_system();
@@ -129,18 +159,22 @@ __global__ __launch_bounds__(256) void p2p_collect_kernel(char* __restrict__ bas
         out[(int64_t)r * n_words + i] = __builtin_nontemporal_load(s + i);
     }
   }
+  advance_seq(seq_dev, seq, done_c);
 }
 
 // Second shot of the two-shot sum.  After the (bounded) wait for the W pieces of this rank's chunk, every block sums
 // its share and writes it into the reduced area of every peer; the last block to finish publishes the sequence number
 // to all of them.  A rank whose wait ran out sends NaNs — its peers must not wait for it in turn.
 __global__ __launch_bounds__(256) void p2p_reduce_bcast_kernel(char* __restrict__ base, char* const* __restrict__ peer_base,
-                                                               int world, int rank, int slot, int64_t slot_stride,
+                                                               int world, int rank, int64_t slot_stride,
                                                                int64_t max_bytes, int64_t red_offset, int64_t chunk_stride,
-                                                               int64_t len_words, unsigned int seq, long long max_polls,
+                                                               int64_t len_words, const unsigned int* __restrict__ seq_dev,
+                                                               long long max_polls,
                                                                unsigned int* __restrict__ done, int* __restrict__ err,
                                                                int* __restrict__ err_host) {
   __shared__ int timed_out;
+  const unsigned int seq = next_seq(seq_dev);
+  const int slot = (int)(seq & 1u);
   const bool bad = wait_flags(base, slot, world, seq, max_polls, &timed_out);
   if (bad) report_timeout(err, err_host);
   __threadfence_system();
@@ -168,16 +202,21 @@ __global__ __launch_bounds__(256) void p2p_reduce_bcast_kernel(char* __restrict_
 }
 
 // Third step: wait for the W reduced chunks and lay them out: out[r·chunk_words + i] = reduced[r][i].
-__global__ __launch_bounds__(256) void p2p_collect_chunks_kernel(char* __restrict__ base, int world, int slot,
+__global__ __launch_bounds__(256) void p2p_collect_chunks_kernel(char* __restrict__ base, int world,
                                                                  int64_t red_offset, int64_t chunk_stride,
-                                                                 int64_t chunk_words, int64_t n_words, unsigned int seq,
+                                                                 int64_t chunk_words, int64_t n_words,
+                                                                 unsigned int* __restrict__ seq_dev,
+                                                                 unsigned int* __restrict__ done_c,
                                                                  unsigned int* __restrict__ out, long long max_polls,
                                                                  int* __restrict__ err, int* __restrict__ err_host) {
   __shared__ int timed_out;
+  const unsigned int seq = next_seq(seq_dev);
+  const int slot = (int)(seq & 1u);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (wait_flags(base, 2 + slot, world, seq, max_polls, &timed_out)) {
     report_timeout(err, err_host);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) out[i] = kNaNBits;
+    advance_seq(seq_dev, seq, done_c);
     return;
   }
   __threadfence_system();
@@ -186,6 +225,7 @@ __global__ __launch_bounds__(256) void p2p_collect_chunks_kernel(char* __restric
     const int64_t r = i / chunk_words, k = i - r * chunk_words;
     out[i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(red + r * chunk_stride) + k);
   }
+  advance_seq(seq_dev, seq, done_c);
 }
 
 }  // namespace
@@ -229,8 +269,9 @@ EVOX_API int evox_hip_p2p_import(const void* handle, void** ptr) {
 EVOX_API int evox_hip_p2p_close(void* ptr) { return (int)hipIpcCloseMemHandle(ptr); }
 
 // peer_base: device array of W buffer addresses as seen from this process (own buffer at [rank])
-EVOX_API int evox_hip_p2p_put(const void* src, int64_t n_words, void* peer_base, int world, int rank, int slot,
-                              int64_t slot_stride, int64_t max_bytes, unsigned int seq, void* done, int64_t chunk_words,
+// seq_dev: the group's sequence counter on the device (one zero-initialised word; see the head of this file)
+EVOX_API int evox_hip_p2p_put(const void* src, int64_t n_words, void* peer_base, int world, int rank,
+                              int64_t slot_stride, int64_t max_bytes, const void* seq_dev, void* done, int64_t chunk_words,
                               void* stream) {
   if (n_words <= 0 || world < 1 || world > kMaxWorld || chunk_words < 0) return (int)hipErrorInvalidValue;
   const int64_t per_peer = chunk_words > 0 ? chunk_words : n_words;
@@ -239,31 +280,33 @@ EVOX_API int evox_hip_p2p_put(const void* src, int64_t n_words, void* peer_base,
   if (blocks < 1) blocks = 1;
   if (blocks > 64) blocks = 64;                         // W columns share the chip
   p2p_put_kernel<<<dim3(blocks, world), 256, 0, (hipStream_t)stream>>>(
-      (const unsigned int*)src, n_words, (char* const*)peer_base, rank, slot, slot_stride, max_bytes, seq,
-      (unsigned int*)done, chunk_words);
+      (const unsigned int*)src, n_words, (char* const*)peer_base, rank, slot_stride, max_bytes,
+      (const unsigned int*)seq_dev, (unsigned int*)done, chunk_words);
   return evox::last_launch_status();
 }
 
-EVOX_API int evox_hip_p2p_collect(void* own_base, int world, int slot, int64_t slot_stride, int64_t max_bytes,
-                                  int64_t n_words, unsigned int seq, void* out, int reduce, long long max_polls,
+// done_c: one zeroed counter word of the group (last-workgroup detection of the collective's final kernel)
+EVOX_API int evox_hip_p2p_collect(void* own_base, int world, int64_t slot_stride, int64_t max_bytes,
+                                  int64_t n_words, void* seq_dev, void* done_c, void* out, int reduce, long long max_polls,
                                   void* err, void* err_host, void* stream) {
   if (n_words <= 0 || world < 1 || world > kMaxWorld || max_polls < 1) return (int)hipErrorInvalidValue;
   const int64_t work = reduce ? n_words : n_words * world;
   int blocks = (int)((work + 1023) / 1024);
   if (blocks < 1) blocks = 1;
   if (blocks > 512) blocks = 512;
-  p2p_collect_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, world, slot, slot_stride, max_bytes,
-                                                             n_words, seq, (unsigned int*)out, reduce, max_polls,
-                                                             (int*)err, (int*)err_host);
+  p2p_collect_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, world, slot_stride, max_bytes, n_words,
+                                                             (unsigned int*)seq_dev, (unsigned int*)done_c,
+                                                             (unsigned int*)out, reduce, max_polls, (int*)err,
+                                                             (int*)err_host);
   return evox::last_launch_status();
 }
 
 // Second and third step of the two-shot sum (the first is evox_hip_p2p_put with chunk_words > 0).
 // red_offset: byte offset of the reduced area in every rank's buffer; done2: one zeroed counter.
-EVOX_API int evox_hip_p2p_two_shot_finish(void* own_base, void* peer_base, int world, int rank, int slot, int64_t slot_stride,
+EVOX_API int evox_hip_p2p_two_shot_finish(void* own_base, void* peer_base, int world, int rank, int64_t slot_stride,
                                           int64_t max_bytes, int64_t red_offset, int64_t chunk_stride, int64_t chunk_words,
-                                          int64_t n_words, unsigned int seq, void* out, long long max_polls, void* done2,
-                                          void* err, void* err_host, void* stream) {
+                                          int64_t n_words, void* seq_dev, void* done_c, void* out, long long max_polls,
+                                          void* done2, void* err, void* err_host, void* stream) {
   if (n_words <= 0 || world < 1 || world > kMaxWorld || max_polls < 1 || chunk_words <= 0 || (chunk_words & 3) ||
       chunk_words * 4 > chunk_stride || chunk_words * 4 > max_bytes || chunk_words * world < n_words || rank < 0 || rank >= world)
     return (int)hipErrorInvalidValue;
@@ -271,15 +314,17 @@ EVOX_API int evox_hip_p2p_two_shot_finish(void* own_base, void* peer_base, int w
   len = len < 0 ? 0 : (len > chunk_words ? chunk_words : len);
   int blocks = (int)((len + 1023) / 1024);
   blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-  p2p_reduce_bcast_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, (char* const*)peer_base, world, rank, slot,
-                                                                  slot_stride, max_bytes, red_offset, chunk_stride, len, seq,
-                                                                  max_polls, (unsigned int*)done2, (int*)err, (int*)err_host);
+  p2p_reduce_bcast_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, (char* const*)peer_base, world, rank,
+                                                                  slot_stride, max_bytes, red_offset, chunk_stride, len,
+                                                                  (const unsigned int*)seq_dev, max_polls,
+                                                                  (unsigned int*)done2, (int*)err, (int*)err_host);
   int e = evox::last_launch_status();
   if (e) return e;
   blocks = (int)((n_words + 1023) / 1024);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-  p2p_collect_chunks_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, world, slot, red_offset, chunk_stride,
-                                                                    chunk_words, n_words, seq, (unsigned int*)out, max_polls,
+  p2p_collect_chunks_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((char*)own_base, world, red_offset, chunk_stride,
+                                                                    chunk_words, n_words, (unsigned int*)seq_dev,
+                                                                    (unsigned int*)done_c, (unsigned int*)out, max_polls,
                                                                     (int*)err, (int*)err_host);
   return evox::last_launch_status();
 }

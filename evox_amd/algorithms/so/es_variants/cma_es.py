@@ -438,7 +438,7 @@ class CMAES(Algorithm):
         for b in range(1, full.shape[0]):
             packed += full[b]
         if native:
-            return self._tell_native(state, None, reduced=(packed[nn:nn + n], packed[:nn], packed[nn + n:nn + n + 4]), ws=ws)
+            return self._tell_native(state, None, reduced=(packed[nn:nn + n], packed[:nn], None), ws=ws)
         step_sum, gram = packed[nn:nn + n], packed[:nn].view(n, n)
         mean = state.mean + self.cm * step_sum
         ps, pc, hsig, sigma = self._paths(state, mean)
@@ -494,9 +494,11 @@ class CMAES(Algorithm):
                 # Only about μ/λ of the local rows are selected.  Rows are exchangeable between the ranks, so that number
                 # is hypergeometric with a standard deviation of at most √local / 2: the selected rows are compacted
                 # into `keep` slots (mean + 12 standard deviations; one launch, ``ops/cma_native.py::select_local``) and
-                # only those go through the gather and the Gram product.  A count beyond `keep` would drop rows: every
-                # rank adds that fact to the message, and any overflow poisons the update on every rank in the same
-                # generation (and raises at the next periodic host check).
+                # only those go through the gather and the Gram product.  Exchangeability fails when the fitness has
+                # massive ties (a converged run whose values have collapsed onto a few floats, a plateau): ties go to
+                # the lower row index, i.e. to the lower ranks, and a rank can hold more selected rows than slots.  The
+                # surplus rows (the last ones in row order — tied with rows that were kept) are then left out of the
+                # update; every rank adds that fact to the message and the count is reported as a warning.
                 from ....ops import cma_native as _nat
                 if presorted is not None:
                     local_order, sqrt_w_local = _nat.presorted_select_local(presorted[0], world, rank, local, presorted[1],
@@ -537,24 +539,25 @@ class CMAES(Algorithm):
             overflow = packed[nn + self.dim]
             consts["calls"] += 1
             # The diagnosis without a host synchronisation: the flag word of every generation is copied into pinned host
-            # memory asynchronously and looked at by the following calls — an overflow (which has already poisoned the
-            # update on every rank) is reported one or two generations later, whenever the copy has landed.
+            # memory asynchronously and looked at by the following calls — an overflow is reported (once) one or two
+            # generations later, whenever the copy has landed.
             if pop.is_cuda and not torch.cuda.is_current_stream_capturing():
                 seen = consts.get("overflow_host")
                 if seen is None:
                     seen = consts["overflow_host"] = torch.zeros(1, dtype=torch.float32).pin_memory()
-                if float(seen[0]) > 0:
-                    raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(seen[0])} rank(s): "
-                                       "the update was poisoned (NaN) on every rank")
+                if float(seen[0]) > 0 and not consts.get("overflow_warned"):
+                    import warnings
+
+                    consts["overflow_warned"] = True
+                    warnings.warn(f"row-sharded CMA-ES: more than {keep} of the {local} local rows were selected on "
+                                  f"{int(seen[0])} rank(s) (massive ties in the fitness?); the surplus rows were left out "
+                                  "of the update", RuntimeWarning)
                 seen.copy_(overflow.reshape(1), non_blocking=True)
-            elif consts["calls"] % 64 == 0 and float(overflow) > 0:
-                raise RuntimeError(f"more than {keep} of the {local} local rows were selected on {int(overflow)} rank(s)")
             gram = packed[:nn] if native else packed[:nn].view(self.dim, self.dim)
             if native and ws is not None:
-                # everything after the all-reduce — whitening, paths, covariance, factorisation — in one native call;
-                # an overflow turns the covariance into NaNs there, on every rank alike
-                return self._tell_native(state, None, reduced=(packed[nn:nn + self.dim], gram, packed[nn + self.dim:]), ws=ws)
-            step_sum = torch.where(overflow > 0, torch.full_like(overflow, float("nan")), packed[nn:nn + self.dim])
+                # everything after the all-reduce — whitening, paths, covariance, factorisation — in one native call
+                return self._tell_native(state, None, reduced=(packed[nn:nn + self.dim], gram, None), ws=ws)
+            step_sum = packed[nn:nn + self.dim]
             mean, ps, pc, sigma, alpha, _ = _gemm.cma_paths(
                 state.mean, step_sum, self._whiten(state, step_sum), state.ps, state.pc, state.sigma, state.count_iter_dev,
                 (self.cs, self.cc, self.mueff, self.cm, self.damps, self.chiN, self.c1, self.cmu))

@@ -39,9 +39,9 @@ _native.register_hip_api({
     "evox_hip_p2p_export": (I, [P, P, I]),
     "evox_hip_p2p_import": (I, [P, P]),
     "evox_hip_p2p_close": (I, [P]),
-    "evox_hip_p2p_put": (I, [P, I64, P, I, I, I, I64, I64, ctypes.c_uint32, P, I64, P]),
-    "evox_hip_p2p_collect": (I, [P, I, I, I64, I64, I64, ctypes.c_uint32, P, I, ctypes.c_longlong, P, P, P]),
-    "evox_hip_p2p_two_shot_finish": (I, [P, P, I, I, I, I64, I64, I64, I64, I64, I64, ctypes.c_uint32, P, ctypes.c_longlong,
+    "evox_hip_p2p_put": (I, [P, I64, P, I, I, I64, I64, P, P, I64, P]),
+    "evox_hip_p2p_collect": (I, [P, I, I64, I64, I64, P, P, P, I, ctypes.c_longlong, P, P, P]),
+    "evox_hip_p2p_two_shot_finish": (I, [P, P, I, I, I64, I64, I64, I64, I64, I64, P, P, P, ctypes.c_longlong,
                                          P, P, P, P]),
     "evox_hip_host_device_ptr": (I, [P, P]),
 })
@@ -104,7 +104,10 @@ class P2PGroup:
         check(lib.evox_hip_host_device_ptr(self._err_host.data_ptr(), ctypes.byref(dev_ptr)), "hipHostGetDevicePointer")
         self._err_host_dev = dev_ptr.value
         self._broken = False
-        self._seq = 0
+        # sequence number of the collectives, kept on the device and advanced by the last kernel of each one: the
+        # launches of a collective take no argument that changes from call to call (they can be recorded into a graph)
+        self._seq_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._done_c = torch.zeros(1, dtype=torch.int32, device=self.device)
         # ≈ 1 µs per poll (a sleep of 32·64 cycles plus the load): the budget bounds the wait kernel
         self._max_polls = max(1000, int(timeout_s * 1e6))
         dist.barrier(group=group)                     # every buffer is mapped before anyone writes
@@ -124,23 +127,22 @@ class P2PGroup:
         if n * 4 > self.max_bytes:
             raise ValueError(f"message of {n * 4} bytes exceeds the group's max_bytes={self.max_bytes}")
         self._raise_if_timed_out()
-        self._seq = (self._seq + 1) & 0xFFFFFFFF or 1
-        slot = self._seq & 1
         out = torch.empty(n if reduce else n * self.world, dtype=src.dtype, device=self.device)
         lib, s = hip(), stream_of(src)
         two_shot = reduce and self.world > 1 and n * 4 >= self.two_shot_min_bytes
         # words of a chunk: a multiple of 4 (16-byte stores) that covers the message with W chunks
         chunk = ((n + self.world - 1) // self.world + 3) // 4 * 4 if two_shot else 0
-        check(lib.evox_hip_p2p_put(src.data_ptr(), n, self._peer_table.data_ptr(), self.world, self.rank, slot,
-                                   self.slot_stride, self.max_bytes, self._seq, self._done.data_ptr(), chunk, s), "p2p_put")
+        seq, done_c = self._seq_dev.data_ptr(), self._done_c.data_ptr()
+        check(lib.evox_hip_p2p_put(src.data_ptr(), n, self._peer_table.data_ptr(), self.world, self.rank,
+                                   self.slot_stride, self.max_bytes, seq, self._done.data_ptr(), chunk, s), "p2p_put")
         if two_shot:
-            check(lib.evox_hip_p2p_two_shot_finish(self._own, self._peer_table.data_ptr(), self.world, self.rank, slot,
+            check(lib.evox_hip_p2p_two_shot_finish(self._own, self._peer_table.data_ptr(), self.world, self.rank,
                                                    self.slot_stride, self.max_bytes, self._red_offset, self.chunk_stride,
-                                                   chunk, n, self._seq, out.data_ptr(), self._max_polls,
+                                                   chunk, n, seq, done_c, out.data_ptr(), self._max_polls,
                                                    self._done2.data_ptr(), self._err.data_ptr(), self._err_host_dev, s),
                   "p2p_two_shot_finish")
         else:
-            check(lib.evox_hip_p2p_collect(self._own, self.world, slot, self.slot_stride, self.max_bytes, n, self._seq,
+            check(lib.evox_hip_p2p_collect(self._own, self.world, self.slot_stride, self.max_bytes, n, seq, done_c,
                                            out.data_ptr(), int(reduce), self._max_polls, self._err.data_ptr(),
                                            self._err_host_dev, s), "p2p_collect")
         return out

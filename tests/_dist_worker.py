@@ -162,6 +162,82 @@ def main():
         os.environ["EVOX_AMD_P2P"] = "0"
         g.close()
         result = {"ok": ok}
+    elif case == "p2p_graph":
+        # the collectives recorded into a graph: the sequence number lives on the device, so every replay is a new
+        # collective; replays are interleaved with eager collectives and synchronisations and each one is checked
+        from evox_amd.parallel.p2p import P2PGroup
+
+        torch.cuda.set_device(0)
+        g = P2PGroup(max_bytes=1 << 20, timeout_s=10.0)
+        g.two_shot_min_bytes = 4096 * 4
+        ok = True
+        gen = torch.Generator().manual_seed(99)
+        for n in (37, 8192):                                   # one-shot and two-shot sums
+            x = torch.zeros(n, device=dev)
+            x.copy_(torch.randn(world, n, generator=gen)[rank])
+            g.all_reduce(x)                                    # an eager collective before the recording
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                red = g.all_reduce(x)
+                gat = g.all_gather(x)
+            for it in range(4):
+                full = torch.randn(world, n, generator=gen)
+                x.copy_(full[rank])
+                graph.replay()
+                torch.cuda.synchronize()
+                ok &= bool(torch.allclose(red.cpu(), full.sum(0), rtol=1e-5, atol=1e-5))
+                ok &= bool(torch.equal(gat.cpu(), full.reshape(-1)))
+                eager = g.all_reduce(x)                        # eager work between the replays
+                ok &= bool(torch.allclose(eager.cpu(), full.sum(0), rtol=1e-5, atol=1e-5))
+        g.check()
+        dist.barrier()
+        g.close()
+        result = {"ok": ok}
+    elif case == "cmaes_ties":
+        # every individual gets the same fitness: ties go to the lower row index, so the lower ranks hold ALL selected
+        # rows — more than their compaction slots.  The surplus is left out, the run goes on, and a warning says so.
+        import warnings
+
+        from evox_amd.core.problem import Problem
+
+        class Flat(Problem):
+            def evaluate(self, state, x):
+                return torch.zeros(x.shape[0], device=x.device), state
+
+        algo = A.CMAES(c, 1.0, pop_size=2048, decomposition="newton_schulz", precision="bf16")
+        wf = ShardedWorkflow(algo, Flat())
+        state = wf.init(ex.PRNGKey(3))
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for _ in range(12):
+                state = wf.step(state)
+            torch.cuda.synchronize() if dev.type == "cuda" else None
+        alg = state.get_child_state("algorithm")
+        result = {"finite": bool(torch.isfinite(alg.mean).all() and torch.isfinite(alg.C).all()),
+                  "warned": sum("left out" in str(w.message) for w in caught)}
+    elif case == "sharded_p2p_graph":
+        # a row-sharded generation replayed from a HIP graph, its collectives being the peer-to-peer kernels
+        torch.cuda.set_device(0)
+        os.environ["EVOX_AMD_P2P"] = "1"
+        result = {}
+        for name in ("pso", "cmaes"):
+            vecs = {}
+            for mode in (False, True):
+                algo = A.PSO(lb, ub, 2048) if name == "pso" else A.CMAES(c, 1.0, pop_size=2048, decomposition="newton_schulz",
+                                                                         precision="bf16")
+                wf = ShardedWorkflow(algo, problems.numerical.Ackley(), graph_step=mode)
+                state = wf.init(ex.PRNGKey(3))
+                for _ in range(30):
+                    state = wf.step(state)
+                torch.cuda.synchronize()
+                dist.check_p2p()
+                alg = state.get_child_state("algorithm")
+                vec = alg.global_best_location if name == "pso" else alg.mean
+                vecs[mode] = (vec.tolist(), wf.graph_replays if mode else 0)
+                dist.barrier()
+            result[name] = {"eager": vecs[False][0], "graph": vecs[True][0], "replays": vecs[True][1]}
+        os.environ["EVOX_AMD_P2P"] = "0"
     elif case == "p2p_timeout":
         # rank 1 joins the collective late; rank 0 polls a few times only, so its wait kernel gives up,
         # finishes, and the host reports the time-out (no wave is left spinning)

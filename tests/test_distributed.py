@@ -307,6 +307,15 @@ def test_deterministic_row_sharded_cma_es_on_gpu(precision, tmp_path):
 
 
 @pytest.mark.gpu
+def test_row_sharded_cma_es_survives_a_fitness_of_ties(tmp_path):
+    """All fitness values equal: the stable ranking hands every selected row to the lower rank, beyond the slots its
+    selected rows are compacted into.  The update leaves the surplus out (finite state on both ranks) and warns once."""
+    res = launch("cmaes_ties", 2, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    assert all(r["finite"] for r in res)
+    assert res[0]["warned"] == 1 and res[1]["warned"] == 1
+
+
+@pytest.mark.gpu
 def test_resync_on_gpu_leaves_identical_replicas(tmp_path):
     """Two ranks on the one GPU (gloo, device tensors staged through the host): a nudged replica and whatever
     last-bit differences the ranks' library GEMMs produce are gone after the broadcast that ends generation 30."""
@@ -322,6 +331,32 @@ def test_one_shot_p2p_collectives(world, tmp_path):
     the one GPU of the test box (handles are exchanged over gloo)."""
     res = launch("p2p", world, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
     assert all(r["ok"] for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_collectives_replay_from_a_graph(world, tmp_path):
+    """The collectives' sequence number lives on the device, so their launches can be recorded: four replays per
+    message size (one-shot and two-shot sums, all-gather), eager collectives and synchronisations in between, every
+    replay checked."""
+    res = launch("p2p_graph", world, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    assert all(r["ok"] for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_row_sharded_generation_replays_from_a_graph_with_p2p_collectives(world, tmp_path):
+    """A whole row-sharded CMA-ES generation (sampling, evaluation, distributed ranking with its all-gather, the local
+    sums, their all-reduce, the folded tail) recorded into a HIP graph whose collectives are the peer-to-peer kernels:
+    2, 4 and 8 ranks sharing the one GPU replay it in step."""
+    res = launch("sharded_p2p_graph", world, tmp_path, {"EVOX_TEST_DEVICE": "cuda"})
+    for r in res:
+        # the swarm is bit for bit the eager one; CMA-ES polls its factorisation control under replay instead of adapting
+        # it every generation, so its mean agrees to the accuracy of the factorisation
+        assert r["pso"]["replays"] >= 10 and r["pso"]["graph"] == r["pso"]["eager"]
+        assert r["cmaes"]["replays"] >= 2
+        assert torch.allclose(torch.tensor(r["cmaes"]["graph"]), torch.tensor(r["cmaes"]["eager"]), atol=5e-2, rtol=5e-2)
+    assert all(r["cmaes"]["graph"] == res[0]["cmaes"]["graph"] for r in res), "replicas diverged under replay"
 
 
 @pytest.mark.gpu

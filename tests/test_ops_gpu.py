@@ -1422,7 +1422,7 @@ def test_cmaes_row_sharded_tell_takes_the_folded_tail(cuda, n, lam, monkeypatch)
     """The part of a row-sharded tell behind the all-reduce (whitening product, paths, covariance from the tile-packed
     summed rank-mu term, factorisation) runs the folded launch sequence too: same state as the launch chain on the same
     reduced message, the single-process tell's state to rounding, the next ask's draws made ahead bit-equal to draws made
-    on the spot, and a poisoned message (rows dropped somewhere) turns the covariance into NaNs."""
+    on the spot."""
     import evox_amd as ex
     from evox_amd import algorithms, problems
     from evox_amd.workflows import ShardedWorkflow
