@@ -133,8 +133,10 @@ def main():
         m = dist.all_reduce(x, "max")
         b = dist.broadcast(x, src=world - 1)
         g2 = dist.all_gather(x.reshape(1, 3), axis=1)
+        begun = dist.all_reduce_begin(x.clone()).wait()            # the split form gives what the in-place one gives
+        inplace = dist.all_reduce_(x.clone())
         result = {"gather": g.tolist(), "sum": s.tolist(), "max": m.tolist(), "bcast": b.tolist(),
-                  "gather_axis1": list(g2.shape)}
+                  "gather_axis1": list(g2.shape), "begin_wait": begun.tolist(), "inplace": inplace.tolist()}
     elif case == "p2p":
         # one-shot collectives over IPC-mapped device memory: the ranks share the one visible GPU
         from evox_amd.parallel.p2p import P2PGroup

@@ -46,6 +46,7 @@ def test_collectives(tmp_path):
         assert r["gather"] == [0.0, 1.0, 2.0, 10.0, 11.0, 12.0]
         assert r["sum"] == [10.0, 12.0, 14.0] and r["max"] == [10.0, 11.0, 12.0]
         assert r["bcast"] == [10.0, 11.0, 12.0] and r["gather_axis1"] == [1, 6]
+        assert r["begin_wait"] == r["inplace"] == r["sum"]
 
 
 @pytest.mark.parametrize("case", ["cmaes", "openes", "pgpe", "ars", "des", "snes", "sepcmaes", "maes"])
