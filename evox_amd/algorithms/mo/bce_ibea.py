@@ -25,10 +25,21 @@ from .indicator import ibea_fitness_only, ibea_survivors
 
 
 def _third_nearest(dist):
+    """``(distance to the third nearest other point, distances with the diagonal and NaNs at +inf)``.  Only three values
+    per row are wanted: a selection of the three smallest, not a sort of every row."""
     d = dist.clone()
     d.fill_diagonal_(float("inf"))
     d = torch.nan_to_num(d, nan=float("inf"))
-    return torch.sort(d, dim=1).values[:, min(2, d.shape[1] - 1)], d
+    k = min(3, d.shape[1])
+    return torch.topk(d, k, dim=1, largest=False, sorted=True).values[:, k - 1], d
+
+
+def _third_nearest_distance(points):
+    """The first result of :func:`_third_nearest` straight from the coordinates (streamed on the GPU: no n × n matrix)."""
+    n = points.shape[0]
+    if n > 3 and points.is_cuda:
+        return _sel.knn_distances(points, 3)[:, 2]
+    return _third_nearest(_cdist(points, points))[0]
 
 
 def exploration(pc_obj, npc_obj, n_nd, n):
@@ -37,7 +48,7 @@ def exploration(pc_obj, npc_obj, n_nd, n):
     f_min, f_max = pc_obj.amin(0), pc_obj.amax(0)
     span = (f_max - f_min).clamp_min(1e-12)
     a, b = (pc_obj - f_min) / span, (npc_obj - f_min) / span
-    r0 = _third_nearest(_cdist(a, a))[0].mean()
+    r0 = _third_nearest_distance(a).mean()
     r = n_nd / n * r0
     return (_cdist(a, b) <= r).sum(1) <= 1
 

@@ -92,14 +92,15 @@ def _host_max() -> int:
 
 def _device_jacobi(C) -> bool:
     """Orders whose symmetric eigendecomposition runs in the one-workgroup Jacobi kernel (``csrc/linalg_small.hip``): up
-    to ``EVOX_AMD_DEVICE_EIGH_MAX`` (default 192) — and up to 384 while a generation is being recorded into a graph,
-    where the host round trip of the alternative is not possible."""
+    to ``EVOX_AMD_DEVICE_EIGH_MAX`` (default 64: beyond that the host LAPACK round trip is faster in eager issue — order
+    100: 0.3 ms including both copies against 0.5–1.4 ms for the latency-bound kernel) — and up to 384 while a generation
+    is being recorded into a graph, where a host round trip is not possible."""
     from . import linalg_small as _ls
 
     n = C.shape[-1]
     if not _ls.device_linalg(C, n):
         return False
-    return n <= int(os.environ.get("EVOX_AMD_DEVICE_EIGH_MAX", "192")) or torch.cuda.is_current_stream_capturing()
+    return n <= int(os.environ.get("EVOX_AMD_DEVICE_EIGH_MAX", "64")) or torch.cuda.is_current_stream_capturing()
 
 
 def eigh_reference(C, B_prev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
