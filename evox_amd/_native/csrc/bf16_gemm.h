@@ -375,6 +375,9 @@ struct EpiAffine {
   struct Out {
     float* f32[MAXB];             // optional fp32 image, pitch ldf
     uint16_t* pl[MAXB][NPO];      // optional split planes, pitch ldp (pl[z][0] == nullptr: none)
+    uint16_t* plt[MAXB][NPO];     // optional split planes of the TRANSPOSE (plain products only: the NT form takes the
+                                  // right factor row-major, so a non-symmetric result that will be a right factor later
+                                  // is stored both ways)
     const float* cin[MAXB];       // optional addend, pitch ldf
     const float* prev[MAXB];      // optional replacement under keep, pitch ldf
     const float* scale[MAXB];     // optional device scalar
@@ -468,6 +471,19 @@ struct EpiAffine {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (n + r < N) put(w, z, m, n + r, x[r]);
+      }
+      if (w.plt[z][0] != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= N) break;
+          float rem = x[r];
+#pragma unroll
+          for (int p = 0; p < NPO; ++p) {
+            const uint32_t b = f32_to_bf16_bits(rem);
+            w.plt[z][p][(long long)(n + r) * ldp + m] = (uint16_t)b;
+            rem -= bf16_bits_to_f32(b);
+          }
+        }
       }
       if (mirror == 1) {
 #pragma unroll

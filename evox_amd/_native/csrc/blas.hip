@@ -664,6 +664,27 @@ int ns_product(const uint16_t* a0, const uint16_t* a1, const uint16_t* b0, const
   return launch<64, 64, 2, 4, NSP, true, 3, EpiAffine<NPO>>(g, epi, upper_tiles(T), 1, batch, st);
 }
 
+// the same without symmetry: every tile of the T x T grid, nothing mirrored
+template <int NSP, int NPO>
+int ns_product_full(const uint16_t* a0, const uint16_t* a1, const uint16_t* b0, const uint16_t* b1, int batch, int64_t plane,
+                    int64_t ldp, int n, const EpiAffine<NPO>& epi, hipStream_t st) {
+  Args<NSP> g{};
+  for (int p = 0; p < NSP; ++p) {
+    g.a[0][p] = a0 + p * plane;
+    g.b[0][p] = b0 + p * plane;
+    g.a[1][p] = (batch > 1 ? a1 : a0) + p * plane;
+    g.b[1][p] = (batch > 1 ? b1 : b0) + p * plane;
+  }
+  g.lda = g.ldb = ldp;
+  g.M = g.N = n;
+  g.ksteps = (n + 63) / 64;
+  g.ksteps_per_split = g.ksteps;
+  const int T = (n + 63) / 64;
+  g.tiles_m = g.tiles_n = T;
+  if (batch > 1) return launch<64, 64, 2, 4, NSP, false, 2, EpiAffine<NPO>>(g, epi, T * T, 1, batch, st);
+  return launch<64, 64, 2, 4, NSP, false, 3, EpiAffine<NPO>>(g, epi, T * T, 1, batch, st);
+}
+
 template <int NPO>
 EpiAffine<NPO> affine(int n, int64_t ldp) {
   EpiAffine<NPO> e{};
@@ -680,10 +701,21 @@ void set_planes(typename EpiAffine<NPO>::Out& o, int z, uint16_t* base, int64_t 
   for (int p = 0; p < NPO; ++p) o.pl[z][p] = base + p * plane;
 }
 
+template <int NPO>
+void set_planes_t(typename EpiAffine<NPO>::Out& o, int z, uint16_t* base, int64_t plane) {
+  for (int p = 0; p < NPO; ++p) o.plt[z][p] = base + p * plane;
+}
+
+// full != 0: the iterations after the fifth-order step multiply every tile and mirror nothing.  Mirroring replaces a
+// product Y T by the symmetric matrix made of its upper triangle; Y and T commute only up to rounding, the difference
+// feeds back into the iteration and is amplified by about (sqrt(cond) - 1) / 2 per step, which limits the mirrored form
+// to well-conditioned matrices.  The plain form keeps every iterate in both orientations (the NT product takes its
+// right factor row-major) at twice the tiles per product; only the final products, whose results leave the iteration,
+// are mirrored again so that the factors come out symmetric to the last bit.
 template <int NSP>
-int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_steps, int safe, uint16_t* planes, float* f32ws,
-                   float* vec, float* scal, const float* prev_sqrt, const float* prev_inv, float* out_sqrt, float* out_inv,
-                   uint16_t* out_sqrt_bf16, hipStream_t stream) {
+int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_steps, int safe, int full, uint16_t* planes,
+                   float* f32ws, float* vec, float* scal, const float* prev_sqrt, const float* prev_inv, float* out_sqrt,
+                   float* out_inv, uint16_t* out_sqrt_bf16, hipStream_t stream) {
   const int64_t nn = (int64_t)n * n;
   const int64_t plane = (int64_t)n * ldp;               // elements of one bf16 plane
   const int64_t sm = plane * NSP;                       // one split matrix
@@ -764,6 +796,57 @@ int ns_sqrt_planes(const float* C, int n, int64_t ldp, int iters, int power_step
   }
   const uint16_t* Y = Y1;
   const uint16_t* Z = Pp;
+  if (full) {
+    // Y1 and Z1 = p are polynomials in Y0 computed by mirrored products: symmetric to the last bit, their own transposes.
+    const uint16_t *Yt = Y1, *Zt = Pp;
+    uint16_t* Tt = Y0;                                    // Y0 is dead after the first step
+    uint16_t* set_a[4] = {Yb[0], Zb[0], Yb[1], Zb[1]};    // Y, Yt, Z, Zt of the odd iterations
+    uint16_t* set_b[4] = {A2, Qp, Pp, Y1};                // ... of the even ones (free from the second iteration on)
+    for (int it = 1; it < iters; ++it) {
+      const bool last = it + 1 == iters;
+      {
+        // T = 1.5 I - 0.5 Z Y, both orientations
+        auto epi = affine<NSP>(n, ldp);
+        epi.o[0].alpha = -0.5f;
+        epi.o[0].gamma = 1.5f;
+        set_planes<NSP>(epi.o[0], 0, Tp, plane);
+        set_planes_t<NSP>(epi.o[0], 0, Tt, plane);
+        if (last) epi.o[0].f32[0] = Tf;
+        e = ns_product_full<NSP, NSP>(Z, nullptr, Yt, nullptr, 1, plane, ldp, n, epi, stream);
+        if (e) return e;
+      }
+      if (!last) {
+        uint16_t** o = (it & 1) ? set_a : set_b;
+        auto epi = affine<NSP>(n, ldp);
+        epi.o[0].alpha = 1.f;
+        set_planes<NSP>(epi.o[0], 0, o[0], plane);
+        set_planes_t<NSP>(epi.o[0], 0, o[1], plane);
+        set_planes<NSP>(epi.o[0], 1, o[2], plane);
+        set_planes_t<NSP>(epi.o[0], 1, o[3], plane);
+        e = ns_product_full<NSP, NSP>(Y, Tp, Tt, Zt, 2, plane, ldp, n, epi, stream);   // Y T and T Z
+        if (e) return e;
+        Y = o[0]; Yt = o[1]; Z = o[2]; Zt = o[3];
+      } else {
+        int res_blocks = evox::stream_grid((int64_t)((n + kResStride - 1) / kResStride) * n, 256);
+        if (res_blocks > kPartRow) res_blocks = kPartRow;
+        ns_residual_kernel<<<res_blocks, 256, 0, stream>>>(Tf, n, scal);
+        ns_flags_kernel<<<1, 256, 0, stream>>>(scal, n, res_blocks, prev_sqrt != nullptr && prev_inv != nullptr);
+        auto epi = affine<1>(n, ldp);
+        epi.o[0].alpha = 1.f;
+        epi.o[0].f32[0] = out_sqrt;
+        epi.o[0].f32[1] = out_inv;
+        epi.o[0].scale[0] = scal + 12;
+        epi.o[0].scale[1] = scal + 11;
+        epi.o[0].prev[0] = prev_sqrt;
+        epi.o[0].prev[1] = prev_inv;
+        epi.o[0].pl[0][0] = out_sqrt_bf16;
+        epi.keep = scal + 15;
+        e = ns_product<NSP, 1>(Y, Tp, Tt, Zt, 2, plane, ldp, n, epi, stream);          // upper tiles of Y T and T Z, mirrored
+        if (e) return e;
+      }
+    }
+    return 0;
+  }
   for (int it = 1; it < iters; ++it) {
     const bool last = it + 1 == iters;
     {
@@ -842,17 +925,26 @@ EVOX_API int evox_hip_ns_cond(const float* inv, int n, float* vec2, float* scal,
 // pad columns are never written), f32ws = 3 * n * n floats.  ldp: a multiple of 64 elements >= n rounded up to 64.
 // out_sqrt_bf16 (optional): n x ldp, pad columns zero.  iters >= 1 (the first is the fifth-order step; with
 // iters == 1 it is the whole factorisation and the residual is estimated with a probe vector).
-EVOX_API int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe,
-                                   void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt,
-                                   const float* prev_inv, float* out_sqrt, float* out_inv, void* out_sqrt_bf16,
-                                   void* stream) {
+// full != 0: plain (un-mirrored) products in the iterations after the first step, for ill-conditioned matrices.
+EVOX_API int evox_hip_ns_sqrt_planes(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe,
+                                     int full, void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt,
+                                     const float* prev_inv, float* out_sqrt, float* out_inv, void* out_sqrt_bf16,
+                                     void* stream) {
   if (n <= 0 || iters < 1 || power_steps < 1 || power_steps > kMaxPow || (nsp != 2 && nsp != 3)) return (int)hipErrorInvalidValue;
   if (ldp < (int64_t)((n + 63) / 64) * 64 || (ldp & 7) || ((uintptr_t)planes & 15) || ((uintptr_t)out_sqrt_bf16 & 15))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   if (nsp == 2)
-    return ns_sqrt_planes<2>(C, n, ldp, iters, power_steps, safe, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt, prev_inv,
-                             out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
-  return ns_sqrt_planes<3>(C, n, ldp, iters, power_steps, safe, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt, prev_inv,
-                           out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
+    return ns_sqrt_planes<2>(C, n, ldp, iters, power_steps, safe, full, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt,
+                             prev_inv, out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
+  return ns_sqrt_planes<3>(C, n, ldp, iters, power_steps, safe, full, (uint16_t*)planes, f32ws, vec, scal, prev_sqrt,
+                           prev_inv, out_sqrt, out_inv, (uint16_t*)out_sqrt_bf16, st);
+}
+
+EVOX_API int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe,
+                                   void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt,
+                                   const float* prev_inv, float* out_sqrt, float* out_inv, void* out_sqrt_bf16,
+                                   void* stream) {
+  return evox_hip_ns_sqrt_planes(C, n, ldp, nsp, iters, power_steps, safe, 0, planes, f32ws, vec, scal, prev_sqrt, prev_inv,
+                                 out_sqrt, out_inv, out_sqrt_bf16, stream);
 }

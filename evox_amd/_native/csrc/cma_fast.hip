@@ -739,7 +739,7 @@ static int tell_fast(const CmaTell* t, const CmaFast* f, hipStream_t st) {
 // factorisation by the symmetric two-plane driver with ONE fifth-order step, estimate-scaled (not the safe norm bound),
 // n a multiple of 4, and a previous record whose scale entry is valid (any earlier call of either driver).
 EVOX_API int evox_hip_cma_tell_fast(const CmaTell* t, const CmaFast* f, void* stream) {
-  if (t == nullptr || f == nullptr || !t->factor || !t->ns_symmetric || t->ns_iters != 1 || t->ns_safe ||
+  if (t == nullptr || f == nullptr || !t->factor || t->ns_symmetric != 1 || t->ns_iters != 1 || t->ns_safe ||
       t->ns_planes != 2 || (t->n & 3) || t->n <= 0 || t->b16_o == nullptr || t->prev_rec == nullptr ||
       t->ctrl_vec == nullptr)
     return (int)hipErrorInvalidValue;

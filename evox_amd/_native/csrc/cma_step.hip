@@ -30,9 +30,9 @@ int evox_hip_bf16_cov(const void* Yt, int64_t ldy, int n, int mu, const float* C
                       float c1, float cmu, float* out, float* ws, int64_t ws_floats, void* stream);
 int evox_hip_cov_from_packed(const float* packed, int n, const float* C, const float* pc, const float* alpha, float c1,
                              float cmu, const float* poison, float* out, void* stream);
-int evox_hip_ns_sqrt_bf16(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe, void* planes,
-                          float* f32ws, float* vec, float* scal, const float* prev_sqrt, const float* prev_inv,
-                          float* out_sqrt, float* out_inv, void* out_sqrt_bf16, void* stream);
+int evox_hip_ns_sqrt_planes(const float* C, int n, int64_t ldp, int nsp, int iters, int power_steps, int safe, int full,
+                            void* planes, float* f32ws, float* vec, float* scal, const float* prev_sqrt, const float* prev_inv,
+                            float* out_sqrt, float* out_inv, void* out_sqrt_bf16, void* stream);
 int evox_hip_ns_sqrt(const float* C, int n, int iters, int power_steps, int safe, float* work, const float* eye, float* vec,
                      float* scal, const float* prev_sqrt, const float* prev_inv, float* out_sqrt, float* out_inv, int tune,
                      int first_step, void* out_sqrt_bf16, void* stream);
@@ -389,8 +389,10 @@ EVOX_API int evox_hip_cma_tell(const CmaTell* t, void* stream) {
   }
   if (e || !t->factor) return e;
   if (t->ns_symmetric) {
-    e = evox_hip_ns_sqrt_bf16(t->C_o, n, t->ldn, t->ns_planes, t->ns_iters, t->ns_power, t->ns_safe, t->planes, t->ns_f32,
-                              t->vec4, t->scal, t->B, t->invsqrtC, t->B_o, t->inv_o, t->b16_o, stream);
+    // ns_symmetric: 1 mirrored plane products, 2 plain plane products in the iterations (ill-conditioned covariance)
+    e = evox_hip_ns_sqrt_planes(t->C_o, n, t->ldn, t->ns_planes, t->ns_iters, t->ns_power, t->ns_safe,
+                                t->ns_symmetric == 2, t->planes, t->ns_f32, t->vec4, t->scal, t->B, t->invsqrtC, t->B_o,
+                                t->inv_o, t->b16_o, stream);
   } else {
     if (t->lib_work == nullptr || t->lib_eye == nullptr) return (int)hipErrorInvalidValue;
     e = evox_hip_ns_sqrt(t->C_o, n, t->ns_iters, t->ns_power, t->ns_safe, t->lib_work, t->lib_eye, t->vec4, t->scal, t->B,

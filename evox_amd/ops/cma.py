@@ -211,6 +211,12 @@ class NewtonSchulzSqrt:
     #   0 cond estimate from below, 1 cond bound from above, 2 1/√s, 3 √s, 4 scale s ≈ λmax, 5 residual, 6 failed
     REC = 7
     SYM_COND_MAX = 30.0      # the symmetric-half products are used while the cond bound of two calls ago is below
+    # beyond it the plane driver multiplies whole products in its iterations (``full``): with two planes (16 significant
+    # bits) up to TWO_PLANE_COND_MAX — measured at n = 1000: C^{-1/2} to 1.8e-4 at cond 1e3, 3.6e-3 at 1e4 —, with three
+    # planes (24 bits) up to PLANE_COND_MAX (3.2e-4 at 1e4, 6.7e-3 at 1e5); beyond that the fp32 products of the vendor
+    # library (``tools/ns_full_check.py``)
+    TWO_PLANE_COND_MAX = 2.0e3
+    PLANE_COND_MAX = float(os.environ.get("EVOX_AMD_NS_PLANE_COND_MAX", "2e4"))
     COND_EVERY = 4           # calls between refreshes of the condition estimates
     COND_TRUST = 3.0         # the estimate from below times this factor may stand in for a looser bound from above
 
@@ -360,8 +366,11 @@ class NewtonSchulzSqrt:
         use_safe = safe > 0
         if use_safe and not capturing:
             safe -= 1
+        full, nplanes = False, self.planes
         if capturing:
             symmetric = bool(int(ctrl.get("ns_sym", 0))) and bool(self.planes and have_ws and gpu)
+            full = symmetric and int(ctrl.get("ns_sym", 0)) >= 2
+            nplanes = 3 if int(ctrl.get("ns_sym", 0)) == 3 else self.planes
         else:
             # The bound from above (an ∞-norm) overshoots by up to √n when the eigenvectors are far from the axes;
             # the estimate from below (a power vector carried from call to call) is tight after a few refreshes.
@@ -372,10 +381,18 @@ class NewtonSchulzSqrt:
                 cond = float(self.initial_cond)
             if lagged is not None and lagged[1] > 0.0:
                 cond = lagged[1] if not lagged[0] > 0.0 else min(lagged[1], self.COND_TRUST * lagged[0])
-            symmetric = bool(self.planes and have_ws and gpu and 0.0 < cond <= self.SYM_COND_MAX and not use_safe)
-        self.symmetric_calls += int(symmetric)
+            planes_ok = bool(self.planes and have_ws and gpu)
+            symmetric = planes_ok and 0.0 < cond <= self.SYM_COND_MAX and not use_safe
+            if planes_ok and not symmetric and (cond <= 0.0 or cond <= self.PLANE_COND_MAX) and (calls >= 2 or self.initial_cond is not None):
+                # own kernels off the best case too: the plane driver with plain products (also under the safe scaling)
+                symmetric = full = True
+                # an unknown conditioning (no bound yet, or the safe scaling after a failed call) takes the wide form
+                nplanes = self.planes if (0.0 < cond <= self.TWO_PLANE_COND_MAX and not use_safe) else 3
+        self.symmetric_calls += int(symmetric and not full)
+        self.full_plane_calls = getattr(self, "full_plane_calls", 0) + int(full)
         used = max(1, iters)
-        return {"iters": iters, "safe": safe, "use_safe": use_safe, "symmetric": symmetric, "used": used, "calls": calls,
+        return {"iters": iters, "safe": safe, "use_safe": use_safe, "symmetric": symmetric, "full": full, "planes": nplanes, "used": used,
+                "calls": calls,
                 "power": 8 if calls == 0 else 1,
                 "cond": bool(self.planes and gpu and (calls % self.COND_EVERY == 0 or capturing))}
 
@@ -387,7 +404,9 @@ class NewtonSchulzSqrt:
             # a recording freezes the host values: only the call counter moves (the replay advances it on the host)
             return dict(ctrl, ns_calls=plan["calls"] + 1, ns_vec=new_vec, ns_res1=rec, ns_res2=ctrl["ns_res1"])
         return {"ns_iters": plan["iters"], "ns_safe": plan["safe"], "ns_calls": plan["calls"] + 1, "ns_used1": plan["used"],
-                "ns_used2": int(ctrl["ns_used1"]), "ns_sym": int(plan["symmetric"]), "ns_vec": new_vec, "ns_res1": rec,
+                "ns_used2": int(ctrl["ns_used1"]), "ns_sym": int(plan["symmetric"]) + int(plan.get("full", False)) + int(plan.get("full", False) and plan.get("planes") == 3),
+                "ns_vec": new_vec,
+                "ns_res1": rec,
                 "ns_res2": ctrl["ns_res1"]}
 
     def library_workspace(self, n: int, device):
@@ -405,7 +424,9 @@ class NewtonSchulzSqrt:
         product on the bf16 matrix cores and mirrors it; forcing the iterates symmetric changes the first-order
         error propagation of the coupled iteration, which then amplifies rounding errors by about (√cond − 1)/2 per
         step, so it is used while the condition bound of the covariance (from the factorisation of two calls ago)
-        is below ``SYM_COND_MAX``.  Beyond that the full fp32 products of the vendor library run."""
+        is below ``SYM_COND_MAX``.  Beyond that the same kernels multiply whole products in the iterations (every
+        iterate kept in both orientations; ``csrc/blas.hip::ns_sqrt_planes``) up to ``PLANE_COND_MAX``, and only
+        beyond that the full fp32 products of the vendor library run."""
         n = C.shape[0]
         capturing = C.is_cuda and torch.cuda.is_current_stream_capturing()
         gpu_native = C.is_cuda and C.dtype == torch.float32 and os.environ.get("EVOX_AMD_NS", "native") == "native"
@@ -416,7 +437,8 @@ class NewtonSchulzSqrt:
             vec4.view(2, 2 * n)[:, :n].copy_(ctrl["ns_vec"])
             if pl["symmetric"]:
                 from . import cma_bf16 as _b
-                sq, inv, b16 = _b.ns_sqrt(C, ws, pl["used"], scal, vec4, power_steps=pl["power"], safe=pl["use_safe"], prev=prev)
+                sq, inv, b16 = _b.ns_sqrt(C, ws, pl["used"], scal, vec4, power_steps=pl["power"], safe=pl["use_safe"], prev=prev,
+                                          full=pl["full"], planes=pl["planes"])
             else:
                 from . import blas as _blas
                 w = self.library_workspace(n, C.device)

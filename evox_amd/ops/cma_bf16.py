@@ -30,7 +30,7 @@ _native.register_hip_api({
     "evox_hip_bf16_gram_packed": (I, [P, I64, I, I, P, P, I64, P]),
     "evox_hip_cov_from_packed": (I, [P, I, P, P, P, F, F, P, P, P]),
     "evox_hip_ns_scal_floats": (I, []),
-    "evox_hip_ns_sqrt_bf16": (I, [P, I, I64, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "evox_hip_ns_sqrt_planes": (I, [P, I, I64, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P]),
     "evox_hip_matvec": (I, [P, I, P, P, P]),
 })
 
@@ -119,6 +119,17 @@ class Workspace:
         buf = self._factor[self._factor_next]
         self._factor_next ^= 1
         return buf
+
+    def ns_planes_buffer(self, planes: int) -> torch.Tensor:
+        """Zero-filled plane storage of the factorisation for ``planes`` (2 or 3) planes per matrix.  Each count has a
+        buffer of its own: the pad columns of a plane are never written and must stay zero, and the two layouts put
+        them in different places.  The three-plane buffer (ill-conditioned covariances) is allocated on first use."""
+        if planes == self.ns_planes:
+            return self.ns()["planes"]
+        extra = self.__dict__.setdefault("_ns_extra", {})
+        if planes not in extra:
+            extra[planes] = torch.zeros((10 * planes, self.n, self.ldn), dtype=torch.bfloat16, device=self.device)
+        return extra[planes]
 
     def ns(self):
         if self._ns is None:
@@ -242,9 +253,11 @@ def gram(ws: Workspace, out: torch.Tensor):
 
 
 def ns_sqrt(C, ws: Workspace, iters: int, scal: torch.Tensor | None = None, vec: torch.Tensor | None = None, *,
-            power_steps: int = 1, safe: bool = False, prev=None):
-    """``(sqrtC, invsqrtC, sqrtC_bf16)`` after ``iters`` (≥ 1) coupled Newton–Schulz steps whose products are
-    symmetric-half products of bf16 split planes (well-conditioned ``C`` only: see ``NewtonSchulzSqrt.step``).
+            power_steps: int = 1, safe: bool = False, prev=None, full: bool = False, planes: int | None = None):
+    """``(sqrtC, invsqrtC, sqrtC_bf16)`` after ``iters`` (≥ 1) coupled Newton–Schulz steps whose products run on bf16
+    split planes: symmetric-half products mirrored on write (well-conditioned ``C`` only), or with ``full`` plain
+    products in the iterations after the first step (any conditioning: see ``NewtonSchulzSqrt.step``).  ``planes``
+    (default: the workspace's count): 2 carries 16 significant bits per operand, 3 carries 24.
     ``sqrtC_bf16`` is the (n, pitch(n)) zero-padded bf16 copy the sampling product reads.  ``scal`` (the driver's
     scalar block) and ``vec`` (2n floats, the first n a unit vector carried between calls) default to the
     workspace's own; ``scal[13:16]`` afterwards holds the scale, the residual bound and the flag telling that
@@ -259,8 +272,9 @@ def ns_sqrt(C, ws: Workspace, iters: int, scal: torch.Tensor | None = None, vec:
     out_s, out_i = torch.empty_like(C), torch.empty_like(C)
     out_b = ws.factor_buffer()
     ps, pi = (prev[0].contiguous(), prev[1].contiguous()) if prev is not None else (None, None)
-    check(hip().evox_hip_ns_sqrt_bf16(C.data_ptr(), n, ws.ldn, ws.ns_planes, max(1, int(iters)), int(power_steps),
-                                      int(bool(safe)), st["planes"].data_ptr(), st["f32"].data_ptr(), vec.data_ptr(),
+    planes = ws.ns_planes if planes is None else int(planes)
+    check(hip().evox_hip_ns_sqrt_planes(C.data_ptr(), n, ws.ldn, planes, max(1, int(iters)), int(power_steps),
+                                      int(bool(safe)), int(bool(full)), ws.ns_planes_buffer(planes).data_ptr(), st["f32"].data_ptr(), vec.data_ptr(),
                                       scal.data_ptr(), ps.data_ptr() if ps is not None else None,
                                       pi.data_ptr() if pi is not None else None, out_s.data_ptr(), out_i.data_ptr(),
                                       out_b.data_ptr(), stream_of(C)), "ns_sqrt_bf16")

@@ -214,7 +214,7 @@ class Generation:
         left in its record)."""
         if reduced is not None and (reduced[1].dim() != 1 or os.environ.get("EVOX_AMD_CMA_FAST_SHARDED", "1") == "0"):
             return False
-        return (bool(factor) and plan is not None and bool(plan["symmetric"]) and plan["used"] == 1
+        return (bool(factor) and plan is not None and bool(plan["symmetric"]) and not plan.get("full") and plan["used"] == 1
                 and not plan["use_safe"] and plan["calls"] >= 2 and self.ws.ns_planes == 2 and n % 4 == 0
                 and os.environ.get("EVOX_AMD_CMA_FAST", "1") != "0")
 
@@ -272,13 +272,15 @@ class Generation:
             t.ctrl_vec, t.prev_rec = state.ns_vec.data_ptr(), state.ns_res1.data_ptr()
             t.ctrl_vec_o, t.rec_o = ctrl_o.data_ptr(), rec_o.data_ptr()
             t.ns_iters, t.ns_power, t.ns_safe = plan["used"], plan["power"], int(plan["use_safe"])
-            t.ns_symmetric, t.ns_cond = int(plan["symmetric"]), int(plan["cond"])
+            t.ns_symmetric, t.ns_cond = int(plan["symmetric"]) + int(plan.get("full", False)), int(plan["cond"])
             # the record of this call goes straight into a pinned slot of the iteration control (read two calls later)
             slot = self.ns.pinned_slot() if not torch.cuda.is_current_stream_capturing() else None
             t.rec_host = slot[2] if slot is not None else None
             if plan["symmetric"]:
                 b16 = ws.factor_buffer()
                 t.b16_o = b16.data_ptr()
+                t.ns_planes = int(plan.get("planes") or ws.ns_planes)
+                t.planes = ws.ns_planes_buffer(t.ns_planes).data_ptr()
             else:
                 from . import blas as _blas
                 if not _blas.available():

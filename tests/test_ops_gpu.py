@@ -1462,6 +1462,38 @@ def test_cmaes_row_sharded_tell_takes_the_folded_tail(cuda, n, lam, monkeypatch)
     assert torch.equal(p1, p2) and torch.equal(n1.key, n2.key) and torch.equal(n1.count_iter_dev, n2.count_iter_dev)
 
 
+@pytest.mark.parametrize("cond,planes,iters,tol", [(1e2, 2, 8, 1e-4), (1e3, 2, 10, 5e-4), (1e3, 3, 12, 1e-4), (1e4, 3, 14, 5e-4)])
+def test_newton_schulz_plane_driver_with_plain_products(cuda, cond, planes, iters, tol):
+    """Ill-conditioned matrices: the plane driver multiplies whole (un-mirrored) products in its iterations, every
+    iterate kept in both orientations; C^{1/2} and C^{-1/2} against fp64, factors symmetric to the last bit.  The
+    mirrored form loses C^{-1/2} at these condition numbers (1.6e-3 at 1e3, 9e-2 at 1e4)."""
+    from evox_amd.ops import cma_bf16 as b16
+
+    n = 520
+    g = torch.Generator().manual_seed(7)
+    Q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    ev = torch.logspace(0, -float(torch.log10(torch.tensor(cond))), n, dtype=torch.float64)
+    C64 = ((Q * ev) @ Q.T).to(cuda)
+    C64 = 0.5 * (C64 + C64.T)
+    ws = b16.Workspace(n, 8, 4, cuda)
+    S, Z, S16 = b16.ns_sqrt(C64.float(), ws, iters, power_steps=8, full=True, planes=planes)
+    torch.cuda.synchronize()
+    S64, Z64 = S.double(), Z.double()
+    eye = torch.eye(n, dtype=torch.float64, device=cuda)
+    assert float((S64 @ S64 - C64).norm() / C64.norm()) < tol
+    assert float((Z64 @ S64 - eye).norm() / n ** 0.5) < tol
+    assert torch.equal(S, S.T) and torch.equal(Z, Z.T)
+    assert torch.allclose(S16[:, :n].float(), S, rtol=8e-3, atol=1e-6)
+    # a second call on the same workspace with the other plane count: each count has its own zero-padded storage
+    other = 5 - planes
+    S2, Z2, _ = b16.ns_sqrt(C64.float(), ws, iters + 2, power_steps=8, full=True, planes=other)
+    S3, Z3, _ = b16.ns_sqrt(C64.float(), ws, iters, power_steps=8, full=True, planes=planes)
+    # (the power vector of the scale estimate is carried in the workspace: repeated calls agree to rounding, not in bits)
+    assert torch.allclose(S3, S, rtol=0, atol=2 * tol) and torch.allclose(Z3, Z, rtol=0, atol=2 * tol * float(Z.abs().max()))
+    assert float((Z3.double() @ S3.double() - eye).norm() / n ** 0.5) < tol
+    assert torch.isfinite(S2).all() and torch.isfinite(Z2).all()
+
+
 def test_newton_schulz_fifth_order_step_alone(cuda):
     """iters = 1: the fifth-order first step is the whole factorisation (covariances close to a multiple of the
     identity); the residual then comes from a probe vector and the guard still passes previous factors on."""

@@ -165,3 +165,32 @@ def test_migrate_hook_replaces_the_worst_residents(name):
         assert float(b.global_best_fitness) == 0.0 and float(b.global_best_location.abs().max()) == 0.0
     else:
         assert float(b.fitness[b.best_index]) == 0.0
+
+
+def test_newton_schulz_plan_picks_the_driver_by_conditioning():
+    """Host decisions of a factorisation (``NewtonSchulzSqrt.plan``) from the condition bound two calls ago: mirrored
+    plane products while it is small, plain plane products with two and then three planes beyond, the fp32 library
+    products only past ``PLANE_COND_MAX``; the choice is stored in the control (``ns_sym``) for recorded steps."""
+    from evox_amd.ops.cma import NewtonSchulzSqrt
+
+    ns = NewtonSchulzSqrt(planes=2, initial_cond=1.0)
+    ctrl = ns.init_control(8, torch.device("cpu"))
+
+    def plan_for(cond):
+        rec = torch.tensor([cond / 2.0, cond, 1.0, 1.0, 1.0, 1e-5, 0.0])
+        c = dict(ctrl, ns_calls=5, ns_used1=3, ns_used2=3, ns_res1=rec, ns_res2=rec)
+        pl = ns.plan(c, False, True, True)
+        return pl, ns.commit(c, pl, rec, c["ns_vec"], False)["ns_sym"]
+
+    pl, sym = plan_for(4.0)
+    assert pl["symmetric"] and not pl["full"] and pl["planes"] == 2 and sym == 1
+    pl, sym = plan_for(500.0)
+    assert pl["symmetric"] and pl["full"] and pl["planes"] == 2 and sym == 2
+    pl, sym = plan_for(8000.0)
+    assert pl["symmetric"] and pl["full"] and pl["planes"] == 3 and sym == 3
+    pl, sym = plan_for(1e6)
+    assert not pl["symmetric"] and not pl["full"] and sym == 0
+    # a recorded step keeps the driver of the call before the recording
+    for stored, want in ((1, (True, False, 2)), (2, (True, True, 2)), (3, (True, True, 3)), (0, (False, False, 2))):
+        pl = ns.plan(dict(ctrl, ns_calls=5, ns_sym=stored), True, True, True)
+        assert (pl["symmetric"], pl["full"], pl["planes"]) == want

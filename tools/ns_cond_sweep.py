@@ -2,8 +2,8 @@
 
 For every condition number a covariance ``C = Q diag(λ) Qᵀ`` (log-uniform spectrum between 1 and cond, random
 orthogonal Q) is factorised repeatedly through the controller CMA-ES uses (``ops.cma.NewtonSchulzSqrt.step``) until
-the iteration count has settled; reported are the settled count, which driver ran (symmetric bf16 planes or the fp32
-library products), the time of one factorisation, its residual ``‖Z·Y − I‖_F/√n`` measured in fp64 on the host, and
+the iteration count has settled; reported are the settled count, which driver ran (bf16 planes with mirrored products, with plain
+products on two or three planes, or the fp32 library products), the time of one factorisation, its residual ``‖Z·Y − I‖_F/√n`` measured in fp64 on the host, and
 for comparison the time of ``torch.linalg.eigh`` on the same matrix.
 
     python tools/ns_cond_sweep.py [--n 1000] [--planes 2] > gpurun_out/ns_cond_sweep.txt
@@ -61,7 +61,8 @@ def main():
             torch.linalg.eigh(C)
         torch.cuda.synchronize()
         eigh_ms = (time.perf_counter() - t0) / 3 * 1e3
-        driver = "bf16-planes-symmetric" if ns.symmetric_calls - sym0 > args.timed // 2 else "fp32-library"
+        sym = int(ctrl["ns_sym"])          # driver of the last call: 0 library, 1 mirrored planes, 2 / 3 plain products on 2 / 3 planes
+        driver = {0: "fp32-library", 1: "bf16-planes-symmetric", 2: "bf16-planes-plain-2", 3: "bf16-planes-plain-3"}[sym]
         print(f"{cond:9.0e}  {int(ctrl['ns_iters']):3d}  {driver:22s}  {ms:8.3f}  inv-residual {res:.2e}  sqrt-error {acc:.2e}  eigh {eigh_ms:7.2f}",
               flush=True)
 
