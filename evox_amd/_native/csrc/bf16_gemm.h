@@ -278,7 +278,27 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(Args<NP> g, Epi ep
 
   const auto est = epi.init(z);
   const int mirror = UPPER ? (tm_i != tn_i ? 1 : 2) : 0;   // 1: tile above the diagonal, 2: on it
-  if constexpr (Epi::kRowStaged && (16 % TN == 0)) {
+  if constexpr (Epi::kTileStaged && BM == BN) {
+    // The whole BM x BN tile passes through LDS: the epilogue then stores complete rows — of the tile and, for a
+    // symmetric product or a result that is kept in both orientations, of its transpose — instead of 16 rows of 64
+    // bytes per wave-instruction and single bf16 elements for the mirrored half.
+    constexpr int P = BN + 1;                            // odd pitch: column reads are free of bank conflicts
+    static_assert(2 * BM * P * 4 <= G::LDS_BYTES, "tile and scratch reuse the stage memory");
+    __syncthreads();                                     // every wave has finished reading the last stage
+    float* tile = reinterpret_cast<float*>(smem);
+    float* scratch = tile + BM * P;
+    if (!(g.probe & 4)) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          float* q = tile + (wm0 + a * 16 + (lane & 15)) * P + wn0 + b * 16 + (lane >> 4) * 4;
+          q[0] = acc[a][b][0]; q[1] = acc[a][b][1]; q[2] = acc[a][b][2]; q[3] = acc[a][b][3];
+        }
+      __syncthreads();
+      epi.template store_tile<BM, P>(est, z, m0, n0, tile, scratch, mirror, (int)threadIdx.x, G::NT);
+    }
+  } else if constexpr (Epi::kRowStaged && (16 % TN == 0)) {
     // Row-contiguous stores: a lane holds 4 columns of one row and a wave-instruction would touch 16 rows with 64
     // bytes each.  Each wave passes its 16-row blocks through a private LDS patch and stores 16 / TN whole rows of
     // its TN * 64-byte wide tile per instruction instead.
@@ -320,6 +340,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_nt_kernel(Args<NP> g, Epi ep
 // X[m][n] = mean[n] + sigma * v   (fp32 out, row pitch ldo a multiple of 4, base 16-byte aligned)
 struct EpiSample {
   static constexpr bool kRowStaged = true;
+  static constexpr bool kTileStaged = false;
   float* __restrict__ out;
   const float* __restrict__ mean;
   const float* __restrict__ sigma;
@@ -346,6 +367,7 @@ struct EpiSample {
 // raw partial sums of one K split: ws[split][m][n] (pitch ld, a multiple of 4; only computed tiles are written)
 struct EpiSlab {
   static constexpr bool kRowStaged = true;
+  static constexpr bool kTileStaged = false;
   float* __restrict__ ws;
   long long ld, slab;
   int M, N, splits;
@@ -372,6 +394,7 @@ struct EpiSlab {
 template <int NPO>
 struct EpiAffine {
   static constexpr bool kRowStaged = false;
+  static constexpr bool kTileStaged = true;        // square tiles go through store_tile, others through operator()
   struct Out {
     float* f32[MAXB];             // optional fp32 image, pitch ldf
     uint16_t* pl[MAXB][NPO];      // optional split planes, pitch ldp (pl[z][0] == nullptr: none)
@@ -417,6 +440,109 @@ struct EpiAffine {
       }
     }
   }
+  // four consecutive elements of row r, columns c .. c + 3 (c a multiple of 4; r < M, c < N): fp32 image and planes
+  __device__ __forceinline__ void put4(float* f32, uint16_t* const (&pl)[NPO], int r, int c, const float (&x)[4]) const {
+    if (c + 3 < N && (ldf & 3) == 0) {
+      if (f32 != nullptr) *reinterpret_cast<float4*>(f32 + (long long)r * ldf + c) = make_float4(x[0], x[1], x[2], x[3]);
+      if (pl[0] != nullptr) {
+        float rem[4] = {x[0], x[1], x[2], x[3]};
+#pragma unroll
+        for (int p = 0; p < NPO; ++p) {
+          uint32_t b[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            b[k] = f32_to_bf16_bits(rem[k]);
+            rem[k] -= bf16_bits_to_f32(b[k]);
+          }
+          *reinterpret_cast<uint2*>(pl[p] + (long long)r * ldp + c) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c + k >= N) break;
+      if (f32 != nullptr) f32[(long long)r * ldf + c + k] = x[k];
+      if (pl[0] != nullptr) {
+        float rem = x[k];
+#pragma unroll
+        for (int p = 0; p < NPO; ++p) {
+          const uint32_t b = f32_to_bf16_bits(rem);
+          pl[p][(long long)r * ldp + c + k] = (uint16_t)b;
+          rem -= bf16_bits_to_f32(b);
+        }
+      }
+    }
+  }
+
+  // Epilogue of a square B x B tile held in LDS (`tile`, pitch P floats; `scratch`: a second array of that shape).
+  // Every output is stored in complete rows; the transposed copy (mirror 1), the symmetric fill of a diagonal tile
+  // (mirror 2) and the planes of the transpose (plt) read the finished values back from `scratch` column-wise.
+  template <int B, int P>
+  __device__ __forceinline__ void store_tile(const State& st, int z, int m0, int n0, const float* tile, float* scratch,
+                                             int mirror, int tid, int nt) const {
+    constexpr int QPR = B / 4, NQ = B * QPR;
+    uint16_t* const none[NPO] = {};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q >= nout) break;
+      const Out& w = o[q];
+      if (st.skip && w.prev[z] == nullptr) continue;
+      const bool has_t = w.plt[z][0] != nullptr;
+      const bool staged = mirror != 0 || has_t;
+      for (int e = tid; e < NQ; e += nt) {
+        const int row = e / QPR, c4 = (e - row * QPR) * 4;
+        const int m = m0 + row, n = n0 + c4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (m < M && n < N) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (n + k >= N) break;
+            float y;
+            if (st.skip) {
+              y = w.prev[z][(long long)m * ldf + n + k];
+            } else {
+              y = w.alpha * tile[row * P + c4 + k];
+              if (w.cin[z] != nullptr) y = fmaf(st.bt[q], w.cin[z][(long long)m * ldf + n + k], y);
+              if (m == n + k) y += w.gamma;
+              y *= st.sc[q];
+            }
+            x[k] = y;
+          }
+          if (mirror != 2) put4(w.f32[z], w.pl[z], m, n, x);
+        }
+        if (staged) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) scratch[row * P + c4 + k] = x[k];
+        }
+      }
+      if (!staged) continue;
+      __syncthreads();
+      for (int e = tid; e < NQ; e += nt) {
+        const int row = e / QPR, c4 = (e - row * QPR) * 4;
+        float x[4];
+        if (mirror == 2) {
+          // tile on the diagonal: both halves from the elements on and above it — symmetric to the last bit
+          const int m = m0 + row, n = n0 + c4;
+          if (m >= M || n >= N) continue;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = row <= c4 + k ? scratch[row * P + c4 + k] : scratch[(c4 + k) * P + row];
+          put4(w.f32[z], w.pl[z], m, n, x);
+          continue;
+        }
+        // row `row` of the transposed tile: element k is (original row c4 + k, original column row)
+        const int m = n0 + row, n = m0 + c4;
+        if (m >= N || n >= M) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) x[k] = scratch[(c4 + k) * P + row];
+        if (mirror == 1) put4(w.f32[z], w.pl[z], m, n, x);
+        if (has_t) put4(nullptr, w.plt[z], m, n, x);
+      }
+      __syncthreads();                                     // scratch is reused by the next output
+    }
+    (void)none;
+  }
+
   __device__ __forceinline__ void operator()(const State& st, int z, int, int m, int n, f32x4v v, int mirror) const {
     if (m >= M || n >= N) return;
 #pragma unroll

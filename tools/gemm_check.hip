@@ -333,6 +333,9 @@ static void check_symm(const Mat& A, const Mat& B, const std::vector<double>& re
 
 int main(int argc, char** argv) {
   const bool quick = argc > 1 && atoi(argv[1]) == 1;
+  // timing experiments (results are not checked): GEMM_PROBE = 1 stage the first steps only, 2 skip the multiply,
+  // 4 skip the epilogue (sums of these)
+  if (const char* e = getenv("GEMM_PROBE")) g_probe = atoi(e);
   std::mt19937 rng(1234);
   {
     // small odd shapes first: edge handling
