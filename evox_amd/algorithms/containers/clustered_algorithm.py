@@ -25,7 +25,7 @@ from ...core.algorithm import Algorithm
 from ...core.state import State
 from ...core import distributed as dist
 from ...core.module import Stateful
-from ._members import as_stack, batch, member_ask, member_tell, widen
+from ._members import as_stack, batch, for_each_member, member_ask, member_tell, widen
 
 
 class ClusterdAlgorithm(Algorithm):
@@ -72,11 +72,31 @@ class ClusterdAlgorithm(Algorithm):
             key = rnd.fold_in(key, dist.get_process_id())
         return super().init(key, no_state)
 
+    # -- recording a generation into a graph: the members' host counters and variants are the container's ---------
+    def graph_host_counters(self):
+        out = []
+        for name, m in zip(self.members._names, self.members):
+            extra = getattr(m, "graph_host_counters", None)
+            for c in (extra() if extra else ()):
+                path = f"children/members/children/{name}/fields/"
+                out.append(path + c if isinstance(c, str) else (path + c[0], c[1]))
+        return tuple(out)
+
+    def graph_variant(self, state):
+        member = state.get_child_state("members")
+        variants = []
+        for name, m in zip(self.members._names, self.members):
+            fn = getattr(m, "graph_variant", None)
+            if fn is not None:
+                variants.append(fn(member.get_child_state(name)))
+        return tuple(variants) if variants else None
+
+    @property
+    def graph_settle_steps(self):
+        return max((int(getattr(m, "graph_settle_steps", 0) or 0) for m in self.members), default=0)
+
     def _ask(self, state, first):
-        pops = []
-        for m in self.members:
-            pop, state = member_ask(m, state, first)
-            pops.append(pop)
+        pops, state = for_each_member(list(self.members), state, lambda m, s: member_ask(m, s, first))
         pop = pops[0] if len(pops) == 1 else torch.cat(pops, dim=1)
         if self.distribute and dist.get_world_size() > 1:
             # (P, C_local·d) per rank -> (P, C·d): ranks hold consecutive blocks
@@ -85,8 +105,7 @@ class ClusterdAlgorithm(Algorithm):
         return pop, state
 
     def _tell(self, state, fitness, first):
-        for m in self.members:
-            state = member_tell(m, state, fitness, first)
+        _, state = for_each_member(list(self.members), state, lambda m, s: (None, member_tell(m, s, fitness, first)))
         return state
 
     def init_ask(self, state):

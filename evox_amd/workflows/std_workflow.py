@@ -337,9 +337,10 @@ class StdWorkflow(Workflow):
                 raise ValueError("graph_step cannot record host-side evaluation or migration")
             extra = getattr(self.algorithm, "graph_host_counters", None)
             counters = ["fields/generation"]
-            for c in (extra() if extra else ()):         # names, or (name, modulus) for counters that wrap around
-                counters.append(f"children/algorithm/fields/{c}" if isinstance(c, str)
-                                else (f"children/algorithm/fields/{c[0]}", c[1]))
+            for c in (extra() if extra else ()):         # names, or (name, modulus) for counters that wrap around;
+                name = c if isinstance(c, str) else c[0]  # a name with a "/" is a path below the algorithm's state (containers)
+                path = f"children/algorithm/{name}" if "/" in name else f"children/algorithm/fields/{name}"
+                counters.append(path if isinstance(c, str) else (path, c[1]))
             graphed = self._graphed[variant] = GraphedStep(self._bare_step, host_counters=counters, mode=self.graph_mode)
         hooks = self.registered_hooks
         for m in hooks["pre_step"]:

@@ -201,3 +201,29 @@ def test_batched_clustered_cma_es_on_gpu():
     inner = state.get_child_state("algorithm").get_child_state("members").get_child_state("m0000")
     assert inner.C.shape == (100, 10, 10) and inner.C.is_cuda and inner.sigma.shape == (100,)
     assert float(monitor.get_best_fitness()) < 0.7 * first
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base", ["DE", "SHADE", "SepCMAES"])
+def test_member_loop_container_records_with_its_members_host_counters(base):
+    """A container over members that keep host-side counters (DE's sliding window offset, CMA-ES's generation count)
+    hands those counters — with their paths below its own state — to the recording, so the whole member loop replays
+    from one HIP graph and equals eager issue."""
+    dev = torch.device("cuda")
+    lb, ub = torch.full((5,), -10.0, device=dev), torch.full((5,), 10.0, device=dev)
+    make = {"DE": lambda: algorithms.DE(lb, ub, 64), "SHADE": lambda: algorithms.SHADE(lb, ub, 64),
+            "SepCMAES": lambda: algorithms.SepCMAES(torch.full((5,), 3.0, device=dev), 1.0, pop_size=64)}[base]
+    out = {}
+    for mode in (False, True):
+        algo = algorithms.ClusterdAlgorithm(make(), dim=40, num_cluster=8)
+        assert not algo.fused and len(algo.members) == 8
+        wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), graph_step=mode)
+        state = wf.init(ex.PRNGKey(7).to(dev))
+        for _ in range(25):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        m0 = state.get_child_state("algorithm").get_child_state("members").get_child_state("m0003")
+        out[mode] = (m0.mean if base == "SepCMAES" else m0.population).clone()
+        if mode:
+            assert wf.graph_replays >= 15
+    assert torch.equal(out[True], out[False])
