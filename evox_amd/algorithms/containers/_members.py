@@ -107,3 +107,39 @@ def for_each_member(members, state, call):
         r, state = call(m, state)
         results.append(r)
     return results, state
+
+
+class MemberRecording:
+    """For containers with a stack of members (attribute ``members_attr``): the members' host counters, recording
+    variants and settling generations are the container's (paths below the container's own state), so that a workflow
+    can record the whole member loop."""
+
+    members_attr = "members"
+
+    @property
+    def _member_stack(self):
+        return getattr(self, self.members_attr)
+
+    def graph_host_counters(self):
+        out = []
+        stack = self._member_stack
+        for name, m in zip(stack._names, stack):
+            extra = getattr(m, "graph_host_counters", None)
+            for c in (extra() if extra else ()):
+                path = f"children/{self.members_attr}/children/{name}/fields/"
+                out.append(path + c if isinstance(c, str) else (path + c[0], c[1]))
+        return tuple(out)
+
+    def graph_variant(self, state):
+        member = state.get_child_state(self.members_attr)
+        variants = []
+        stack = self._member_stack
+        for name, m in zip(stack._names, stack):
+            fn = getattr(m, "graph_variant", None)
+            if fn is not None:
+                variants.append(fn(member.get_child_state(name)))
+        return tuple(variants) if variants else None
+
+    @property
+    def graph_settle_steps(self):
+        return max((int(getattr(m, "graph_settle_steps", 0) or 0) for m in self._member_stack), default=0)

@@ -25,10 +25,10 @@ from ...core.algorithm import Algorithm
 from ...core.state import State
 from ...core import distributed as dist
 from ...core.module import Stateful
-from ._members import as_stack, batch, for_each_member, member_ask, member_tell, widen
+from ._members import MemberRecording, as_stack, batch, for_each_member, member_ask, member_tell, widen
 
 
-class ClusterdAlgorithm(Algorithm):
+class ClusterdAlgorithm(MemberRecording, Algorithm):
     def __init__(self, base_algorithm, dim: int, num_cluster: int, fuse="auto", distribute: bool = False):
         """``fuse``: "auto" (fuse when the base algorithm allows it), True (require it) or False (member loop).
         ``distribute``: deal the blocks out over the ranks of the job (``num_cluster`` divisible by the world size)."""
@@ -71,29 +71,6 @@ class ClusterdAlgorithm(Algorithm):
         if self.distribute and key is not None and dist.get_world_size() > 1:
             key = rnd.fold_in(key, dist.get_process_id())
         return super().init(key, no_state)
-
-    # -- recording a generation into a graph: the members' host counters and variants are the container's ---------
-    def graph_host_counters(self):
-        out = []
-        for name, m in zip(self.members._names, self.members):
-            extra = getattr(m, "graph_host_counters", None)
-            for c in (extra() if extra else ()):
-                path = f"children/members/children/{name}/fields/"
-                out.append(path + c if isinstance(c, str) else (path + c[0], c[1]))
-        return tuple(out)
-
-    def graph_variant(self, state):
-        member = state.get_child_state("members")
-        variants = []
-        for name, m in zip(self.members._names, self.members):
-            fn = getattr(m, "graph_variant", None)
-            if fn is not None:
-                variants.append(fn(member.get_child_state(name)))
-        return tuple(variants) if variants else None
-
-    @property
-    def graph_settle_steps(self):
-        return max((int(getattr(m, "graph_settle_steps", 0) or 0) for m in self.members), default=0)
 
     def _ask(self, state, first):
         pops, state = for_each_member(list(self.members), state, lambda m, s: member_ask(m, s, first))

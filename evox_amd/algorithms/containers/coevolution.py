@@ -16,7 +16,7 @@ import torch
 from ...core import random as rnd
 from ...core.algorithm import Algorithm
 from ...core.state import State
-from ._members import as_stack, batch, member_ask, member_tell, same_configuration
+from ._members import MemberRecording, as_stack, batch, member_ask, member_tell, same_configuration
 
 
 class _CoevolutionBase(Algorithm):
@@ -73,7 +73,9 @@ class _CoevolutionBase(Algorithm):
         return state.replace(best_fit=fitness[best].expand(self.num_subpops).clone(), best_dec=best_dec, coop_pops=None)
 
 
-class VectorizedCoevolution(_CoevolutionBase):
+class VectorizedCoevolution(MemberRecording, _CoevolutionBase):
+    members_attr = "base_algorithms"
+
     _can_batch = True
 
     def setup(self, key):
