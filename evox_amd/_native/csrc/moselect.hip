@@ -359,6 +359,79 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_blocked_kernel(const 
   }
 }
 
+// The blocked sort on PACKED entries.  What a compare-swap moves decides its cost: (index, key 1, key 2) is three
+// conditional moves per side and two more to pick the key.  Here an entry is ONE word, (r1 << 16) | r2, with r1 and r2
+// the dense ranks of the element's two keys (equal keys share a rank, so `<` on ranks is `<` on keys; 0 is the sentinel
+// below every element): a comparison by key 1 looks at the upper halves, by key 2 at the lower halves, and a swap moves
+// one register per side (one bit-field extract per side picks the deciding rank).  The kernel returns the packed words in their final order; which element each word stands for
+// is recovered outside (elements with both keys equal are indistinguishable to the sort and never pass each other, so
+// the k-th occurrence of a word in the result is the k-th such element in index order).  n <= 65 535.
+template <int B, bool FRESH>
+__global__ __launch_bounds__(1024) void stochastic_ranking_packed_kernel(const uint32_t* __restrict__ packed,
+                                                                         const float* __restrict__ u, float pc, int n,
+                                                                         uint32_t* __restrict__ out,
+                                                                         const int32_t* __restrict__ seed_ptr,
+                                                                         const float* __restrict__ pc_dev) {
+  static_assert(B % 4 == 0, "coin groups hold four positions");
+  if (pc_dev) pc = *pc_dev;
+  constexpr int T = 1024;
+  __shared__ uint32_t c_w[T], f_w[T];
+  const int t = 2 * ((threadIdx.x >> 7) * 64 + (threadIdx.x & 63)) + ((threadIdx.x >> 6) & 1);
+  const int threads = (n + B - 1) / B;
+  uint32_t x[B];
+  uint32_t offs[FRESH ? 1 : B];                          // per-position coins: the bit offset of each comparator's key
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    const int p = t * B + q;
+    x[q] = p < n ? packed[p] : 0u;
+    if constexpr (!FRESH) offs[q] = p < n - 1 && u[p] < pc ? 16u : 0u;
+  }
+  const uint32_t seed = FRESH ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
+  f_w[t] = x[0];
+  __syncthreads();
+  const int sweeps = (n + 1) / 2;
+  const int steps = threads + 2 * sweeps;
+  const bool has_work = t < threads;
+  for (int step = 0; step < steps; ++step) {
+    const int d = step - t;
+    if (has_work && d >= 0 && !(d & 1) && (d >> 1) < sweeps) {
+      uint32_t a = t == 0 ? x[0] : c_w[t - 1];
+      const uint32_t nx = t == threads - 1 ? 0u : f_w[t + 1];
+      uint32_t masks[B / 4];
+      if constexpr (FRESH) {
+#pragma unroll
+        for (int w = 0; w < B / 4; ++w)
+          masks[w] = sr_coin_mask(sr_coin_group(seed, (uint32_t)(d >> 1), (uint32_t)(t * (B / 4) + w)), pc7);
+      }
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const uint32_t b = q + 1 < B ? x[q + 1] : nx;
+        // where the deciding rank starts in the word: bit 16 (key 1) when the coin is set, bit 0 (key 2) otherwise
+        const uint32_t off = FRESH ? (masks[q >> 2] >> (8 * (q & 3) + 3)) & 16u : offs[q];
+        const bool lt = __builtin_amdgcn_ubfe(a, off, 16u) < __builtin_amdgcn_ubfe(b, off, 16u);
+        x[q] = lt ? b : a;                                 // b moves left, a keeps bubbling right
+        a = lt ? a : b;
+      }
+      c_w[t] = a;
+      f_w[t] = x[0];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    const int p = t * B + q;
+    if (p < n) out[p] = x[q];
+  }
+}
+
+template <int B>
+int launch_ranking_packed(const uint32_t* packed, const float* u, float pc, int n, uint32_t* out, const int32_t* seed,
+                          const float* pc_dev, hipStream_t st) {
+  if (seed) stochastic_ranking_packed_kernel<B, true><<<1, 1024, 0, st>>>(packed, u, pc, n, out, seed, pc_dev);
+  else stochastic_ranking_packed_kernel<B, false><<<1, 1024, 0, st>>>(packed, u, pc, n, out, seed, pc_dev);
+  return last_launch_status();
+}
+
 template <int B>
 int launch_ranking_blocked(const float* I1, const float* I2, const float* u, float pc, int n, int64_t* rank,
                            const int32_t* seed, const float* pc_dev, hipStream_t st) {
@@ -592,6 +665,18 @@ EVOX_API int evox_hip_stochastic_ranking_fresh_dev(const float* I1, const float*
                                                    int n, int64_t* rank, int* scratch, void* stream) {
   if (seed == nullptr || pc == nullptr) return (int)hipErrorInvalidValue;
   return stochastic_ranking_any(I1, I2, nullptr, 0.5f, n, rank, scratch, seed, pc, stream);
+}
+
+// The stochastic ranking on packed entries (see stochastic_ranking_packed_kernel): packed[i] = (r1[i] << 16) | r2[i],
+// out = the packed words in their final order.  u / seed / pc as above (pc_dev optional).  4096 < n <= 24 576.
+EVOX_API int evox_hip_stochastic_ranking_packed(const uint32_t* packed, const float* u, const int32_t* seed, float pc,
+                                                const float* pc_dev, int n, uint32_t* out, void* stream) {
+  if (n <= 1 || n > 1024 * 24 || packed == nullptr || out == nullptr || (u == nullptr && seed == nullptr))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (n <= 1024 * 8) return launch_ranking_packed<8>(packed, u, pc, n, out, seed, pc_dev, st);
+  if (n <= 1024 * 16) return launch_ranking_packed<16>(packed, u, pc, n, out, seed, pc_dev, st);
+  return launch_ranking_packed<24>(packed, u, pc, n, out, seed, pc_dev, st);
 }
 
 // MOEA/D replacement as a scatter: entry e = (row, slot) offers values[e] to sub-problem target[e]; a sub-problem takes

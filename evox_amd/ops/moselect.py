@@ -28,6 +28,7 @@ _native.register_hip_api({
     "evox_hip_stochastic_ranking": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_stochastic_ranking_fresh": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_stochastic_ranking_fresh_dev": (I, [P, P, P, P, I, P, P, P]),
+    "evox_hip_stochastic_ranking_packed": (I, [P, P, P, F, P, I, P, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
@@ -423,6 +424,51 @@ def coin_reference(seed: int, sweep: int, position: int, pc: float) -> bool:
     return ((word >> (8 * (position & 3))) & 0x7F) < pc7
 
 
+def _dense_ranks(v: torch.Tensor) -> torch.Tensor:
+    """1-based dense ranks in ascending order: equal values share a rank, so ``<`` on ranks is ``<`` on values (NaN keys
+    count as the smallest value)."""
+    from . import sort as _sort
+
+    v = torch.where(torch.isnan(v), torch.full_like(v, float("-inf")), v)
+    order = _sort.argsort(v)
+    sv = v[order]
+    new = torch.ones_like(sv, dtype=torch.int32)
+    new[1:] = (sv[1:] != sv[:-1]).to(torch.int32)
+    dense = torch.cumsum(new, 0, dtype=torch.int32)
+    out = torch.empty_like(dense)
+    out[order] = dense
+    return out
+
+
+def _stochastic_ranking_packed(I1, I2, u, pc, seed, pc_dev):
+    """The blocked sort on one-word entries (``csrc/moselect.hip::stochastic_ranking_packed_kernel``): both keys are
+    replaced by their dense ranks, packed into one 32-bit word per element; the kernel returns the words in their final
+    order, and the element behind each word is found by matching two stable sorts by word (elements whose two keys are
+    both equal never pass each other in the bubble sort, so the k-th occurrence of a word is the k-th such element in
+    index order).  Same permutation as the float kernels for NaN-free keys."""
+    from . import sort as _sort
+
+    n = I1.shape[0]
+    packed = (_dense_ranks(I1) << 16) | _dense_ranks(I2)
+    out = torch.empty(n, dtype=torch.int32, device=I1.device)
+    check(hip().evox_hip_stochastic_ranking_packed(packed.data_ptr(), u.data_ptr() if u is not None else None,
+                                                   seed.data_ptr() if seed is not None else None, float(pc) if pc_dev is None else 0.5,
+                                                   pc_dev.data_ptr() if pc_dev is not None else None, n, out.data_ptr(),
+                                                   stream_of(I1)), "stochastic_ranking_packed")
+    by_word = _sort.radix_argsort(packed, bits=(0, 32))            # elements, by word then index
+    positions = _sort.radix_argsort(out, bits=(0, 32))             # final positions, by word then position
+    rank = torch.empty(n, dtype=torch.int64, device=I1.device)
+    rank[positions] = by_word
+    return rank
+
+
+def _packed_ranking_applies(I1) -> bool:
+    import os
+
+    n = I1.shape[0]
+    return on_gpu(I1) and 4096 < n <= 24 * 1024 and os.environ.get("EVOX_AMD_SRA_PACKED", "1") != "0"
+
+
 def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor:
     """SRA's stochastic bubble sort, ⌈n/2⌉ sweeps; a comparison ranks by ``I1`` when its coin says so and by ``I2``
     otherwise; larger values move to the front.
@@ -439,6 +485,8 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
         # probability and seed both on the device: the call reads no host value (it can be recorded into a HIP graph)
         seed = seed.reshape(-1)[:1].to(device=I1.device, dtype=torch.int32).contiguous()
         pcd = pc.reshape(-1)[:1].to(torch.float32).contiguous()
+        if _packed_ranking_applies(I1):
+            return _stochastic_ranking_packed(I1, I2, None, 0.5, seed, pcd)
         scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
         check(hip().evox_hip_stochastic_ranking_fresh_dev(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pcd.data_ptr(), n,
                                                           rank.data_ptr(), scratch.data_ptr() if scratch is not None else None,
@@ -447,6 +495,8 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
     pc = float(pc)
     if seed is not None:
         seed = seed.reshape(-1)[:1].to(device=I1.device, dtype=torch.int32).contiguous()
+        if _packed_ranking_applies(I1):
+            return _stochastic_ranking_packed(I1, I2, None, pc, seed, None)
         if on_gpu(I1):
             scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
             check(hip().evox_hip_stochastic_ranking_fresh(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pc, n, rank.data_ptr(),
@@ -456,6 +506,8 @@ def stochastic_ranking(I1, I2, u, pc, seed: torch.Tensor = None) -> torch.Tensor
             _native.cpu().evox_cpu_stochastic_ranking_fresh(I1.data_ptr(), I2.data_ptr(), seed.data_ptr(), pc, n, rank.data_ptr())
         return rank
     u = u.contiguous().float()
+    if _packed_ranking_applies(I1):
+        return _stochastic_ranking_packed(I1, I2, u, pc, None, None)
     if on_gpu(I1):
         scratch = torch.empty(n, dtype=torch.int32, device=I1.device) if n > 40000 else None
         check(hip().evox_hip_stochastic_ranking(I1.data_ptr(), I2.data_ptr(), u.data_ptr(), pc, n, rank.data_ptr(),

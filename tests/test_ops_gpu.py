@@ -1727,6 +1727,32 @@ def test_stochastic_ranking_with_fresh_coins_equals_host_twin(cuda, n):
     assert torch.equal(got_dev, got)
 
 
+@pytest.mark.parametrize("n", [4100, 9000, 20000])
+def test_stochastic_ranking_on_packed_ranks_handles_equal_elements(cuda, n, monkeypatch):
+    """Long permutations are sorted on one-word entries (both keys replaced by dense ranks): with many elements whose
+    two keys are BOTH equal — indistinguishable to the sort, recovered by occurrence order — and with -0 / +0 and
+    infinities among the keys, the result equals the host twin and the three-word kernel, for both kinds of coins."""
+    from evox_amd.ops import moselect
+
+    g = torch.Generator().manual_seed(n)
+    I1 = (torch.rand(n, generator=g) * 6).round() / 6
+    I2 = (torch.rand(n, generator=g) * 5).round() / 5 - 0.4
+    I2[I2.abs() < 1e-6] = 0.0
+    I2[::7] = -I2[::7]                                     # some -0.0 next to +0.0
+    I1[::501] = float("inf")
+    I2[::733] = float("-inf")
+    seed = torch.tensor([n], dtype=torch.int32)
+    u = torch.rand(n, generator=g)
+    ref_fresh = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
+    ref_pos = moselect.stochastic_ranking(I1, I2, u, 0.45)
+    for packed in ("1", "0"):
+        monkeypatch.setenv("EVOX_AMD_SRA_PACKED", packed)
+        got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), None, 0.47, seed=seed.to(cuda))
+        assert torch.equal(got.cpu(), ref_fresh), packed
+        got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), u.to(cuda), 0.45)
+        assert torch.equal(got.cpu(), ref_pos), packed
+
+
 @pytest.mark.parametrize("n,mu", [(1000, 5632), (64, 128), (260, 300)])
 def test_packed_gram_equals_full_gram(cuda, n, mu):
     """The tile-packed upper triangle of the rank-mu product — what the ranks of a multi-process job sum — unpacks to the
