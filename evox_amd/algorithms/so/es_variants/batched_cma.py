@@ -32,7 +32,7 @@ def _batched_eigh(C: torch.Tensor, B_prev: Optional[torch.Tensor] = None):
     from ....ops import linalg_small as _ls
 
     if _ls.device_linalg(C, C.shape[-1]):
-        evals, B = _ls.eigh_small(C, B_prev)
+        evals, B = _ls.eigh_small(C, B_prev, spd=True)
         return B.contiguous(), evals
     if C.is_cuda and C.shape[-1] <= _cma._host_max():
         evals, B = torch.linalg.eigh(C.cpu())

@@ -91,16 +91,17 @@ def _host_max() -> int:
 
 
 def _device_jacobi(C) -> bool:
-    """Orders whose symmetric eigendecomposition runs in the one-workgroup Jacobi kernel (``csrc/linalg_small.hip``): up
-    to ``EVOX_AMD_DEVICE_EIGH_MAX`` (default 64: beyond that the host LAPACK round trip is faster in eager issue — order
-    100: 0.3 ms including both copies against 0.5–1.4 ms for the latency-bound kernel) — and up to 384 while a generation
-    is being recorded into a graph, where a host round trip is not possible."""
+    """Orders whose symmetric eigendecomposition runs in the one-workgroup Jacobi kernels (``csrc/linalg_small.hip``): up
+    to ``EVOX_AMD_DEVICE_EIGH_MAX`` (default 134, the largest order whose warm-started positive definite form works in
+    LDS: order 100 takes 0.33–0.54 ms there from the previous eigenvectors against 0.37 ms for copy to the host, LAPACK
+    and copy back, without stalling the stream; beyond 134 the host round trip is faster in eager issue) — and up to 384
+    while a generation is being recorded into a graph, where a host round trip is not possible."""
     from . import linalg_small as _ls
 
     n = C.shape[-1]
     if not _ls.device_linalg(C, n):
         return False
-    return n <= int(os.environ.get("EVOX_AMD_DEVICE_EIGH_MAX", "64")) or torch.cuda.is_current_stream_capturing()
+    return n <= int(os.environ.get("EVOX_AMD_DEVICE_EIGH_MAX", "134")) or torch.cuda.is_current_stream_capturing()
 
 
 def eigh_reference(C, B_prev: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -110,7 +111,7 @@ def eigh_reference(C, B_prev: Optional[torch.Tensor] = None) -> Tuple[torch.Tens
     if _device_jacobi(C):
         from . import linalg_small as _ls
 
-        evals, B = _ls.eigh_small(C, B_prev)
+        evals, B = _ls.eigh_small(C, B_prev, spd=True)         # every caller decomposes a covariance matrix
         return B.contiguous(), evals
     if C.is_cuda and C.shape[-1] <= _host_max():
         evals, B = torch.linalg.eigh(C.cpu())

@@ -39,6 +39,8 @@ P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_small_max_lds_floats": (I, []),
     "evox_hip_small_eigh": (I, [P, P, P, P, P, I, I, I, _native.F, P]),
+    "evox_hip_small_eigh_spd": (I, [P, P, P, P, P, P, I, I, I, _native.F, P]),
+    "evox_hip_small_eigh_spd_fits": (I, [I, I]),
     "evox_hip_small_svd_vt": (I, [P, P, P, I, I, I, I, _native.F, P]),
     "evox_hip_small_cholesky": (I, [P, P, I, I, P]),
     "evox_hip_small_qr_q": (I, [P, P, I, I, I, P]),
@@ -56,22 +58,38 @@ def device_linalg(x: torch.Tensor, n: int) -> bool:
             and os.environ.get("EVOX_AMD_SMALL_LINALG", "device") == "device")
 
 
-def eigh_small(C: torch.Tensor, B0: torch.Tensor = None, sort: bool = True, max_sweeps: int = 24):
+def eigh_small(C: torch.Tensor, B0: torch.Tensor = None, sort: bool = True, max_sweeps: int = 24, spd: bool = False,
+               sweeps_out: torch.Tensor = None):
     """``(evals, B)`` of the symmetric (positive semi-definite) ``C`` — (n, n) or (batch, n, n) — by one-sided Jacobi
     rotations, ``C = B diag(evals) Bᵀ`` with the eigenvectors in the columns of ``B``.  ``B0``: eigenvectors of a nearby
     matrix (the previous generation's): the iteration then starts from ``C B0`` and needs one or two sweeps instead of
-    eight.  ``sort``: ascending eigenvalues as ``torch.linalg.eigh`` returns them (tensor ops on the device)."""
+    eight.  ``sort``: ascending eigenvalues as ``torch.linalg.eigh`` returns them (tensor ops on the device).
+
+    ``spd=True`` declares ``C`` positive definite (a covariance matrix): the rotations then work on its Cholesky factor
+    (of ``B0ᵀ C B0`` with ``B0``), which moves half the data per rotation, converges in 7–8 sweeps at any conditioning
+    and in three from a nearby start; orders whose working matrices do not fit the LDS (n > 188, or n > 134 with
+    ``B0``) take the general form.  A direction along which ``C`` is singular to working precision (Cholesky pivot
+    below 1e-6 of its diagonal entry) comes back with eigenvalue 0 and a zero vector.  ``sweeps_out``: an int32 tensor of
+    ``batch`` entries that receives the sweeps taken (``spd`` only)."""
     single = C.dim() == 2
     Cb = (C[None] if single else C).contiguous()
     b, n = Cb.shape[0], Cb.shape[-1]
     V = torch.empty_like(Cb)
-    W = torch.empty_like(Cb)
     ev = torch.empty((b, n), dtype=torch.float32, device=C.device)
     V0 = None
     if B0 is not None:
         V0 = (B0[None] if single else B0).transpose(-1, -2).contiguous()      # vectors as rows = column-major columns
-    check(hip().evox_hip_small_eigh(Cb.data_ptr(), V0.data_ptr() if V0 is not None else None, V.data_ptr(), ev.data_ptr(),
-                                    W.data_ptr(), n, b, int(max_sweeps), _JACOBI_TOL, stream_of(Cb)), "small_eigh")
+    if spd and hip().evox_hip_small_eigh_spd_fits(n, int(V0 is not None)):
+        scratch = torch.empty_like(Cb) if V0 is not None else None
+        check(hip().evox_hip_small_eigh_spd(Cb.data_ptr(), V0.data_ptr() if V0 is not None else None, V.data_ptr(),
+                                            ev.data_ptr(), scratch.data_ptr() if scratch is not None else None,
+                                            sweeps_out.data_ptr() if sweeps_out is not None else None, n, b,
+                                            int(max_sweeps), _JACOBI_TOL, stream_of(Cb)), "small_eigh_spd")
+    else:
+        W = torch.empty_like(Cb)
+        check(hip().evox_hip_small_eigh(Cb.data_ptr(), V0.data_ptr() if V0 is not None else None, V.data_ptr(),
+                                        ev.data_ptr(), W.data_ptr(), n, b, int(max_sweeps), _JACOBI_TOL, stream_of(Cb)),
+              "small_eigh")
     B = V.transpose(-1, -2)
     if sort:
         order = torch.argsort(ev, dim=-1)

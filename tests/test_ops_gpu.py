@@ -2195,6 +2195,89 @@ def test_small_eigh_jacobi_against_fp64(cuda, n):
             assert float((Bq @ torch.diag(evs[s].double().cpu()) @ Bq.T - stack[s].double().cpu()).norm()) < 2e-5 * float(stack[s].norm())
 
 
+@pytest.mark.parametrize("n", [3, 5, 31, 64, 100, 101, 124, 127, 128, 134, 150, 188])
+def test_small_eigh_of_positive_definite_matrices_against_fp64(cuda, n):
+    """The positive definite form (one-sided Jacobi on the Cholesky factor, all in LDS) against ``torch.linalg.eigh`` in
+    fp64 at conditionings 10 … 10⁶: eigenvalues to 1e-5 of the largest (and to 2e-5 / 3e-4 of themselves at cond 10 /
+    10⁴), ``‖B D Bᵀ − C‖`` and orthonormality as the general form; the sweeps taken do not grow with the conditioning; a
+    warm start from the eigenvectors of a nearby matrix takes no more sweeps and gives the same answer; batches in one
+    launch; a matrix of half rank gives finite results: its non-zero eigenpairs, zero eigenvalues with zero vectors for
+    the rest."""
+    from evox_amd.ops import linalg_small as ls
+
+    g = torch.Generator().manual_seed(1000 + n)
+    eye = torch.eye(n, dtype=torch.float64)
+    for cond in (10.0, 1e4, 1e6):
+        Q = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))[0]
+        lam = torch.logspace(0, math.log10(cond), n, dtype=torch.float64)
+        C64 = (Q * lam) @ Q.T
+        C64 = 0.5 * (C64 + C64.T)
+        C = C64.float().to(cuda)
+        ref = torch.linalg.eigvalsh(C.double().cpu())                     # of the matrix as rounded to fp32
+        sweeps = torch.zeros(1, dtype=torch.int32, device=cuda)
+        ev, B = ls.eigh_small(C, spd=True, sweeps_out=sweeps)
+        evd, Bd = ev.double().cpu(), B.double().cpu()
+        if cond <= 1e4:
+            assert float((evd / ref - 1).abs().max()) < (2e-5 if cond <= 10 else 3e-4), cond
+        assert torch.allclose(evd, ref, atol=1e-5 * float(ref.max()))
+        assert float((Bd @ torch.diag(evd) @ Bd.T - C64).norm() / C64.norm()) < 1e-5
+        assert float((Bd.T @ Bd - eye).abs().max()) < 5e-5
+        assert 1 <= int(sweeps) <= 10, (cond, int(sweeps))
+        cold = int(sweeps)
+        if n <= 134 and n > 3:
+            # warm start: the matrix moved by two percent (a rank-n update as a covariance adaptation makes it)
+            Z = (Q * lam.sqrt()) @ torch.randn(n, 3 * n, generator=g, dtype=torch.float64)
+            C2_64 = 0.98 * C64 + 0.02 * (Z @ Z.T) / (3 * n)
+            C2 = C2_64.float().to(cuda)
+            ev2, B2 = ls.eigh_small(C2, B0=B, spd=True, sweeps_out=sweeps)
+            ref2 = torch.linalg.eigvalsh(C2.double().cpu())
+            ev2d, B2d = ev2.double().cpu(), B2.double().cpu()
+            assert torch.allclose(ev2d, ref2, atol=2e-5 * float(ref2.max()))
+            if cond <= 1e4:
+                assert float((ev2d / ref2 - 1).abs().max()) < (5e-5 if cond <= 10 else 6e-4), cond
+            assert float((B2d @ torch.diag(ev2d) @ B2d.T - C2_64).norm() / C2_64.norm()) < 2e-5
+            assert float((B2d.T @ B2d - eye).abs().max()) < 1e-4
+            assert int(sweeps) <= cold + (cond > 1e4), (cond, int(sweeps), cold)
+    stack = torch.stack([C, 2 * C + torch.eye(n, device=cuda), C.flip(0).flip(1)])
+    evs, Bs = ls.eigh_small(stack, spd=True)
+    for s in range(3):
+        want = torch.linalg.eigvalsh(stack[s].double().cpu())
+        assert torch.allclose(evs[s].double().cpu(), want, atol=2e-5 * float(want.max()))
+        Bq = Bs[s].double().cpu()
+        assert float((Bq @ torch.diag(evs[s].double().cpu()) @ Bq.T - stack[s].double().cpu()).norm()) < 2e-5 * float(stack[s].norm())
+    if n > 3:
+        low = torch.randn(n, n // 2, generator=g, dtype=torch.float64)
+        S = (low @ low.T).float().to(cuda)                                 # rank n/2
+        ev, B = ls.eigh_small(S, spd=True)
+        assert bool(torch.isfinite(ev).all()) and bool(torch.isfinite(B).all())
+        want = torch.linalg.eigvalsh(S.double().cpu())
+        assert torch.allclose(ev.double().cpu(), want, atol=1e-4 * float(want.max()))
+        gram = (B.T @ B).double().cpu()
+        on = gram.diagonal() > 0.5                                         # the vectors that are not zero
+        assert int(on.sum()) >= n // 2 and float((gram[on][:, on] - torch.eye(int(on.sum()), dtype=torch.float64)).abs().max()) < 1e-4
+        assert float(gram[~on].abs().max() if bool((~on).any()) else 0.0) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1, 7, 100, 128, 160, 191, 250])
+def test_small_cholesky_in_lds_and_from_memory(cuda, n):
+    """Both forms of the one-workgroup Cholesky factorisation (left-looking in LDS up to order 190, right-looking from
+    memory beyond) against fp64; NaNs from a non-positive pivot on."""
+    from evox_amd.ops import linalg_small as ls
+
+    g = torch.Generator().manual_seed(n)
+    a = torch.randn(n, 2 * n + 3, generator=g, dtype=torch.float64)
+    A64 = a @ a.T / (2 * n + 3) + 0.05 * torch.eye(n, dtype=torch.float64)
+    L = ls.cholesky_small(A64.float().to(cuda))
+    ref = torch.linalg.cholesky(A64)
+    assert torch.allclose(L.double().cpu(), ref, atol=2e-5 * float(ref.abs().max()))
+    assert float(L.triu(1).abs().max()) == 0.0 if n > 1 else True
+    if n >= 7:
+        bad = A64.clone()
+        bad[n // 2, n // 2] = -1.0
+        Lb = ls.cholesky_small(bad.float().to(cuda))
+        assert bool(torch.isfinite(Lb[: n // 2]).all()) and bool(torch.isnan(Lb[n // 2, n // 2]))
+
+
 @pytest.mark.parametrize("k,m", [(1, 50), (8, 100), (50, 100), (50, 2000), (120, 384)])
 def test_small_svd_cholesky_qr_expm_against_fp64(cuda, k, m):
     from evox_amd.ops import linalg_small as ls
