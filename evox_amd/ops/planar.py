@@ -1,0 +1,79 @@
+"""Binding of the planar-physics step kernel (``csrc/planar.hip``): one environment per lane, all sub-steps of an
+environment step in one launch.  The parameter block is the engine's static matrices at fixed offsets."""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from .. import _native
+from ._util import check, hip, on_gpu, stream_of
+
+P, I = _native.P, _native.I
+_native.register_hip_api({
+    "evox_hip_planar_param_floats": (I, []),
+    "evox_hip_planar_step": (I, [P, I, I, I, P, P, P, I, P]),
+})
+
+MAX_LINKS, MAX_CONTACTS, MAX_ACTUATORS = 7, 8, 8
+_OFF = dict(head=0, free=16, anc=32, wcom=96, wcon=160, mass=224, length=232, rest=240, mconst=256, lo=352, hi=368,
+            damping=384, stiffness=400, act_dof=416, act_gear=424)
+
+
+def fits(engine) -> bool:
+    m = engine.model
+    return engine.L <= MAX_LINKS and len(m.contacts) <= MAX_CONTACTS and len(m.actuators) <= MAX_ACTUATORS
+
+
+def applies(engine, q: torch.Tensor) -> bool:
+    """The kernel serves fp32 states on a GPU (``EVOX_AMD_PLANAR=tensor`` keeps the tensor formulation)."""
+    return (on_gpu(q) and q.dtype == torch.float32 and fits(engine)
+            and os.environ.get("EVOX_AMD_PLANAR", "kernel") == "kernel")
+
+
+def param_block(engine) -> torch.Tensor:
+    """The engine's constants as the float block the kernel reads (host tensor)."""
+    m, L, N = engine.model, engine.L, engine.ndof
+    blk = torch.zeros(int(hip().evox_hip_planar_param_floats()) if torch.cuda.is_available() else 432, dtype=torch.float32)
+    head = [L, len(m.contacts), len(m.actuators), m.substeps, m.dt, m.max_velocity, m.gravity, m.contact_stiffness,
+            m.contact_damping, m.friction, m.limit_stiffness, m.limit_damping, m.drag[0], m.drag[1], m.drag[2]]
+    blk[:len(head)] = torch.tensor(head, dtype=torch.float32)
+    free = torch.zeros(N)
+    free[engine.free] = 1.0
+    blk[_OFF["free"]:_OFF["free"] + N] = free
+
+    def put(off, mat, stride):
+        for r in range(mat.shape[0]):
+            blk[off + r * stride: off + r * stride + mat.shape[1]] = mat[r]
+
+    put(_OFF["anc"], engine.anc, MAX_LINKS)
+    put(_OFF["wcom"], engine.W_com, MAX_LINKS)
+    if engine.W_con.shape[0]:
+        put(_OFF["wcon"], engine.W_con, MAX_LINKS)
+    blk[_OFF["mass"]:_OFF["mass"] + L] = engine.mass
+    blk[_OFF["length"]:_OFF["length"] + L] = engine.lengths
+    blk[_OFF["rest"]:_OFF["rest"] + L] = engine.rest_abs
+    put(_OFF["mconst"], engine.M_const, MAX_LINKS + 2)
+    big = 3.0e38                                     # stands for "no limit" (keeps inf − inf out of the kernel)
+    blk[_OFF["lo"]:_OFF["lo"] + N] = engine.lo.clamp_min(-big)
+    blk[_OFF["hi"]:_OFF["hi"] + N] = engine.hi.clamp_max(big)
+    blk[_OFF["damping"]:_OFF["damping"] + N] = engine.damping
+    blk[_OFF["stiffness"]:_OFF["stiffness"] + N] = engine.stiffness
+    for a, (dof, gear) in enumerate(m.actuators):
+        blk[_OFF["act_dof"] + a] = float(dof)
+        blk[_OFF["act_gear"] + a] = float(gear)
+    return blk
+
+
+def step(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, ctrl):
+    """One environment step for every row of ``q`` / ``qd`` (new tensors)."""
+    m = engine.model
+    q, qd = q.contiguous().clone(), qd.contiguous().clone()
+    nact = len(m.actuators)
+    if nact:
+        ctrl = (torch.zeros(q.shape[0], nact, device=q.device) if ctrl is None else ctrl.to(torch.float32).contiguous())
+        assert ctrl.shape == (q.shape[0], nact)
+    assert q.shape == qd.shape == (q.shape[0], engine.ndof)
+    check(hip().evox_hip_planar_step(params.data_ptr(), engine.L, len(m.contacts), nact, q.data_ptr(), qd.data_ptr(),
+                                     ctrl.data_ptr() if nact else None, q.shape[0], stream_of(q)), "planar_step")
+    return q, qd
