@@ -8,8 +8,9 @@
 //
 //   wide layers  (out > 64): a thread owns 4 consecutive output columns (one 16-byte / 8-byte load per
 //                            input row), the LDS read of the input activation is a broadcast;
-//   narrow layers (out <= 64): the weight block is walked as a flat array (coalesced), products are
-//                            accumulated with LDS float atomics, then bias + activation.
+//   narrow layers (out <= 64): the weight block is walked as a flat array (coalesced), every thread sums
+//                            its rows of one column, the partial sums are added in a fixed order (no
+//                            atomics: the same inputs give the same bits), then bias + activation.
 #include "hip_common.h"
 #include <hip/hip_bf16.h>
 #include <cstdlib>
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const T* __restrict__ f
   const int W = d.max_width;
   float* buf0 = lds;                 // [E][W]
   float* buf1 = lds + E * W;
+  float* red = lds + 2 * E * W;      // [E][parts][nout] partial sums of a narrow layer, at most E * NT floats
   const int p = blockIdx.x;
   const T* theta = flat + (int64_t)p * pitch;
   const int t = threadIdx.x;
@@ -134,19 +136,28 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const T* __restrict__ f
         }
       }
     } else {
-      for (int e = t; e < E * nout; e += NT) hout[(e / nout) * W + (e % nout)] = has_b ? ld1(bl + (e % nout)) : 0.f;
-      __syncthreads();
-      const int total = nin * nout;
-      for (int idx = t; idx < total; idx += NT) {
-        const float w = ld1(Wl + idx);
-        const int i = idx / nout, c = idx - i * nout;
+      // narrow layer: the weight block is walked as a flat array (coalesced) — thread t owns column t % nout and the
+      // rows t / nout, t / nout + parts, ...; the partial sums meet in LDS and are added in a FIXED order (bias first,
+      // then part 0, 1, ...), so that the same inputs give the same bits on every call
+      const int parts = NT / nout, c = t % nout, part = t / nout;
+      float acc[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) atomicAdd(&hout[e * W + c], hin[e * W + i] * w);
+      for (int e = 0; e < E; ++e) acc[e] = 0.f;
+      if (part < parts) {
+        for (int i = part; i < nin; i += parts) {
+          const float w = ld1(Wl + (int64_t)i * nout + c);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[e] = fmaf(hin[e * W + i], w, acc[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[(e * parts + part) * nout + c] = acc[e];
       }
       __syncthreads();
       for (int e = t; e < E * nout; e += NT) {
-        float* q = &hout[(e / nout) * W + (e % nout)];
-        *q = activate(*q, act);
+        const int ee = e / nout, cc = e - ee * nout;
+        float sum = has_b ? ld1(bl + cc) : 0.f;
+        for (int pt = 0; pt < parts; ++pt) sum += red[(ee * parts + pt) * nout + cc];
+        hout[ee * W + cc] = activate(sum, act);
       }
     }
     __syncthreads();
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
   const int W = d.max_width;
   float* buf0 = lds;
   float* buf1 = lds + EA * W;
+  float* red = lds + 2 * EA * W;                        // partial sums of a narrow layer, at most EA * NT floats
   const int p0 = blockIdx.x * NP;                       // first pair of this workgroup
   const int t = threadIdx.x;
   auto member = [&](int ea) -> int64_t {                 // population row evaluated by activation set ea
@@ -268,34 +280,38 @@ __global__ __launch_bounds__(NT) void mlp_pair_kernel(const T* __restrict__ flat
         for (int ea = 0; ea < EA; ++ea) hout[ea * W + c] = activate(acc[ea], act);
       }
     } else {
-      // narrow layers: flat walk with LDS accumulation (a small share of the parameters)
-      for (int e = t; e < EA * nout; e += NT) {
-        const int ea = e / nout, c = e - ea * nout;
-        const int q = ea / (2 * E), sign = (ea / E) & 1;
-        float b = has_b ? ld1(bq[q] + c) : 0.f;
-        if (has_b && sign) b = 2.f * ld1c(cbl + c) - b;
-        hout[ea * W + c] = b;
-      }
-      __syncthreads();
-      const int total = nin * nout;
-      for (int idx = t; idx < total; idx += NT) {
-        const float cw = ld1c(Cl + idx);
-        const int i = idx / nout, c = idx - i * nout;
+      // narrow layers (a small share of the parameters): flat coalesced walk, thread t owns column t % nout and every
+      // parts-th row; partial sums meet in LDS and are added in a fixed order (see mlp_forward_kernel)
+      const int parts = NT / nout, c = t % nout, part = t / nout;
+      float acc[EA];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          const float w = ld1(Wq[q] + idx);
-          const float wm = 2.f * cw - w;
+      for (int ea = 0; ea < EA; ++ea) acc[ea] = 0.f;
+      if (part < parts) {
+        for (int i = part; i < nin; i += parts) {
+          const int64_t idx = (int64_t)i * nout + c;
+          const float cw = ld1c(Cl + idx);
 #pragma unroll
-          for (int e = 0; e < E; ++e) {
-            atomicAdd(&hout[((q * 2) * E + e) * W + c], hin[((q * 2) * E + e) * W + i] * w);
-            atomicAdd(&hout[((q * 2 + 1) * E + e) * W + c], hin[((q * 2 + 1) * E + e) * W + i] * wm);
+          for (int q = 0; q < NP; ++q) {
+            const float w = ld1(Wq[q] + idx);
+            const float wm = 2.f * cw - w;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              acc[(q * 2) * E + e] = fmaf(hin[((q * 2) * E + e) * W + i], w, acc[(q * 2) * E + e]);
+              acc[(q * 2 + 1) * E + e] = fmaf(hin[((q * 2 + 1) * E + e) * W + i], wm, acc[(q * 2 + 1) * E + e]);
+            }
           }
         }
+#pragma unroll
+        for (int ea = 0; ea < EA; ++ea) red[(ea * parts + part) * nout + c] = acc[ea];
       }
       __syncthreads();
       for (int e = t; e < EA * nout; e += NT) {
-        float* v = &hout[(e / nout) * W + (e % nout)];
-        *v = activate(*v, act);
+        const int ea = e / nout, cc = e - ea * nout;
+        const int q = ea / (2 * E), sign = (ea / E) & 1;
+        float sum = has_b ? ld1(bq[q] + cc) : 0.f;
+        if (has_b && sign) sum = 2.f * ld1c(cbl + cc) - sum;
+        for (int pt = 0; pt < parts; ++pt) sum += red[(ea * parts + pt) * nout + cc];
+        hout[ea * W + cc] = activate(sum, act);
       }
     }
     __syncthreads();
@@ -314,7 +330,7 @@ int launch_pairs(const T* flat, int64_t pitch, const CT* center, int half, const
   // Pairs per workgroup: sharing one centre pass between several pairs was measured slower than one
   // pair per workgroup (98 / 123 / 165 ms per OpenES generation for 1 / 2 / 4 pairs: fewer, fatter
   // workgroups hide less latency and the centre stays cached anyway), so 1 is the default.
-  auto lds_of = [&](int np) { return (size_t)2 * (2 * np * E) * d.max_width * sizeof(float); };
+  auto lds_of = [&](int np) { return (size_t)(2 * np * E) * (2 * d.max_width + NT) * sizeof(float); };
   const char* cap_env = getenv("EVOX_AMD_MLP_PAIRS");
   const int cap = cap_env ? atoi(cap_env) : 1;
   if (cap >= 4 && half % 4 == 0 && lds_of(4) <= 64 * 1024 && E == 1)
@@ -343,7 +359,7 @@ int launch(const T* flat, int64_t pitch, const void* center, int center_dtype, i
     }
     return (int)hipErrorInvalidValue;
   }
-  const size_t lds = (size_t)2 * E * d.max_width * sizeof(float);
+  const size_t lds = (size_t)E * (2 * d.max_width + NT) * sizeof(float);
 #define EVOX_MLP(EE) mlp_forward_kernel<T, EE><<<P, NT, lds, s>>>(flat, pitch, obs, out, d)
   switch (E) {
     case 1: EVOX_MLP(1); break;
@@ -383,7 +399,7 @@ static int mlp_dispatch(const void* flat, int dtype, int64_t pitch, const void* 
   if (off > pitch) return (int)hipErrorInvalidValue;
   d.max_width = (d.max_width + 3) / 4 * 4;
   const int ea = center ? 2 * E : E;
-  if ((size_t)2 * ea * d.max_width * sizeof(float) > 64 * 1024) return (int)hipErrorInvalidValue;
+  if ((size_t)ea * (2 * d.max_width + NT) * sizeof(float) > 64 * 1024) return (int)hipErrorInvalidValue;
   const int half = P / 2;
   if (dtype == 1)
     return launch<uint16_t>((const uint16_t*)flat, pitch, center, center_dtype, half, obs, out, P, E, d, (hipStream_t)stream);

@@ -59,7 +59,7 @@ def _hip_ok(flat, obs, sizes, activation, final_activation) -> bool:
     return (flat.is_cuda and obs.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1
             and obs.shape[1] in (1, 2, 4) and isinstance(activation, str) and isinstance(final_activation, str)
             and activation in _ACT_CODE and final_activation in _ACT_CODE and 1 <= len(sizes) - 1 <= 8
-            and 2 * obs.shape[1] * ((max(sizes) + 3) // 4 * 4) * 4 <= 64 * 1024)
+            and obs.shape[1] * (2 * ((max(sizes) + 3) // 4 * 4) + 256) * 4 <= 64 * 1024)
 
 
 def _forward_hip(flat, obs, sizes, activation, final_activation, bias):
@@ -112,7 +112,7 @@ def _mirror_of(flat, E, sizes):
     center, half = tag
     if (flat.shape[0] != 2 * half or E not in (1, 2) or center.dtype != torch.float32 or not center.is_contiguous()
             or center.device != flat.device or center.numel() != flat.shape[1]
-            or 4 * E * ((max(sizes) + 3) // 4 * 4) * 4 > 64 * 1024):
+            or 2 * E * (2 * ((max(sizes) + 3) // 4 * 4) + 256) * 4 > 64 * 1024):
         return None
     return center
 

@@ -135,6 +135,7 @@ class PlanarEngine:
         self.lengths = torch.tensor([ln.length for ln in model.links])
         self._dev: Dict = {}
         self._params: Dict = {}
+        self._resident: Dict = {}
 
     def on(self, device):
         if device not in self._dev:
@@ -154,7 +155,16 @@ class PlanarEngine:
     def points(self, q, W):
         """Positions (B, P, 2) of the points with weight rows ``W`` (P, L)."""
         _, u = self.directions(q)
-        return q[:, None, :2] + torch.einsum("pk,bkc->bpc", W.to(q.device), u)
+        return q[:, None, :2] + torch.einsum("pk,bkc->bpc", self.resident(W, q.device), u)
+
+    def resident(self, t: torch.Tensor, device):
+        """``t`` on ``device``, copied once (a copy from host memory per call would synchronise and cannot be recorded)."""
+        if t.device == device:
+            return t
+        key = (id(t), device)
+        if key not in self._resident:
+            self._resident[key] = (t, t.to(device))               # the host tensor is kept so that its id stays taken
+        return self._resident[key][1]
 
     def link_segments(self, q):
         """Start and end points of every link, (B, L, 2) each (for drawing)."""
@@ -278,14 +288,16 @@ class PlanarEnv(TensorEnv):
         self.act_dim = len(model.actuators)
 
     def _noise_mask(self, device):
-        mask = torch.zeros(self.engine.ndof, device=device)
-        mask[self.engine.on(device)["free"]] = 1.0
-        return mask
+        if not hasattr(self, "_mask"):
+            self._mask = torch.zeros(self.engine.ndof)
+            self._mask[self.engine.free] = 1.0
+        return self.engine.resident(self._mask, device)
 
     def reset(self, key, batch, device):
+        device = torch.device(device)
         k0, k1, k2 = rnd.split(key.to(device), 3)
         mask = self._noise_mask(device)
-        q = self.q0.to(device) + self.reset_noise * mask * (2.0 * rnd.uniform(k0, (batch, self.engine.ndof)) - 1.0)
+        q = self.engine.resident(self.q0, device) + self.reset_noise * mask * (2.0 * rnd.uniform(k0, (batch, self.engine.ndof)) - 1.0)
         qd = self.reset_noise * mask * (2.0 * rnd.uniform(k1, (batch, self.engine.ndof)) - 1.0)
         extra = self._reset_extra(k2, batch, device)
         st = {"q": q, "qd": qd, **extra}

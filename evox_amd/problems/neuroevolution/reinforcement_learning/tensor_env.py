@@ -142,43 +142,88 @@ class TensorEnvProblem(Problem):
         return total, state.replace(key=key)
 
     # ------------------------------------------------------------------------------------
-    def rollout(self, key, weights, respect_done: bool = False):
+    def rollout(self, key, weights, respect_done: bool = False, snapshots: bool = False):
         """One episode of ONE individual (``weights`` without the population axis): the observations
-        ``(T+1, obs_dim)``, rewards ``(T,)`` and done flags ``(T,)`` on the host."""
+        ``(T+1, obs_dim)``, rewards ``(T,)`` and done flags ``(T,)`` on the host.  ``snapshots=True`` adds a fourth
+        item: what the environment's ``snapshot(env_state)`` returned at every time step (the link segments of a planar
+        mechanism), or ``None`` when the environment has no such method."""
         from ....core.tree import tree_leaves, tree_map
         device = tree_leaves(weights)[0].device
         batched = tree_map(lambda w: w.unsqueeze(0), weights)
         env_state, obs = self.env.reset(key.to(device), 1, device)
+        snap = getattr(self.env, "snapshot", None) if snapshots else None
         frames, rewards, dones = [obs[0].detach().cpu()], [], []
+        shots = [snap(env_state)] if snap is not None else None
         for _ in range(self.max_episode_length):
             action = self.policy(batched, obs.reshape(1, 1, -1)).reshape(1, -1)
             env_state, obs, reward, done = self.env.step(env_state, action)
             frames.append(obs[0].detach().cpu())
             rewards.append(float(reward[0]))
             dones.append(bool(done[0]))
+            if shots is not None:
+                shots.append(snap(env_state))
             if respect_done and dones[-1]:
                 break
-        return torch.stack(frames), torch.tensor(rewards), torch.tensor(dones)
+        out = (torch.stack(frames), torch.tensor(rewards), torch.tensor(dones))
+        return out + (shots,) if snapshots else out
 
     def visualize(self, key, weights, output_type: str = "HTML", respect_done: bool = False, width: int = 320,
                   height: int = 240, **kwargs):
         """Roll one individual out and render the episode (reference: ``brax.py:99-133``, which renders the physics
-        scene through ``brax.io``; a tensor environment has no scene, so what is drawn is its observation vector).
+        scene through ``brax.io``).  A planar mechanism (an environment with ``snapshot``) is drawn as its links over the
+        ground line, the camera following it; any other tensor environment has no scene, so what is drawn is its
+        observation vector.
 
-        ``output_type="HTML"``: a self-contained page — an animated bar display of the observation with a slider, and the
-        cumulative reward curve.  ``"rgb_array"``: one ``(height, width, 3)`` uint8 array per time step.  An environment
-        may supply its own ``render(obs_row, width, height) -> uint8 array`` for the frames."""
+        ``output_type="HTML"``: a self-contained page — the animated scene (or bar display of the observation) with a
+        slider, and the cumulative reward curve.  ``"rgb_array"``: one ``(height, width, 3)`` uint8 array per time step.
+        An environment may supply its own ``render(obs_row, width, height) -> uint8 array`` for the frames."""
         assert output_type in ("HTML", "rgb_array"), "output_type must be either HTML or rgb_array"
-        obs, rewards, dones = self.rollout(key, weights, respect_done)
+        obs, rewards, dones, shots = self.rollout(key, weights, respect_done, snapshots=True)
         if output_type == "rgb_array":
+            if shots is not None:
+                return [_links_frame(seg, width, height) for seg in shots]
             draw = getattr(self.env, "render", None) or _bars_frame
             return [draw(row, width, height) for row in obs]
         import json
         lim = float(obs.abs().max().clamp_min(1e-6))
-        payload = json.dumps({"obs": [[round(float(v), 5) for v in row] for row in obs],
-                              "ret": [round(float(v), 5) for v in torch.cumsum(rewards, 0)],
-                              "done": [int(d) for d in dones], "lim": lim})
-        return _HTML_TEMPLATE.replace("__DATA__", payload).replace("__W__", str(width)).replace("__H__", str(height))
+        payload = {"obs": [[round(float(v), 5) for v in row] for row in obs],
+                   "ret": [round(float(v), 5) for v in torch.cumsum(rewards, 0)],
+                   "done": [int(d) for d in dones], "lim": lim}
+        if shots is not None:
+            payload["seg"] = [[[round(float(v), 4) for v in link.reshape(-1)] for link in seg] for seg in shots]
+        return _HTML_TEMPLATE.replace("__DATA__", json.dumps(payload)).replace("__W__", str(width)).replace("__H__", str(height))
+
+
+def _links_frame(segments, width: int, height: int, metres: float = 3.0):
+    """Link segments (L, 2, 2) = (link, start/end, x/z) as dark lines over a ground line; ``metres`` of scene height,
+    the camera centred on the mechanism horizontally."""
+    import numpy as np
+
+    img = np.full((height, width, 3), 255, dtype=np.uint8)
+    seg = np.asarray(segments, dtype=np.float64)
+    scale = height / metres
+    cx = float(seg[..., 0].mean())
+    ground = int(round(height * 0.85))
+
+    def px(x, z):
+        return (x - cx) * scale + width / 2.0, ground - z * scale
+
+    img[min(max(ground, 0), height - 1), :, :] = 120
+    # distance marks on the ground every half metre, so that motion shows although the camera follows
+    first = math.floor((cx - width / 2.0 / scale) * 2.0) / 2.0
+    for k in range(int(width / scale * 2) + 3):
+        u, _ = px(first + 0.5 * k, 0.0)
+        if 0 <= int(u) < width:
+            img[ground:min(ground + 4, height), int(u), :] = 120
+    for (x0, z0), (x1, z1) in seg:
+        (u0, v0), (u1, v1) = px(x0, z0), px(x1, z1)
+        n = int(max(abs(u1 - u0), abs(v1 - v0))) + 2
+        us = np.clip(np.round(np.linspace(u0, u1, n)).astype(int), 0, width - 1)
+        vs = np.clip(np.round(np.linspace(v0, v1, n)).astype(int), 0, height - 1)
+        for du in (-1, 0, 1):
+            for dv in (-1, 0, 1):
+                img[np.clip(vs + dv, 0, height - 1), np.clip(us + du, 0, width - 1)] = (30, 60, 140)
+    return img
 
 
 def _bars_frame(row, width: int, height: int):
@@ -210,13 +255,25 @@ const D = __DATA__;
 const c = document.getElementById('c').getContext('2d'), r = document.getElementById('r').getContext('2d');
 const W = __W__, H = __H__, T = D.obs.length, sl = document.getElementById('t');
 sl.max = T - 1;
+function scene(t) {
+  const S = D.seg[t], sc = H / 3.0, g = H * 0.85;
+  let cx = 0; S.forEach(l => { cx += (l[0] + l[2]) / 2; }); cx /= S.length;
+  c.strokeStyle = '#777'; c.lineWidth = 1; c.beginPath(); c.moveTo(0, g); c.lineTo(W, g); c.stroke();
+  const first = Math.floor((cx - W / 2 / sc) * 2) / 2;
+  for (let k = 0; k < W / sc * 2 + 3; k++) { const u = (first + 0.5 * k - cx) * sc + W / 2; c.beginPath(); c.moveTo(u, g); c.lineTo(u, g + 4); c.stroke(); }
+  c.strokeStyle = '#1e3c8c'; c.lineWidth = 3; c.lineCap = 'round';
+  S.forEach(l => { c.beginPath(); c.moveTo((l[0] - cx) * sc + W / 2, g - l[1] * sc); c.lineTo((l[2] - cx) * sc + W / 2, g - l[3] * sc); c.stroke(); });
+}
 function draw(t) {
-  c.clearRect(0, 0, W, H); c.strokeStyle = '#999'; c.beginPath(); c.moveTo(0, H / 2); c.lineTo(W, H / 2); c.stroke();
+  c.clearRect(0, 0, W, H);
+  if (D.seg) { scene(t); } else {
+  c.strokeStyle = '#999'; c.beginPath(); c.moveTo(0, H / 2); c.lineTo(W, H / 2); c.stroke();
   const o = D.obs[t], bw = W / o.length;
   for (let i = 0; i < o.length; i++) {
     const h = (H / 2 - 2) * Math.min(Math.abs(o[i]) / D.lim, 1);
     c.fillStyle = o[i] >= 0 ? '#266ec8' : '#c85032';
     c.fillRect(i * bw, o[i] >= 0 ? H / 2 - h : H / 2, Math.max(bw - 1, 1), h);
+  }
   }
   r.clearRect(0, 0, W, H);
   if (D.ret.length) {

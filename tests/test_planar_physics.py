@@ -203,3 +203,51 @@ def test_step_kernel_matches_the_tensor_formulation(name):
     # the environment's own step takes the kernel, finite and of the right shapes
     st, o, r, d = env.step(st, torch.zeros(256, env.act_dim, device=dev))
     assert o.shape == (256, env.obs_dim) and bool(torch.isfinite(o).all())
+
+
+def test_visualize_draws_the_mechanism():
+    """``visualize`` of a planar task renders the links (reference ``brax.py:99-133`` renders the physics scene): frames
+    with dark link pixels above the ground line, an HTML page that carries the segments of every time step."""
+    def policy(w, obs):
+        return torch.tanh(obs @ w)                       # (pop, episodes, obs) @ (pop, obs, act)
+
+    prob = Brax(policy, "hopper", 20, 1)
+    w = 0.1 * torch.randn(11, 3, generator=torch.Generator().manual_seed(0))
+    frames = prob.visualize(ex.PRNGKey(0), w, output_type="rgb_array", width=160, height=120)
+    assert len(frames) == 21 and frames[0].shape == (120, 160, 3) and frames[0].dtype.name == "uint8"
+    dark = (frames[0] == (30, 60, 140)).all(-1)
+    assert int(dark.sum()) > 100 and int(dark[: int(120 * 0.85)].sum()) > 0.9 * int(dark.sum())       # the body, above the ground
+    page = prob.visualize(ex.PRNGKey(0), w, output_type="HTML")
+    assert page.startswith("<!DOCTYPE html>") and '"seg"' in page and "scene(t)" in page
+    obs, rew, done, shots = prob.rollout(ex.PRNGKey(0), w, snapshots=True)
+    assert len(shots) == obs.shape[0] == 21 and tuple(shots[0].shape) == (4, 2, 2)
+    assert len(prob.rollout(ex.PRNGKey(0), w)) == 3
+
+
+@pytest.mark.gpu
+def test_policy_search_on_a_physics_task_records_into_a_graph():
+    """OpenES over MLP policies on the hopper, whole generation (sampling, 40 policy + physics steps, update) replayed
+    from a HIP graph: the same generations as eager issue, and the search improves the return."""
+    from evox_amd import algorithms, workflows
+    from evox_amd.models import MLP
+
+    dev = torch.device("cuda")
+    net = MLP([11, 16, 3])
+
+    def run(graph):
+        prob = Brax(net.batched_apply, "hopper", 40, 1)
+        algo = algorithms.OpenES(net.init(ex.PRNGKey(1), device=dev), 256, 0.05, 0.1)
+        wf = workflows.StdWorkflow(algo, prob, opt_direction="max", graph_step=graph)
+        state = wf.init(ex.PRNGKey(2).to(dev))
+        for _ in range(8):
+            state = wf.step(state)
+        return wf, state.get_child_state("algorithm").center.clone()
+
+    we, ce = run(False)
+    wg, cg = run(True)
+    assert wg.graph_step is True and wg._graphed is not None
+    assert torch.allclose(ce, cg, atol=1e-5)
+    prob = Brax(net.batched_apply, "hopper", 40, 1)
+    start, _ = prob.evaluate(prob.setup(ex.PRNGKey(3).to(dev)), net.init(ex.PRNGKey(1), device=dev)[None])
+    end, _ = prob.evaluate(prob.setup(ex.PRNGKey(3).to(dev)), ce[None])
+    assert bool(torch.isfinite(end).all()) and float(end[0]) >= float(start[0]) - 1.0
