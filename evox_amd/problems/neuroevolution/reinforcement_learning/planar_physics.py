@@ -492,7 +492,8 @@ class InvertedDoublePendulum(PlanarEnv):
     def _observe(self, st):
         q, qd = st["q"], st["qd"]
         th = q[:, 3:5]
-        return torch.cat([q[:, :1], torch.sin(th), torch.cos(th), qd[:, [0, 3, 4]].clamp(-10, 10)], dim=1)
+        # (slices, not an index list: that would be a host-to-device copy per call, which cannot be recorded)
+        return torch.cat([q[:, :1], torch.sin(th), torch.cos(th), qd[:, :1].clamp(-10, 10), qd[:, 3:5].clamp(-10, 10)], dim=1)
 
     def _outcome(self, before, after, a):
         tip = self.engine.points(after["q"], self._tip)[:, 0]
