@@ -25,14 +25,19 @@ constexpr float kContactRamp = 1.0e-3f;    // metres
 constexpr float kLimitRamp = 1.0e-2f;      // radians
 
 // offsets into the parameter block (floats; counts are stored as floats)
+// task block (locomotion recipe): [0] mode (0: physics only, 1: locomotion), [1] control range, [2] forward weight,
+// [3] control cost, [4] healthy bonus, [5] terminates, [6] z low, [7] z high, [8] angle low, [9] angle high,
+// [10] leading coordinates left out of the observation, [11] velocity clip, [12] seconds per environment step
+constexpr int kOffTask = 440, kTaskFloats = 16;
 constexpr int kOffHead = 0, kOffFree = 16, kOffAnc = 32, kOffWcom = 96, kOffWcon = 160, kOffMass = 224, kOffLen = 232,
               kOffRest = 240, kOffMconst = 256, kOffLo = 352, kOffHi = 368, kOffDamp = 384, kOffStiff = 400,
-              kOffActDof = 416, kOffActGear = 424, kParamFloats = 432;
+              kOffActDof = 416, kOffActGear = 424, kParamFloats = 456;
 
 template <int L>
 __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict__ P, float* __restrict__ q_io,
                                                          float* __restrict__ qd_io, const float* __restrict__ ctrl,
-                                                         int batch) {
+                                                         int batch, float* __restrict__ obs_out,
+                                                         float* __restrict__ total, uint8_t* __restrict__ done_acc) {
   constexpr int N = L + 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
@@ -41,16 +46,22 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict
               cc = P[kOffHead + 8], mu = P[kOffHead + 9], klim = P[kOffHead + 10], clim = P[kOffHead + 11],
               drag_t = P[kOffHead + 12], drag_n = P[kOffHead + 13], drag_a = P[kOffHead + 14];
   const bool has_drag = drag_t != 0.f || drag_n != 0.f || drag_a != 0.f;
-  float x[N], v[N], qact[N];
+  const bool task = obs_out != nullptr;                  // the locomotion recipe: observation, reward, termination
+  const float crange = task ? P[kOffTask + 1] : 3.0e38f;
+  float x[N], v[N], qact[N], x_before[N];
 #pragma unroll
   for (int d = 0; d < N; ++d) {
     x[d] = q_io[(long long)b * N + d];
     v[d] = qd_io[(long long)b * N + d];
+    x_before[d] = x[d];
     qact[d] = 0.f;
   }
+  float ctrl_sq = 0.f;
   for (int a = 0; a < nact; ++a) {
     const int dof = (int)P[kOffActDof + a];
-    const float f = P[kOffActGear + a] * ctrl[(long long)b * nact + a];
+    const float u = fminf(fmaxf(ctrl[(long long)b * nact + a], -crange), crange);
+    ctrl_sq = fmaf(u, u, ctrl_sq);
+    const float f = P[kOffActGear + a] * u;
 #pragma unroll
     for (int d = 0; d < N; ++d) qact[d] += d == dof ? f : 0.f;
   }
@@ -215,6 +226,37 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict
       x[d] = fmaf(dt, v[d], x[d]);
     }
   }
+  if (task) {
+    // a state that left the numbers ends the episode where it was, without reward
+    bool finite = true;
+#pragma unroll
+    for (int d = 0; d < N; ++d) finite = finite && fabsf(x[d]) < 3.0e38f && fabsf(v[d]) < 3.0e38f;   // false for NaN too
+    if (!finite) {
+#pragma unroll
+      for (int d = 0; d < N; ++d) {
+        x[d] = x_before[d];
+        v[d] = 0.f;
+      }
+    }
+    const float* T = P + kOffTask;
+    const bool terminates = T[5] != 0.f;
+    const bool healthy = x[1] > T[6] && x[1] < T[7] && x[2] > T[8] && x[2] < T[9];
+    const float vx = (x[0] - x_before[0]) / T[12];
+    float reward = T[2] * vx + ((healthy || !terminates) ? T[4] : 0.f) - T[3] * ctrl_sq;
+    if (!finite) reward = 0.f;
+    const bool done_now = (terminates && !healthy) || !finite;
+    const int skip = (int)T[10];
+    const float clip = T[11];
+    float* o = obs_out + (long long)b * (2 * N - skip);
+    int w = 0;
+#pragma unroll
+    for (int d = 0; d < N; ++d)
+      if (d >= skip) o[w++] = x[d];
+#pragma unroll
+    for (int d = 0; d < N; ++d) o[w++] = fminf(fmaxf(v[d], -clip), clip);
+    if (!done_acc[b]) total[b] += reward;
+    if (done_now) done_acc[b] = 1;
+  }
 #pragma unroll
   for (int d = 0; d < N; ++d) {
     q_io[(long long)b * N + d] = x[d];
@@ -223,8 +265,9 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict
 }
 
 template <int L>
-int launch_planar(const float* P, float* q, float* qd, const float* ctrl, int batch, hipStream_t st) {
-  planar_step_kernel<L><<<(batch + 63) / 64, 64, 0, st>>>(P, q, qd, ctrl, batch);
+int launch_planar(const float* P, float* q, float* qd, const float* ctrl, int batch, float* obs, float* total,
+                  uint8_t* done, hipStream_t st) {
+  planar_step_kernel<L><<<(batch + 63) / 64, 64, 0, st>>>(P, q, qd, ctrl, batch, obs, total, done);
   return last_launch_status();
 }
 
@@ -232,21 +275,37 @@ int launch_planar(const float* P, float* q, float* qd, const float* ctrl, int ba
 
 EVOX_API int evox_hip_planar_param_floats() { return kParamFloats; }
 
-// One environment step (the model's sub-steps) of `batch` environments in place.  params: the block laid out as the
-// offsets above (ops/planar.py builds it), on the device; q, qd: batch x (links + 2); ctrl: batch x actuators.
-EVOX_API int evox_hip_planar_step(const float* params, int links, int contacts, int actuators, float* q, float* qd,
-                                  const float* ctrl, int batch, void* stream) {
+static int planar_dispatch(const float* params, int links, int contacts, int actuators, float* q, float* qd,
+                           const float* ctrl, int batch, float* obs, float* total, uint8_t* done, void* stream) {
   if (links < 1 || links > kLM || contacts < 0 || contacts > kCM || actuators < 0 || actuators > kAM || batch <= 0 ||
       params == nullptr || q == nullptr || qd == nullptr || (actuators > 0 && ctrl == nullptr))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (links) {
-    case 1: return launch_planar<1>(params, q, qd, ctrl, batch, st);
-    case 2: return launch_planar<2>(params, q, qd, ctrl, batch, st);
-    case 3: return launch_planar<3>(params, q, qd, ctrl, batch, st);
-    case 4: return launch_planar<4>(params, q, qd, ctrl, batch, st);
-    case 5: return launch_planar<5>(params, q, qd, ctrl, batch, st);
-    case 6: return launch_planar<6>(params, q, qd, ctrl, batch, st);
-    default: return launch_planar<7>(params, q, qd, ctrl, batch, st);
+    case 1: return launch_planar<1>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 2: return launch_planar<2>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 3: return launch_planar<3>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 4: return launch_planar<4>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 5: return launch_planar<5>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 6: return launch_planar<6>(params, q, qd, ctrl, batch, obs, total, done, st);
+    default: return launch_planar<7>(params, q, qd, ctrl, batch, obs, total, done, st);
   }
+}
+
+// One environment step (the model's sub-steps) of `batch` environments in place.  params: the block laid out as the
+// offsets above (ops/planar.py builds it), on the device; q, qd: batch x (links + 2); ctrl: batch x actuators.
+EVOX_API int evox_hip_planar_step(const float* params, int links, int contacts, int actuators, float* q, float* qd,
+                                  const float* ctrl, int batch, void* stream) {
+  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, nullptr, nullptr, nullptr, stream);
+}
+
+// The same with the locomotion recipe of the task block applied in the kernel: controls clipped to the task's range, the
+// observation (coordinates without the leading ones, then clipped velocities) written to obs (batch x (2 (links + 2) -
+// skip)), the step's reward added to total[b] unless done[b] was set before the step, done[b] set when the episode ends
+// (unhealthy, or the state left the numbers: then it is put back and frozen).
+EVOX_API int evox_hip_planar_step_task(const float* params, int links, int contacts, int actuators, float* q, float* qd,
+                                       const float* ctrl, int batch, float* obs, float* total, uint8_t* done,
+                                       void* stream) {
+  if (obs == nullptr || total == nullptr || done == nullptr || links < 1) return (int)hipErrorInvalidValue;
+  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, obs, total, done, stream);
 }

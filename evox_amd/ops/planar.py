@@ -13,11 +13,12 @@ P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_planar_param_floats": (I, []),
     "evox_hip_planar_step": (I, [P, I, I, I, P, P, P, I, P]),
+    "evox_hip_planar_step_task": (I, [P, I, I, I, P, P, P, I, P, P, P, P]),
 })
 
 MAX_LINKS, MAX_CONTACTS, MAX_ACTUATORS = 7, 8, 8
 _OFF = dict(head=0, free=16, anc=32, wcom=96, wcon=160, mass=224, length=232, rest=240, mconst=256, lo=352, hi=368,
-            damping=384, stiffness=400, act_dof=416, act_gear=424)
+            damping=384, stiffness=400, act_dof=416, act_gear=424, task=440)
 
 
 def fits(engine) -> bool:
@@ -31,10 +32,20 @@ def applies(engine, q: torch.Tensor) -> bool:
             and os.environ.get("EVOX_AMD_PLANAR", "kernel") == "kernel")
 
 
-def param_block(engine) -> torch.Tensor:
-    """The engine's constants as the float block the kernel reads (host tensor)."""
+def param_block(engine, task: dict = None) -> torch.Tensor:
+    """The engine's constants as the float block the kernel reads (host tensor).  ``task``: the locomotion recipe
+    (``ctrl_range, forward_weight, ctrl_cost, healthy_reward, terminate, z_range, angle_range, obs_skip, vel_clip,
+    frame_dt``) for ``step_task``."""
     m, L, N = engine.model, engine.L, engine.ndof
-    blk = torch.zeros(int(hip().evox_hip_planar_param_floats()) if torch.cuda.is_available() else 432, dtype=torch.float32)
+    blk = torch.zeros(int(hip().evox_hip_planar_param_floats()) if torch.cuda.is_available() else 456, dtype=torch.float32)
+    if task is not None:
+        big = 3.0e38
+        zr = task["z_range"] or (-big, big)
+        ar = task["angle_range"] or (-big, big)
+        vals = [1.0, task["ctrl_range"], task["forward_weight"], task["ctrl_cost"], task["healthy_reward"],
+                1.0 if task["terminate"] else 0.0, max(zr[0], -big), min(zr[1], big), max(ar[0], -big), min(ar[1], big),
+                float(task["obs_skip"]), task["vel_clip"], task["frame_dt"]]
+        blk[_OFF["task"]:_OFF["task"] + len(vals)] = torch.tensor(vals, dtype=torch.float32)
     head = [L, len(m.contacts), len(m.actuators), m.substeps, m.dt, m.max_velocity, m.gravity, m.contact_stiffness,
             m.contact_damping, m.friction, m.limit_stiffness, m.limit_damping, m.drag[0], m.drag[1], m.drag[2]]
     blk[:len(head)] = torch.tensor(head, dtype=torch.float32)
@@ -77,3 +88,23 @@ def step(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, ctrl):
     check(hip().evox_hip_planar_step(params.data_ptr(), engine.L, len(m.contacts), nact, q.data_ptr(), qd.data_ptr(),
                                      ctrl.data_ptr() if nact else None, q.shape[0], stream_of(q)), "planar_step")
     return q, qd
+
+
+def step_task(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, ctrl: torch.Tensor, obs_dim: int,
+              total: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
+    """One environment step with the locomotion recipe applied in the kernel.  IN PLACE: ``q`` and ``qd`` advance,
+    ``total`` gains the step's reward where ``done`` was not set, ``done`` (bool) is set where the episode ends.  Returns
+    the observations (batch, obs_dim)."""
+    m = engine.model
+    nact = len(m.actuators)
+    B = q.shape[0]
+    assert q.is_contiguous() and qd.is_contiguous() and q.shape == qd.shape == (B, engine.ndof)
+    assert total.shape == (B,) and total.dtype == torch.float32 and total.is_contiguous()
+    assert done.shape == (B,) and done.dtype == torch.bool and done.is_contiguous()
+    ctrl = ctrl.to(torch.float32).contiguous()
+    assert ctrl.shape == (B, nact) and nact > 0
+    obs = torch.empty((B, obs_dim), dtype=torch.float32, device=q.device)
+    check(hip().evox_hip_planar_step_task(params.data_ptr(), engine.L, len(m.contacts), nact, q.data_ptr(), qd.data_ptr(),
+                                          ctrl.data_ptr(), B, obs.data_ptr(), total.data_ptr(), done.data_ptr(),
+                                          stream_of(q)), "planar_step_task")
+    return obs

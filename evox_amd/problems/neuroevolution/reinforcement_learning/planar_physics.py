@@ -135,6 +135,7 @@ class PlanarEngine:
         self.lengths = torch.tensor([ln.length for ln in model.links])
         self._dev: Dict = {}
         self._params: Dict = {}
+        self._params_task: Dict = {}
         self._resident: Dict = {}
 
     def on(self, device):
@@ -340,6 +341,30 @@ class _Locomotion(PlanarEnv):
     def _observe(self, st):
         return torch.cat([st["q"][:, 1:], st["qd"].clamp(-self.vel_clip, self.vel_clip)], dim=1)
 
+    obs_skip = 1                     # leading coordinates left out of the observation (x; the swimmer also drops z)
+
+    def step_accumulate(self, env_state, action, total, done):
+        """One step of a rollout, with the bookkeeping of ``TensorEnvProblem.evaluate`` included: returns
+        ``(env_state, obs, total, done)`` with the step's reward added to ``total`` where ``done`` was not yet set.  On a
+        GPU this is ONE launch (physics, observation, reward, termination, accumulation: ``csrc/planar.hip``), and it
+        works IN PLACE on the state and the accumulators it is given (a rollout owns them)."""
+        from ....ops import planar as _k
+
+        q = env_state["q"]
+        if _k.applies(self.engine, q) and q.is_contiguous() and env_state["qd"].is_contiguous() and done.dtype == torch.bool:
+            eng = self.engine
+            if q.device not in eng._params_task:
+                task = dict(ctrl_range=self.ctrl_range, forward_weight=self.forward_weight, ctrl_cost=self.ctrl_cost,
+                            healthy_reward=self.healthy_reward, terminate=self.terminate, z_range=self.z_range,
+                            angle_range=self.angle_range, obs_skip=self.obs_skip, vel_clip=self.vel_clip,
+                            frame_dt=self.frame_dt)
+                eng._params_task[q.device] = _k.param_block(eng, task).to(q.device)
+            obs = _k.step_task(eng, eng._params_task[q.device], q, env_state["qd"], action, self.obs_dim, total, done)
+            return env_state, obs, total, done
+        env_state, obs, reward, step_done = self.step(env_state, action)
+        total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
+        return env_state, obs, total, done | step_done
+
     def _healthy(self, st):
         ok = torch.ones(st["q"].shape[0], dtype=torch.bool, device=st["q"].device)
         if self.z_range is not None:
@@ -437,7 +462,7 @@ class HalfCheetah(_Locomotion):
 class Swimmer(_Locomotion):
     """Three-link swimmer in a viscous fluid, no gravity (observation 8 = the three angles and five velocities, action 2):
     forward velocity minus 1e-4 of the squared controls."""
-    obs_dim, ctrl_cost, terminate, healthy_reward = 8, 1e-4, False, 0.0
+    obs_dim, ctrl_cost, terminate, healthy_reward, obs_skip = 8, 1e-4, False, 0.0, 2
     reset_noise = 0.1
 
     def __init__(self):

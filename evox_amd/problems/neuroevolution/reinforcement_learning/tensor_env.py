@@ -129,11 +129,16 @@ class TensorEnvProblem(Problem):
         env_state, obs = self.env.reset(eval_key, pop * E, device)
         done = torch.zeros(pop * E, dtype=torch.bool, device=device)
         total = torch.zeros(pop * E, dtype=torch.float32, device=device)
+        # an environment may take the bookkeeping of the loop into its own step (one launch instead of a dozen)
+        accumulate = getattr(self.env, "step_accumulate", None)
         for t in range(self.max_episode_length):
             action = self.policy(weights, obs.reshape(pop, E, -1)).reshape(pop * E, -1)
-            env_state, obs, reward, step_done = self.env.step(env_state, action)
-            total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
-            done = done | step_done
+            if accumulate is not None:
+                env_state, obs, total, done = accumulate(env_state, action, total, done)
+            else:
+                env_state, obs, reward, step_done = self.env.step(env_state, action)
+                total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
+                done = done | step_done
             if self.early_exit_every and (t + 1) % self.early_exit_every == 0 and bool(done.all()):
                 break
         total = self.reduce_fn(total.reshape(pop, E), dim=-1)

@@ -251,3 +251,37 @@ def test_policy_search_on_a_physics_task_records_into_a_graph():
     start, _ = prob.evaluate(prob.setup(ex.PRNGKey(3).to(dev)), net.init(ex.PRNGKey(1), device=dev)[None])
     end, _ = prob.evaluate(prob.setup(ex.PRNGKey(3).to(dev)), ce[None])
     assert bool(torch.isfinite(end).all()) and float(end[0]) >= float(start[0]) - 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hopper", "walker2d", "halfcheetah", "swimmer"])
+def test_fused_rollout_step_matches_step_plus_bookkeeping(name):
+    """``step_accumulate`` on the GPU (physics, observation, reward, termination and the rollout's accumulation in one
+    launch, in place) against ``step`` followed by the loop's own bookkeeping, from the same states, along a rollout
+    with controls beyond the task's range: observations, accumulated returns and done flags agree."""
+    dev = torch.device("cuda")
+    env = make_tensor_env(name)
+    st, _ = env.reset(ex.PRNGKey(21).to(dev), 512, dev)
+    total = torch.zeros(512, device=dev)
+    done = torch.zeros(512, dtype=torch.bool, device=dev)
+    gen = torch.Generator().manual_seed(22)
+    ended = 0
+    for t in range(80):
+        a = (torch.rand(512, env.act_dim, generator=gen) * 3 - 1.5).to(dev)
+        before = {k: v.clone() for k, v in st.items()}
+        total_before, done_before = total.clone(), done.clone()
+        st2, obs2, reward, step_done = env.step(before, a)
+        want_total = total_before + torch.where(done_before, torch.zeros_like(reward), reward)
+        want_done = done_before | step_done
+        st, obs, total, done = env.step_accumulate(st, a, total, done)
+        assert obs.shape == (512, env.obs_dim)
+        assert torch.allclose(obs, obs2, rtol=1e-4, atol=1e-4), (name, t, float((obs - obs2).abs().max()))
+        assert torch.allclose(total, want_total, rtol=1e-4, atol=1e-3), (name, t)
+        # a termination threshold crossed within rounding may flip one flag; never more than a handful
+        assert int((done != want_done).sum()) <= 2, (name, t)
+        done = want_done.clone()
+        total = want_total.clone()
+        st = {k: v.clone() for k, v in st2.items()}
+        ended = int(done.sum())
+    if name in ("hopper", "walker2d"):
+        assert ended > 0                                     # random controls make some of them fall: the rule was exercised
