@@ -86,8 +86,24 @@ def _secondary(dev):
                           f"episode_length={horizon}, fp32 parameters", "evals_per_sec": pop * steps / dt,
                 "env_steps_per_sec": pop * horizon * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 2}
 
+    def openes_hopper():
+        from evox_amd.models import MLP
+        from evox_amd.problems.neuroevolution import Brax
+
+        pop, horizon, steps = 4096, 100, 20
+        net = MLP([11, 32, 32, 3])
+        prob = Brax(net.batched_apply, "hopper", horizon, 1)          # in-tree planar physics, one lane per environment
+        algo = algorithms.OpenES(net.init(ex.PRNGKey(0)).to(dev), pop_size=pop, learning_rate=0.03, noise_stdev=0.1,
+                                 optimizer="adam", mirrored_sampling=True)
+        wf = workflows.StdWorkflow(algo, prob, opt_direction="max")
+        state, dt = timed(wf, wf.init(ex.PRNGKey(3).to(dev)), steps, 5)
+        return {"config": f"OpenES MLP {net.sizes} pop={pop}, planar hopper (articulated-body physics, penalty contact), "
+                          f"episode_length={horizon}", "evals_per_sec": pop * steps / dt,
+                "env_steps_per_sec": pop * horizon * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": 5}
+
     out = {}
-    for name, fn in (("nsga2_dtlz2_pop100k", nsga2), ("shade_cec2022_f1_pop50k", shade), ("openes_mlp_1m_pop4096", openes)):
+    for name, fn in (("nsga2_dtlz2_pop100k", nsga2), ("shade_cec2022_f1_pop50k", shade), ("openes_mlp_1m_pop4096", openes),
+                     ("openes_hopper_pop4096", openes_hopper)):
         try:
             out[name] = fn()
         except Exception as e:               # the headline above stands on its own
@@ -140,7 +156,7 @@ def _main():
                     help="collective backend (default: nccl = RCCL on GPUs, gloo on CPU); gloo with --device cuda "
                          "rehearses the multi-rank path on a single GPU")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary configurations (NSGA-II 10^5, SHADE 50k, OpenES 4096) measured after the "
+                    help="skip the secondary configurations (NSGA-II 10^5, SHADE 50k, OpenES 4096, OpenES on the hopper) measured after the "
                          "headline on a single GPU")
     args = ap.parse_args()
 

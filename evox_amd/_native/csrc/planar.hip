@@ -25,19 +25,23 @@ constexpr float kContactRamp = 1.0e-3f;    // metres
 constexpr float kLimitRamp = 1.0e-2f;      // radians
 
 // offsets into the parameter block (floats; counts are stored as floats)
-// task block (locomotion recipe): [0] mode (0: physics only, 1: locomotion), [1] control range, [2] forward weight,
-// [3] control cost, [4] healthy bonus, [5] terminates, [6] z low, [7] z high, [8] angle low, [9] angle high,
-// [10] leading coordinates left out of the observation, [11] velocity clip, [12] seconds per environment step
-constexpr int kOffTask = 440, kTaskFloats = 16;
+// task block: [0] recipe, [1] control range, then per recipe
+//   1 locomotion: [2] forward weight, [3] control cost, [4] healthy bonus, [5] terminates, [6] z low, [7] z high,
+//                 [8] angle low, [9] angle high, [10] leading coordinates left out of the observation, [11] velocity
+//                 clip, [12] seconds per environment step
+//   2 cart with one pole: [2] largest pole angle
+//   3 cart with two poles, 4 two-link reacher (target in aux): [16 .. 22] weight row of the tip
+constexpr int kOffTask = 440, kTaskFloats = 24, kOffTip = kOffTask + 16;
 constexpr int kOffHead = 0, kOffFree = 16, kOffAnc = 32, kOffWcom = 96, kOffWcon = 160, kOffMass = 224, kOffLen = 232,
               kOffRest = 240, kOffMconst = 256, kOffLo = 352, kOffHi = 368, kOffDamp = 384, kOffStiff = 400,
-              kOffActDof = 416, kOffActGear = 424, kParamFloats = 456;
+              kOffActDof = 416, kOffActGear = 424, kParamFloats = 464;
 
 template <int L>
 __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict__ P, float* __restrict__ q_io,
                                                          float* __restrict__ qd_io, const float* __restrict__ ctrl,
                                                          int batch, float* __restrict__ obs_out,
-                                                         float* __restrict__ total, uint8_t* __restrict__ done_acc) {
+                                                         float* __restrict__ total, uint8_t* __restrict__ done_acc,
+                                                         const float* __restrict__ aux) {
   constexpr int N = L + 2;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
@@ -239,21 +243,68 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict
       }
     }
     const float* T = P + kOffTask;
-    const bool terminates = T[5] != 0.f;
-    const bool healthy = x[1] > T[6] && x[1] < T[7] && x[2] > T[8] && x[2] < T[9];
-    const float vx = (x[0] - x_before[0]) / T[12];
-    float reward = T[2] * vx + ((healthy || !terminates) ? T[4] : 0.f) - T[3] * ctrl_sq;
+    const int recipe = (int)T[0];
+    float reward;
+    bool done_now;
+    if (recipe == 1) {
+      const bool terminates = T[5] != 0.f;
+      const bool healthy = x[1] > T[6] && x[1] < T[7] && x[2] > T[8] && x[2] < T[9];
+      const float vx = (x[0] - x_before[0]) / T[12];
+      reward = T[2] * vx + ((healthy || !terminates) ? T[4] : 0.f) - T[3] * ctrl_sq;
+      done_now = terminates && !healthy;
+      const int skip = (int)T[10];
+      const float clip = T[11];
+      float* o = obs_out + (long long)b * (2 * N - skip);
+      int w = 0;
+#pragma unroll
+      for (int d = 0; d < N; ++d)
+        if (d >= skip) o[w++] = x[d];
+#pragma unroll
+      for (int d = 0; d < N; ++d) o[w++] = fminf(fmaxf(v[d], -clip), clip);
+    } else if (recipe == 2) {
+      // cart with one pole (L = 2): observation (x, theta, xdot, thetadot), one point per step while the pole stands
+      const bool up = fabsf(x[N - 1]) <= T[2];
+      reward = up ? 1.f : 0.f;
+      done_now = !up;
+      float* o = obs_out + (long long)b * 4;
+      o[0] = x[0]; o[1] = x[N - 1]; o[2] = v[0]; o[3] = v[N - 1];
+    } else {
+      // the tip of the chain after the step
+      float tx = x[0], tz = x[1];
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        float al = P[kOffRest + i];
+#pragma unroll
+        for (int k = 0; k < L; ++k) al = fmaf(P[kOffAnc + i * kLM + k], x[2 + k], al);
+        float sn, cs;
+        sincosf(al, &sn, &cs);
+        tx = fmaf(P[kOffTip + i], cs, tx);
+        tz = fmaf(P[kOffTip + i], sn, tz);
+      }
+      if (recipe == 3) {
+        // cart with two poles (L = 3): (x, sin, sin, cos, cos, clipped velocities); 10 minus distance and velocity penalties
+        const float t1 = x[N > 3 ? 3 : 0], t2 = x[N - 1];
+        const float dist = 0.01f * tx * tx + (tz - 1.2f) * (tz - 1.2f);
+        const float v1 = v[N > 3 ? 3 : 0];
+        const float vel = 1e-3f * v1 * v1 + 5e-3f * v[N - 1] * v[N - 1];
+        reward = 10.f - dist - vel;
+        done_now = tz <= 1.f;
+        float* o = obs_out + (long long)b * 8;
+        o[0] = x[0]; o[1] = sinf(t1); o[2] = sinf(t2); o[3] = cosf(t1); o[4] = cosf(t2);
+        o[5] = fminf(fmaxf(v[0], -10.f), 10.f); o[6] = fminf(fmaxf(v1, -10.f), 10.f); o[7] = fminf(fmaxf(v[N - 1], -10.f), 10.f);
+      } else {
+        // two-link reacher (L = 2): (cos, cos, sin, sin, target, velocities, tip - target, 0); minus distance minus controls squared
+        const float gx = aux[(long long)b * 2], gz = aux[(long long)b * 2 + 1];
+        const float dx = tx - gx, dz = tz - gz;
+        reward = -sqrtf(dx * dx + dz * dz) - ctrl_sq;
+        done_now = false;
+        float* o = obs_out + (long long)b * 11;
+        o[0] = cosf(x[2]); o[1] = cosf(x[N - 1]); o[2] = sinf(x[2]); o[3] = sinf(x[N - 1]);
+        o[4] = gx; o[5] = gz; o[6] = v[2]; o[7] = v[N - 1]; o[8] = dx; o[9] = dz; o[10] = 0.f;
+      }
+    }
     if (!finite) reward = 0.f;
-    const bool done_now = (terminates && !healthy) || !finite;
-    const int skip = (int)T[10];
-    const float clip = T[11];
-    float* o = obs_out + (long long)b * (2 * N - skip);
-    int w = 0;
-#pragma unroll
-    for (int d = 0; d < N; ++d)
-      if (d >= skip) o[w++] = x[d];
-#pragma unroll
-    for (int d = 0; d < N; ++d) o[w++] = fminf(fmaxf(v[d], -clip), clip);
+    done_now = done_now || !finite;
     if (!done_acc[b]) total[b] += reward;
     if (done_now) done_acc[b] = 1;
   }
@@ -266,8 +317,8 @@ __global__ __launch_bounds__(64) void planar_step_kernel(const float* __restrict
 
 template <int L>
 int launch_planar(const float* P, float* q, float* qd, const float* ctrl, int batch, float* obs, float* total,
-                  uint8_t* done, hipStream_t st) {
-  planar_step_kernel<L><<<(batch + 63) / 64, 64, 0, st>>>(P, q, qd, ctrl, batch, obs, total, done);
+                  uint8_t* done, const float* aux, hipStream_t st) {
+  planar_step_kernel<L><<<(batch + 63) / 64, 64, 0, st>>>(P, q, qd, ctrl, batch, obs, total, done, aux);
   return last_launch_status();
 }
 
@@ -276,19 +327,20 @@ int launch_planar(const float* P, float* q, float* qd, const float* ctrl, int ba
 EVOX_API int evox_hip_planar_param_floats() { return kParamFloats; }
 
 static int planar_dispatch(const float* params, int links, int contacts, int actuators, float* q, float* qd,
-                           const float* ctrl, int batch, float* obs, float* total, uint8_t* done, void* stream) {
+                           const float* ctrl, int batch, float* obs, float* total, uint8_t* done, const float* aux,
+                           void* stream) {
   if (links < 1 || links > kLM || contacts < 0 || contacts > kCM || actuators < 0 || actuators > kAM || batch <= 0 ||
       params == nullptr || q == nullptr || qd == nullptr || (actuators > 0 && ctrl == nullptr))
     return (int)hipErrorInvalidValue;
   hipStream_t st = (hipStream_t)stream;
   switch (links) {
-    case 1: return launch_planar<1>(params, q, qd, ctrl, batch, obs, total, done, st);
-    case 2: return launch_planar<2>(params, q, qd, ctrl, batch, obs, total, done, st);
-    case 3: return launch_planar<3>(params, q, qd, ctrl, batch, obs, total, done, st);
-    case 4: return launch_planar<4>(params, q, qd, ctrl, batch, obs, total, done, st);
-    case 5: return launch_planar<5>(params, q, qd, ctrl, batch, obs, total, done, st);
-    case 6: return launch_planar<6>(params, q, qd, ctrl, batch, obs, total, done, st);
-    default: return launch_planar<7>(params, q, qd, ctrl, batch, obs, total, done, st);
+    case 1: return launch_planar<1>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    case 2: return launch_planar<2>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    case 3: return launch_planar<3>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    case 4: return launch_planar<4>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    case 5: return launch_planar<5>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    case 6: return launch_planar<6>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
+    default: return launch_planar<7>(params, q, qd, ctrl, batch, obs, total, done, aux, st);
   }
 }
 
@@ -296,16 +348,19 @@ static int planar_dispatch(const float* params, int links, int contacts, int act
 // offsets above (ops/planar.py builds it), on the device; q, qd: batch x (links + 2); ctrl: batch x actuators.
 EVOX_API int evox_hip_planar_step(const float* params, int links, int contacts, int actuators, float* q, float* qd,
                                   const float* ctrl, int batch, void* stream) {
-  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, nullptr, nullptr, nullptr, stream);
+  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-// The same with the locomotion recipe of the task block applied in the kernel: controls clipped to the task's range, the
-// observation (coordinates without the leading ones, then clipped velocities) written to obs (batch x (2 (links + 2) -
-// skip)), the step's reward added to total[b] unless done[b] was set before the step, done[b] set when the episode ends
-// (unhealthy, or the state left the numbers: then it is put back and frozen).
+// The same with the recipe of the task block applied in the kernel: controls clipped to the task's range, the observation
+// written to obs (batch x the task's observation size), the step's reward added to total[b] unless done[b] was set before
+// the step, done[b] set when the episode ends (the task's rule, or the state left the numbers: then it is put back and
+// frozen).  aux: per-environment data of the recipe (the reacher's targets, batch x 2) or null.  recipe / links must
+// agree (2: two links, 3: three links, 4: two links and aux).
 EVOX_API int evox_hip_planar_step_task(const float* params, int links, int contacts, int actuators, float* q, float* qd,
                                        const float* ctrl, int batch, float* obs, float* total, uint8_t* done,
-                                       void* stream) {
-  if (obs == nullptr || total == nullptr || done == nullptr || links < 1) return (int)hipErrorInvalidValue;
-  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, obs, total, done, stream);
+                                       const float* aux, int recipe, void* stream) {
+  if (obs == nullptr || total == nullptr || done == nullptr || recipe < 1 || recipe > 4) return (int)hipErrorInvalidValue;
+  if ((recipe == 2 && links != 2) || (recipe == 3 && links != 3) || (recipe == 4 && (links != 2 || aux == nullptr)))
+    return (int)hipErrorInvalidValue;
+  return planar_dispatch(params, links, contacts, actuators, q, qd, ctrl, batch, obs, total, done, aux, stream);
 }

@@ -13,7 +13,7 @@ P, I = _native.P, _native.I
 _native.register_hip_api({
     "evox_hip_planar_param_floats": (I, []),
     "evox_hip_planar_step": (I, [P, I, I, I, P, P, P, I, P]),
-    "evox_hip_planar_step_task": (I, [P, I, I, I, P, P, P, I, P, P, P, P]),
+    "evox_hip_planar_step_task": (I, [P, I, I, I, P, P, P, I, P, P, P, P, I, P]),
 })
 
 MAX_LINKS, MAX_CONTACTS, MAX_ACTUATORS = 7, 8, 8
@@ -33,19 +33,26 @@ def applies(engine, q: torch.Tensor) -> bool:
 
 
 def param_block(engine, task: dict = None) -> torch.Tensor:
-    """The engine's constants as the float block the kernel reads (host tensor).  ``task``: the locomotion recipe
-    (``ctrl_range, forward_weight, ctrl_cost, healthy_reward, terminate, z_range, angle_range, obs_skip, vel_clip,
-    frame_dt``) for ``step_task``."""
+    """The engine's constants as the float block the kernel reads (host tensor).  ``task``: the recipe that
+    ``step_task`` applies in the kernel — ``recipe`` 1 (locomotion: ``forward_weight, ctrl_cost, healthy_reward,
+    terminate, z_range, angle_range, obs_skip, vel_clip, frame_dt``), 2 (cart with one pole: ``max_angle``), 3 (cart with
+    two poles: ``tip``, the weight row of the tip) or 4 (two-link reacher: ``tip``), each with ``ctrl_range``."""
     m, L, N = engine.model, engine.L, engine.ndof
-    blk = torch.zeros(int(hip().evox_hip_planar_param_floats()) if torch.cuda.is_available() else 456, dtype=torch.float32)
+    blk = torch.zeros(int(hip().evox_hip_planar_param_floats()) if torch.cuda.is_available() else 464, dtype=torch.float32)
     if task is not None:
         big = 3.0e38
-        zr = task["z_range"] or (-big, big)
-        ar = task["angle_range"] or (-big, big)
-        vals = [1.0, task["ctrl_range"], task["forward_weight"], task["ctrl_cost"], task["healthy_reward"],
-                1.0 if task["terminate"] else 0.0, max(zr[0], -big), min(zr[1], big), max(ar[0], -big), min(ar[1], big),
-                float(task["obs_skip"]), task["vel_clip"], task["frame_dt"]]
+        vals = [float(task["recipe"]), task["ctrl_range"]]
+        if task["recipe"] == 1:
+            zr = task["z_range"] or (-big, big)
+            ar = task["angle_range"] or (-big, big)
+            vals += [task["forward_weight"], task["ctrl_cost"], task["healthy_reward"], 1.0 if task["terminate"] else 0.0,
+                     max(zr[0], -big), min(zr[1], big), max(ar[0], -big), min(ar[1], big), float(task["obs_skip"]),
+                     task["vel_clip"], task["frame_dt"]]
+        elif task["recipe"] == 2:
+            vals += [task["max_angle"]]
         blk[_OFF["task"]:_OFF["task"] + len(vals)] = torch.tensor(vals, dtype=torch.float32)
+        if task["recipe"] in (3, 4):
+            blk[_OFF["task"] + 16:_OFF["task"] + 16 + L] = task["tip"].reshape(-1)[:L]
     head = [L, len(m.contacts), len(m.actuators), m.substeps, m.dt, m.max_velocity, m.gravity, m.contact_stiffness,
             m.contact_damping, m.friction, m.limit_stiffness, m.limit_damping, m.drag[0], m.drag[1], m.drag[2]]
     blk[:len(head)] = torch.tensor(head, dtype=torch.float32)
@@ -90,11 +97,11 @@ def step(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, ctrl):
     return q, qd
 
 
-def step_task(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, ctrl: torch.Tensor, obs_dim: int,
-              total: torch.Tensor, done: torch.Tensor) -> torch.Tensor:
-    """One environment step with the locomotion recipe applied in the kernel.  IN PLACE: ``q`` and ``qd`` advance,
+def step_task(engine, params: torch.Tensor, recipe: int, q: torch.Tensor, qd: torch.Tensor, ctrl: torch.Tensor, obs_dim: int,
+              total: torch.Tensor, done: torch.Tensor, aux: torch.Tensor = None) -> torch.Tensor:
+    """One environment step with the task's recipe applied in the kernel.  IN PLACE: ``q`` and ``qd`` advance,
     ``total`` gains the step's reward where ``done`` was not set, ``done`` (bool) is set where the episode ends.  Returns
-    the observations (batch, obs_dim)."""
+    the observations (batch, obs_dim).  ``aux``: per-environment data of the recipe (the reacher's targets)."""
     m = engine.model
     nact = len(m.actuators)
     B = q.shape[0]
@@ -103,8 +110,12 @@ def step_task(engine, params: torch.Tensor, q: torch.Tensor, qd: torch.Tensor, c
     assert done.shape == (B,) and done.dtype == torch.bool and done.is_contiguous()
     ctrl = ctrl.to(torch.float32).contiguous()
     assert ctrl.shape == (B, nact) and nact > 0
+    if aux is not None:
+        aux = aux.to(torch.float32).contiguous()
+        assert aux.shape == (B, 2)
     obs = torch.empty((B, obs_dim), dtype=torch.float32, device=q.device)
     check(hip().evox_hip_planar_step_task(params.data_ptr(), engine.L, len(m.contacts), nact, q.data_ptr(), qd.data_ptr(),
                                           ctrl.data_ptr(), B, obs.data_ptr(), total.data_ptr(), done.data_ptr(),
-                                          stream_of(q)), "planar_step_task")
+                                          aux.data_ptr() if aux is not None else None, int(recipe), stream_of(q)),
+          "planar_step_task")
     return obs

@@ -320,6 +320,35 @@ class PlanarEnv(TensorEnv):
         reward = torch.where(bad, torch.zeros_like(reward), reward)
         return st, self._observe(st), reward, done | bad
 
+    def _recipe(self):
+        """What ``csrc/planar.hip`` needs to apply this task's observation, reward and termination in the step kernel
+        (see ``ops.planar.param_block``), or None when the task has no recipe there."""
+        return None
+
+    _aux_key = None                  # name of the per-environment data the recipe reads (the reacher's targets)
+
+    def step_accumulate(self, env_state, action, total, done):
+        """One step of a rollout, with the bookkeeping of ``TensorEnvProblem.evaluate`` included: returns
+        ``(env_state, obs, total, done)`` with the step's reward added to ``total`` where ``done`` was not yet set.  On a
+        GPU this is ONE launch for a task with a recipe (physics, observation, reward, termination, accumulation:
+        ``csrc/planar.hip``), and it works IN PLACE on the state and the accumulators it is given (a rollout owns them)."""
+        from ....ops import planar as _k
+
+        q = env_state["q"]
+        recipe = self._recipe()
+        if (recipe is not None and _k.applies(self.engine, q) and q.is_contiguous() and env_state["qd"].is_contiguous()
+                and done.dtype == torch.bool):
+            eng = self.engine
+            if q.device not in eng._params_task:
+                eng._params_task[q.device] = _k.param_block(eng, recipe).to(q.device)
+            aux = env_state[self._aux_key] if self._aux_key else None
+            obs = _k.step_task(eng, eng._params_task[q.device], recipe["recipe"], q, env_state["qd"], action, self.obs_dim,
+                               total, done, aux)
+            return env_state, obs, total, done
+        env_state, obs, reward, step_done = self.step(env_state, action)
+        total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
+        return env_state, obs, total, done | step_done
+
     # snapshots for drawing: the link segments of one environment
     def snapshot(self, env_state, index: int = 0):
         s, e = self.engine.link_segments(env_state["q"][index:index + 1])
@@ -343,27 +372,10 @@ class _Locomotion(PlanarEnv):
 
     obs_skip = 1                     # leading coordinates left out of the observation (x; the swimmer also drops z)
 
-    def step_accumulate(self, env_state, action, total, done):
-        """One step of a rollout, with the bookkeeping of ``TensorEnvProblem.evaluate`` included: returns
-        ``(env_state, obs, total, done)`` with the step's reward added to ``total`` where ``done`` was not yet set.  On a
-        GPU this is ONE launch (physics, observation, reward, termination, accumulation: ``csrc/planar.hip``), and it
-        works IN PLACE on the state and the accumulators it is given (a rollout owns them)."""
-        from ....ops import planar as _k
-
-        q = env_state["q"]
-        if _k.applies(self.engine, q) and q.is_contiguous() and env_state["qd"].is_contiguous() and done.dtype == torch.bool:
-            eng = self.engine
-            if q.device not in eng._params_task:
-                task = dict(ctrl_range=self.ctrl_range, forward_weight=self.forward_weight, ctrl_cost=self.ctrl_cost,
-                            healthy_reward=self.healthy_reward, terminate=self.terminate, z_range=self.z_range,
-                            angle_range=self.angle_range, obs_skip=self.obs_skip, vel_clip=self.vel_clip,
-                            frame_dt=self.frame_dt)
-                eng._params_task[q.device] = _k.param_block(eng, task).to(q.device)
-            obs = _k.step_task(eng, eng._params_task[q.device], q, env_state["qd"], action, self.obs_dim, total, done)
-            return env_state, obs, total, done
-        env_state, obs, reward, step_done = self.step(env_state, action)
-        total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
-        return env_state, obs, total, done | step_done
+    def _recipe(self):
+        return dict(recipe=1, ctrl_range=self.ctrl_range, forward_weight=self.forward_weight, ctrl_cost=self.ctrl_cost,
+                    healthy_reward=self.healthy_reward, terminate=self.terminate, z_range=self.z_range,
+                    angle_range=self.angle_range, obs_skip=self.obs_skip, vel_clip=self.vel_clip, frame_dt=self.frame_dt)
 
     def _healthy(self, st):
         ok = torch.ones(st["q"].shape[0], dtype=torch.bool, device=st["q"].device)
@@ -491,6 +503,9 @@ class InvertedPendulum(PlanarEnv):
                             dt=0.01, substeps=2, max_velocity=25.0)
         super().__init__(model, [0.0, 0.0, 0.0, 0.0])
 
+    def _recipe(self):
+        return dict(recipe=2, ctrl_range=self.ctrl_range, max_angle=0.2)
+
     def _observe(self, st):
         return torch.stack([st["q"][:, 0], st["q"][:, 3], st["qd"][:, 0], st["qd"][:, 3]], dim=1)
 
@@ -513,6 +528,9 @@ class InvertedDoublePendulum(PlanarEnv):
                             dt=0.005, substeps=4, max_velocity=50.0)
         super().__init__(model, [0.0] * 5)
         self._tip = self.engine._row(2, 0.6)[None]
+
+    def _recipe(self):
+        return dict(recipe=3, ctrl_range=self.ctrl_range, tip=self._tip)
 
     def _observe(self, st):
         q, qd = st["q"], st["qd"]
@@ -539,6 +557,11 @@ class Reacher(PlanarEnv):
                             dt=0.01, substeps=2, max_velocity=25.0)
         super().__init__(model, [0.0] * 4)
         self._tip = self.engine._row(1, 0.11)[None]
+
+    _aux_key = "target"
+
+    def _recipe(self):
+        return dict(recipe=4, ctrl_range=self.ctrl_range, tip=self._tip)
 
     def _reset_extra(self, key, batch, device):
         # uniform in the disk of radius 0.2
