@@ -683,7 +683,12 @@ class IPOPCMAES(CMAES):
                          pop_size=self.original_pop_size)
 
     def _variant(self, pop_size) -> CMAES:
-        return CMAES(pop_size=pop_size, **self._ctor)
+        # one instance per population size, kept: building one copies its weights to the device (a host-to-device copy
+        # per generation otherwise, and nothing a recording can hold)
+        cache = self.__dict__.setdefault("_variant_cache", {})
+        if pop_size not in cache:
+            cache[pop_size] = CMAES(pop_size=pop_size, **self._ctor)
+        return cache[pop_size]
 
     def ask(self, state):
         if state.pop_size != self.pop_size:

@@ -109,6 +109,7 @@ class StdWorkflow(Workflow):
         self.num_objectives = num_objectives
         self.migrate_helper = migrate_helper
         self.graph_step = graph_step
+        self._variants_issued = set()
         self.graph_mode = graph_mode
         self.graph_replays = 0
         self._eager_before_graph = 0
@@ -330,6 +331,12 @@ class StdWorkflow(Workflow):
         if self._graphed is None:
             self._graphed = {}
         graphed = self._graphed.get(variant)
+        if graphed is None and variant not in self._variants_issued:
+            # The first generation of a variant is issued eagerly: whatever its kernels set up at first use with these
+            # shapes (GEMM plans chosen by timing, workspaces, a kernel's LDS limit) involves the host and cannot be
+            # recorded — e.g. the doubled population after a restart of IPOP-CMA-ES.
+            self._variants_issued.add(variant)
+            return self._step(state)
         if graphed is None:
             from ..utils.graph import GraphedStep
 

@@ -2317,3 +2317,23 @@ def test_small_svd_cholesky_qr_expm_against_fp64(cuda, k, m):
     E = ls.expm_small(S.float().to(cuda)).double().cpu()
     Eref = torch.linalg.matrix_exp(S)
     assert float((E - Eref).norm() / Eref.norm()) < 2e-5
+
+
+def test_graph_replay_survives_a_restart_that_changes_the_population(cuda):
+    """IPOP-CMA-ES under graph replay: the restart (decided at the workflow's polls) doubles the population, the first
+    generation of the new size is issued eagerly (its kernels time GEMM plans and size workspaces at first use, which a
+    recording cannot hold), and the following ones are recorded afresh."""
+    import evox_amd as ex
+    from evox_amd import algorithms, problems, workflows
+
+    algo = algorithms.IPOPCMAES(torch.full((24,), 3.0, device=cuda), 0.5, pop_size=32, stagnation_threshold=4)
+    wf = workflows.StdWorkflow(algo, problems.numerical.Rastrigin(), graph_step=True)
+    state = wf.init(ex.PRNGKey(3).to(cuda))
+    for _ in range(260):
+        state = wf.step(state)
+    a = state.get_child_state("algorithm")
+    assert int(state.generation) == 260
+    assert a.restarts >= 1 and a.pop_size == 32 * 2 ** a.restarts
+    assert wf.graph_step is True and wf._graphed and a.pop_size in wf._graphed
+    assert {32, a.pop_size} <= wf._variants_issued
+    assert bool(torch.isfinite(a.mean).all())
