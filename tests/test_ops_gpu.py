@@ -2102,6 +2102,7 @@ def test_two_objective_sort_in_one_launch_equals_pair_test_sort(n, kind, until, 
     x = _two_objective_points(n, kind, n)
     k = None if until is None else int(n * until)
     monkeypatch.setenv("EVOX_AMD_NDS_M2_SCAN", "0")
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_PATIENCE", "0")
     want, info_w = _nds_hip.rank(x, k, with_info=True)
     monkeypatch.setenv("EVOX_AMD_NDS_M2_SCAN", "1")
     got, info_g = _nds_hip.rank_m2_scan(x, k, with_info=True)
@@ -2111,6 +2112,51 @@ def test_two_objective_sort_in_one_launch_equals_pair_test_sort(n, kind, until, 
     if n <= 3000:
         from evox_amd.ops import nds
         assert torch.equal(got, nds.non_dominated_rank_reference(x.cpu(), k).cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,kind", [(1, "cloud"), (63, "cloud"), (64, "grid"), (65, "chain"), (1500, "cloud"), (9000, "cloud"),
+                                    (24576, "cloud"), (60000, "cloud"), (5000, "front"), (6000, "grid"), (2500, "chain"),
+                                    (7000, "columns"), (3000, "infs"), (40000, "grid"), (50000, "front")])
+@pytest.mark.parametrize("until", [None, 0.5])
+def test_two_objective_patience_sort_equals_pair_test_sort(n, kind, until, monkeypatch):
+    """Two objectives at any size: front index = number of fronts whose smallest (second, first) key lies below the
+    point's own (binary search on the fronts' tails) raised by the dominators of its chunk — front indices, and the
+    collapse of everything behind the target, equal the pair-test sort: ties in either objective, identical points,
+    infinities, one front per point, sizes around the chunk of 64."""
+    from evox_amd.ops import _nds_hip
+
+    x = _two_objective_points(n, kind, 7 * n + 1)
+    k = None if until is None else max(1, int(n * until))
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_SCAN", "0")
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_PATIENCE", "0")
+    want, info_w = _nds_hip.rank(x, k, with_info=True)
+    monkeypatch.setenv("EVOX_AMD_NDS_M2_PATIENCE", "1")
+    got, info_g = _nds_hip.rank_m2_patience(x, k, with_info=True)
+    assert torch.equal(got, want), int((got != want).sum())
+    assert tuple(info_g) == tuple(info_w)
+    if n >= 4097:
+        assert torch.equal(_nds_hip.rank(x, k), want)                       # the dispatcher (this path for whole rankings)
+    if n <= 3000:
+        from evox_amd.ops import nds
+        assert torch.equal(got, nds.non_dominated_rank_reference(x.cpu(), k).cuda())
+
+
+@pytest.mark.gpu
+def test_two_objective_patience_sort_reports_too_many_fronts_and_nan():
+    """More fronts than the kernel's table holds (a chain of 20 000 points), or a NaN: None, and the dispatcher's answer
+    comes from another path."""
+    from evox_amd.ops import _nds_hip
+
+    x = _two_objective_points(20000, "chain", 3)
+    assert _nds_hip.rank_m2_patience(x) is None
+    want = torch.empty(20000, dtype=torch.int64, device="cuda")
+    want[torch.argsort(x[:, 0])] = torch.arange(20000, device="cuda")
+    assert torch.equal(_nds_hip.rank(x), want)
+    y = torch.rand(5000, 2, device="cuda")
+    y[11, 0] = float("nan")
+    assert _nds_hip.rank_m2_patience(y) is None
+    assert _nds_hip.rank(y).shape == (5000,)
 
 
 @pytest.mark.gpu
