@@ -247,11 +247,9 @@ class SpatialEngine:
 
     def step(self, pos, quat, theta, vel, ctrl):
         """``substeps`` semi-implicit Euler steps under constant controls (the kernel on a GPU, see ``ops/spatial.py``)."""
-        try:
-            from ....ops import spatial as _k
-        except ImportError:                                  # the binding is optional: the tensor formulation stands alone
-            _k = None
-        if _k is not None and _k.applies(self, pos):
+        from ....ops import spatial as _k
+
+        if _k.applies(self, pos):
             return _k.step(self, pos, quat, theta, vel, ctrl)
         return self.step_tensor(pos, quat, theta, vel, ctrl)
 
@@ -342,15 +340,17 @@ class Ant(TensorEnv):
         self.engine = SpatialEngine(SpatialModel(bodies, actuators=acts, contacts=contacts, contact_stiffness=2.0e3,
                                                  contact_damping=3.0e1))
         self._theta0 = torch.tensor([0.0, math.radians(50)] * 4)
+        self._pos0, self._pos_noise = torch.tensor([0.0, 0.0, 0.55]), torch.tensor([1.0, 1.0, 0.3])
+        self._quat0 = torch.tensor([[1.0, 0.0, 0.0, 0.0]])
 
     def reset(self, key, batch, device):
         device = torch.device(device)
         k0, k1 = rnd.split(key.to(device))
         e = self.engine
         noise = self.reset_noise * (2.0 * rnd.uniform(k0, (batch, 3 + e.nj)) - 1.0)
-        pos = torch.tensor([0.0, 0.0, 0.55], device=device) + noise[:, :3] * torch.tensor([1.0, 1.0, 0.3], device=device)
-        quat = torch.zeros(batch, 4, device=device)
-        quat[:, 0] = 1.0
+        # (constants are copied to the device once: a host-to-device copy per call could not be recorded into a graph)
+        pos = self._resident(self._pos0, device) + noise[:, :3] * self._resident(self._pos_noise, device)
+        quat = self._resident(self._quat0, device).expand(batch, 4).contiguous()
         theta = self._resident(self._theta0, device) + noise[:, 3:]
         vel = self.reset_noise * rnd.normal(k1, (batch, e.ndof))
         st = {"pos": pos, "quat": quat, "theta": theta, "vel": vel}
@@ -383,6 +383,25 @@ class Ant(TensorEnv):
         reward = torch.where(finite, reward, torch.zeros_like(reward))
         st = {"pos": pos, "quat": quat, "theta": theta, "vel": vel}
         return st, self._observe(st), reward, ~healthy | ~finite
+
+    def step_accumulate(self, env_state, action, total, done):
+        """One step of a rollout with the bookkeeping of ``TensorEnvProblem.evaluate`` included (see
+        ``PlanarEnv.step_accumulate``): on a GPU ONE launch (physics, observation, reward, termination, accumulation of
+        the return: ``csrc/spatial.hip``), in place on the state and the accumulators it is given."""
+        from ....ops import spatial as _k
+
+        pos = env_state["pos"]
+        if (_k.applies(self.engine, pos) and done.dtype == torch.bool
+                and all(env_state[k].is_contiguous() for k in ("pos", "quat", "theta", "vel"))):
+            task = dict(ctrl_range=self.ctrl_range, forward_weight=self.forward_weight, ctrl_cost=self.ctrl_cost,
+                        healthy_reward=self.healthy_reward, z_range=self.z_range, vel_clip=self.vel_clip,
+                        frame_dt=self.frame_dt)
+            obs = _k.step_task(self.engine, task, pos, env_state["quat"], env_state["theta"], env_state["vel"], action,
+                               self.obs_dim, total, done)
+            return env_state, obs, total, done
+        env_state, obs, reward, step_done = self.step(env_state, action)
+        total = total + torch.where(done, torch.zeros_like(reward), reward.to(torch.float32))
+        return env_state, obs, total, done | step_done
 
     def snapshot(self, env_state, index: int = 0):
         return self.engine.segments(env_state["pos"], env_state["quat"], env_state["theta"], index)

@@ -121,3 +121,75 @@ def test_brax_ant_rollout_and_visualisation():
     frames = prob.visualize(ex.PRNGKey(0), w[0], output_type="rgb_array", width=120, height=90)
     assert len(frames) == 16 and frames[0].shape == (90, 120, 3)
     assert int((frames[0] == (30, 60, 140)).all(-1).sum()) > 30
+
+
+@pytest.mark.gpu
+def test_spatial_step_kernel_matches_the_tensor_formulation():
+    """``csrc/spatial.hip`` (one environment per lane) against ``SpatialEngine.step_tensor`` in fp64 from the same states:
+    a free tree of five bodies with skew axes, and the ant along a rollout under random controls (feet touching down
+    and lifting, ankles at their limits) — every environment step agrees to fp32 rounding."""
+    dev = torch.device("cuda")
+    eng = _random_tree(9.81)
+    eng.model.dt, eng.model.substeps = 2e-3, 4
+    st = tuple(t.float().to(dev) for t in _random_state(eng, 200, 5))
+    for t in range(20):
+        got = eng.step(*st, None)
+        want = eng.step_tensor(*(x.double() for x in st), None)
+        for g, w in zip(got, want):
+            assert float(((g.double() - w) / (1 + w.abs())).abs().max()) < 1e-4, t
+        st = got
+    env = make_tensor_env("ant")
+    e = env.engine
+    s, _ = env.reset(ex.PRNGKey(11).to(dev), 256, dev)
+    st = (s["pos"], s["quat"], s["theta"], s["vel"])
+    gen = torch.Generator().manual_seed(12)
+    for t in range(100):
+        a = (torch.rand(256, 8, generator=gen) * 2 - 1).to(dev)
+        got = e.step(*st, a)
+        assert got[0].data_ptr() != st[0].data_ptr()
+        want = e.step_tensor(*(x.double() for x in st), a.double())
+        for g, w in zip(got, want):
+            assert float(((g.double() - w) / (1 + w.abs())).abs().max()) < 2e-3, t
+        st = got
+
+
+@pytest.mark.gpu
+def test_ant_fused_rollout_step_matches_step_plus_bookkeeping_and_records():
+    """``Ant.step_accumulate`` (one launch, in place) against ``step`` plus the rollout's own bookkeeping from the same
+    states; and OpenES over MLP policies on the ant replays from a graph with the generations of eager issue."""
+    from evox_amd import algorithms, workflows
+    from evox_amd.models import MLP
+
+    dev = torch.device("cuda")
+    env = make_tensor_env("ant")
+    st, _ = env.reset(ex.PRNGKey(21).to(dev), 512, dev)
+    total = torch.zeros(512, device=dev)
+    done = torch.zeros(512, dtype=torch.bool, device=dev)
+    gen = torch.Generator().manual_seed(22)
+    for t in range(60):
+        a = (torch.rand(512, 8, generator=gen) * 3 - 1.5).to(dev)
+        before = {k: v.clone() for k, v in st.items()}
+        st2, obs2, reward, step_done = env.step(before, a)
+        want_total = total + torch.where(done, torch.zeros_like(reward), reward)
+        want_done = done | step_done
+        st, obs, total, done = env.step_accumulate(st, a, total, done)
+        assert torch.allclose(obs, obs2, rtol=1e-4, atol=1e-4), (t, float((obs - obs2).abs().max()))
+        assert torch.allclose(total, want_total, rtol=1e-4, atol=1e-3), t
+        assert int((done != want_done).sum()) <= 2, t
+        total, done = want_total.clone(), want_done.clone()
+        st = {k: v.clone() for k, v in st2.items()}
+    net = MLP([27, 32, 8])
+
+    def run(graph):
+        prob = Brax(net.batched_apply, "ant", 30, 1)
+        algo = algorithms.OpenES(net.init(ex.PRNGKey(1), device=dev), 256, 0.05, 0.1)
+        wf = workflows.StdWorkflow(algo, prob, opt_direction="max", graph_step=graph)
+        state = wf.init(ex.PRNGKey(2).to(dev))
+        for _ in range(8):
+            state = wf.step(state)
+        return wf, state.get_child_state("algorithm").center.clone()
+
+    we, ce = run(False)
+    wg, cg = run(True)
+    assert wg.graph_step is True and wg._graphed
+    assert torch.equal(ce, cg)

@@ -11,7 +11,7 @@ from evox_amd.problems.neuroevolution.reinforcement_learning import Brax, make_t
 from evox_amd.utils import rank_based_fitness
 
 gens = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-tasks = sys.argv[2:] or ["inverted_pendulum", "inverted_double_pendulum", "reacher", "swimmer", "hopper", "walker2d", "halfcheetah"]
+tasks = sys.argv[2:] or ["inverted_pendulum", "inverted_double_pendulum", "reacher", "swimmer", "hopper", "walker2d", "halfcheetah", "ant"]
 dev = torch.device("cuda")
 for task in tasks:
     env = make_tensor_env(task)
