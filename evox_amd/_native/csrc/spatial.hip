@@ -223,14 +223,19 @@ __global__ __launch_bounds__(64) void spatial_step_kernel(const float* __restric
         Wy[5 + k] = on * SLOT(k * kBodySlots + 13);
         Wz[5 + k] = on * SLOT(k * kBodySlots + 14);
       }
+      // columns of hinges that do not carry this body are zero: skipped (uniform branches — the model is the same
+      // in every lane), which leaves 8 of an ant leg's 14 columns
 #pragma unroll
       for (int dd = 0; dd < N; ++dd) {
+        if (dd >= 6 && anc_row[dd - 5] == 0.f) continue;
         const float ix = Iw[0][0] * Wx[dd] + Iw[0][1] * Wy[dd] + Iw[0][2] * Wz[dd];
         const float iy = Iw[1][0] * Wx[dd] + Iw[1][1] * Wy[dd] + Iw[1][2] * Wz[dd];
         const float iz = Iw[2][0] * Wx[dd] + Iw[2][1] * Wy[dd] + Iw[2][2] * Wz[dd];
 #pragma unroll
-        for (int e = 0; e <= dd; ++e)
+        for (int e = 0; e <= dd; ++e) {
+          if (e >= 6 && anc_row[e - 5] == 0.f) continue;
           M[dd][e] += m * (Jx[dd] * Jx[e] + Jy[dd] * Jy[e] + Jz[dd] * Jz[e]) + ix * Wx[e] + iy * Wy[e] + iz * Wz[e];
+        }
         Q[dd] += Jx[dd] * f.x + Jy[dd] * f.y + Jz[dd] * f.z + Wx[dd] * tq.x + Wy[dd] * tq.y + Wz[dd] * tq.z;
       }
     }
