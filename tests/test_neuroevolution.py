@@ -180,9 +180,70 @@ def test_dataset_problem_with_pgpe():
     assert float(monitor.get_best_fitness()) < 0.09
 
 
-def test_tensorflow_dataset_requires_tfds():
+def test_tensorflow_dataset_requires_tfds(tmp_path):
     with pytest.raises(ImportError):
-        neuro.TensorflowDataset("fashion_mnist", 8, lambda w, d: 0.0)
+        neuro.TensorflowDataset("fashion_mnist", 8, lambda w, d: 0.0, datadir=str(tmp_path))
+
+
+def test_tensorflow_dataset_reads_the_files_a_download_leaves_on_disk(tmp_path):
+    """Without ``tensorflow_datasets`` the reference's entry point (``tfds.py:26-62``) reads the dataset's own files:
+    IDX (the MNIST family), CIFAR-10's binary batches, numpy archives (one per split, or Keras style with both), parquet;
+    the columns arrive as the TFDS features would (uint8 NHWC images, integer labels), and a search runs on them."""
+    import gzip
+    import struct
+
+    from evox_amd.problems.neuroevolution.supervised_learning.dataset import load_local_dataset
+
+    g = np.random.default_rng(0)
+    # IDX, gzip-compressed like the original distribution
+    d = tmp_path / "mnist"
+    d.mkdir()
+    for stem, n in (("train", 40), ("t10k", 12)):
+        img = g.integers(0, 256, (n, 28, 28), dtype=np.uint8)
+        lab = g.integers(0, 10, n, dtype=np.uint8)
+        with gzip.open(d / f"{stem}-images-idx3-ubyte.gz", "wb") as f:
+            f.write(struct.pack(">HBBIII", 0, 8, 3, n, 28, 28) + img.tobytes())
+        with open(d / f"{stem}-labels-idx1-ubyte", "wb") as f:
+            f.write(struct.pack(">HBBI", 0, 8, 1, n) + lab.tobytes())
+        got = load_local_dataset("mnist", "test" if stem == "t10k" else "train", str(tmp_path))
+        assert got.size == n and got.arrays["image"].shape == (n, 28, 28, 1) and got.arrays["image"].dtype == torch.uint8
+        assert torch.equal(got.arrays["image"][..., 0], torch.as_tensor(img)) and torch.equal(got.arrays["label"], torch.as_tensor(lab.astype(np.int64)))
+    # CIFAR-10 binary batches
+    c = tmp_path / "cifar10" / "cifar-10-batches-bin"
+    c.mkdir(parents=True)
+    rows = g.integers(0, 256, (30, 3073), dtype=np.uint8)
+    rows[:, 0] %= 10
+    rows[:20].tofile(c / "data_batch_1.bin")
+    rows[20:].tofile(c / "data_batch_2.bin")
+    got = load_local_dataset("cifar10", "train", str(tmp_path))
+    assert got.arrays["image"].shape == (30, 32, 32, 3)
+    assert torch.equal(got.arrays["image"][3, 5, 7], torch.as_tensor(rows[3, 1:].reshape(3, 32, 32)[:, 5, 7]))
+    assert torch.equal(got.arrays["label"], torch.as_tensor(rows[:, 0].astype(np.int64)))
+    # numpy archives: Keras style (both splits in one file) and one file per split
+    np.savez(tmp_path / "toy.npz", x_train=np.ones((9, 4, 4), np.uint8), y_train=np.arange(9), x_test=np.zeros((3, 4, 4), np.uint8),
+             y_test=np.arange(3))
+    tr, te = load_local_dataset("toy", "train", str(tmp_path)), load_local_dataset("toy", "test", str(tmp_path))
+    assert tr.arrays["image"].shape == (9, 4, 4, 1) and te.arrays["label"].tolist() == [0, 1, 2]
+    (tmp_path / "blobs").mkdir()
+    np.savez(tmp_path / "blobs" / "train.npz", features=g.normal(size=(64, 5)).astype(np.float32), label=g.integers(0, 3, 64))
+    # parquet: numeric columns and fixed-length list columns
+    import pyarrow as pa
+    import pyarrow.parquet as papq
+
+    (tmp_path / "tab").mkdir()
+    papq.write_table(pa.table({"features": [[float(i), 2.0 * i] for i in range(10)], "label": list(range(10))}),
+                     tmp_path / "tab" / "train-00000-of-00001.parquet")
+    tab = load_local_dataset("tab", "train", str(tmp_path))
+    assert tab.arrays["features"].shape == (10, 2) and tab.arrays["label"].tolist() == list(range(10))
+    assert load_local_dataset("absent", "train", str(tmp_path)) is None
+
+    def loss(w, data):                                       # a linear classifier per individual, batched over the population
+        logits = torch.einsum("bf,pfc->pbc", data["features"], w.reshape(w.shape[0], 5, 3))
+        return torch.nn.functional.cross_entropy(logits.flatten(0, 1), data["label"].repeat(w.shape[0]), reduction="none").reshape(w.shape[0], -1).mean(1)
+
+    prob = neuro.TensorflowDataset("blobs", 16, loss, datadir=str(tmp_path), batched_loss=True)
+    fit, st = prob.evaluate(prob.setup(ex.PRNGKey(0)), torch.zeros(7, 15))
+    assert fit.shape == (7,) and torch.allclose(fit, torch.full((7,), math.log(3.0)), atol=1e-5) and st.step == 1
 
 
 def test_evoxbench_adapter_with_stub_benchmark():
