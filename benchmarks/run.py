@@ -4,6 +4,7 @@
     python benchmarks/run.py cmaes_sphere_bf16         # CMA-ES pop=10k dim=1k Sphere, bf16 sampling
     python benchmarks/run.py nsga2_dtlz2 --pop 100000  # NSGA-II on 3-objective DTLZ2
     python benchmarks/run.py openes_mlp                # OpenES, ~1M-parameter MLP policy, pop=4096
+    python benchmarks/run.py openes_physics --task ant # OpenES, small MLP policies on an in-tree physics task
     python benchmarks/run.py island_shade              # island-model SHADE on CEC'22 F1, pop=50k per island
 
 Multi-GPU configurations: ``python benchmarks/run.py <name> --gpus N`` starts one process per GPU itself
@@ -160,6 +161,29 @@ def openes_mlp(args):
           gens_per_sec=args.steps / dt, ms_per_step=1e3 * dt / args.steps, n_gpus=world)
 
 
+def openes_physics(args):
+    """OpenES over small MLP policies on an in-tree physics task (``--task hopper|walker2d|halfcheetah|swimmer|ant|…``):
+    the environment step, its observation, reward, termination and the return accumulation are one launch per step."""
+    device, world, rank = _setup(args)
+    from evox_amd.models import MLP
+    from evox_amd.problems.neuroevolution import Brax, make_tensor_env
+    env = make_tensor_env(args.task)
+    net = MLP([env.obs_dim, 32, 32, env.act_dim])
+    pop = args.pop or 4096
+    prob = Brax(net.batched_apply, args.task, args.episode_length, 1)
+    algo = algorithms.OpenES(net.init(ex.PRNGKey(0)).to(device), pop_size=pop, learning_rate=0.03, noise_stdev=0.1,
+                             optimizer="adam", mirrored_sampling=True)
+    cls = workflows.ShardedWorkflow if world > 1 else workflows.StdWorkflow
+    kw = {} if world > 1 else {"graph_step": args.graph}
+    wf = cls(algo, prob, opt_direction="max", **kw)
+    state = wf.init(ex.PRNGKey(3).to(device))
+    state, dt = _timed(wf, state, args.steps, args.warmup, device)
+    _emit(rank, config=f"OpenES MLP {net.sizes} pop={pop} x{world} ranks, {args.task} (in-tree physics), "
+          f"episode_length={args.episode_length}", evals_per_sec=pop * args.steps / dt,
+          env_steps_per_sec=pop * args.episode_length * args.steps / dt, gens_per_sec=args.steps / dt,
+          ms_per_step=1e3 * dt / args.steps, n_gpus=world)
+
+
 def island_shade(args):
     device, world, rank = _setup(args)
     pop, d = args.pop or 50000, args.dim or 20
@@ -180,7 +204,7 @@ def island_shade(args):
           gens_per_sec=args.steps / dt, ms_per_step=1e3 * dt / args.steps, migration_us=mig_us, best=best, n_gpus=world)
 
 
-CONFIGS = {f.__name__: f for f in (pso_quickstart, cmaes_sphere_bf16, nsga2_dtlz2, openes_mlp, island_shade)}
+CONFIGS = {f.__name__: f for f in (pso_quickstart, cmaes_sphere_bf16, nsga2_dtlz2, openes_mlp, openes_physics, island_shade)}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -195,6 +219,7 @@ if __name__ == "__main__":
     ap.add_argument("--algo", default="openes")
     ap.add_argument("--param-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--episode-length", type=int, default=50)
+    ap.add_argument("--task", default="hopper", help="openes_physics: the physics task")
     ap.add_argument("--migrate-every", type=int, default=10)
     ap.add_argument("--migrants", type=int, default=64)
     ap.add_argument("--graph", action="store_true", help="replay steady-state generations from a HIP graph")
