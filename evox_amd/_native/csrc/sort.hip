@@ -626,7 +626,116 @@ __global__ __launch_bounds__(kSelThreads) void select_kernel(const float* __rest
   });
 }
 
+// The same selection with the keys held in registers: up to 65 536 keys are 64 per lane of a 1024-thread workgroup,
+// so memory is read once instead of five times and every pass runs at the issue rate of the compute unit.  Wave w
+// owns the contiguous keys [w*64*per, (w+1)*64*per), lane l its positions u*64 + l: loads are coalesced, and the
+// ascending index order of the output is (wave, u, lane), which needs only a running per-wave count (a ballot and a
+// scalar population count per step) and one 16-entry scan over the waves — no per-chunk table.
+// The second and third histogram pass only see the keys that share the prefix found so far; a step of a wave with no
+// such key costs a compare and a branch.
+template <int E>
+__global__ __launch_bounds__(kSelThreads) void select_reg_kernel(const float* __restrict__ x, int n, int per, int k,
+                                                                 int largest, int64_t* __restrict__ out) {
+  __shared__ unsigned int hist[kSelBins];
+  __shared__ unsigned int wave_tot[kSelThreads / 64];
+  __shared__ unsigned int wcnt[kSelThreads / 64][2];
+  __shared__ unsigned int s_bin, s_before;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool lg = largest != 0;
+  const int first = wave * 64 * per + lane;              // index of this lane's key at step 0
+  const int left = n - first;                            // step u holds a key iff u*64 < left
+  uint32_t kk[E];
+#pragma unroll
+  for (int u = 0; u < E; ++u) {
+    kk[u] = 0xffffffffu;
+    if (u < per) {                                       // uniform
+      const int i = first + u * 64;
+      if (i < n) kk[u] = select_key(x[i], lg);
+    }
+  }
+  uint32_t prefix = 0, mask = 0;
+  unsigned int remaining = (unsigned int)k;              // rank (1-based) of the wanted key among the candidates
+#pragma nounroll
+  for (int pass = 0; pass < 3; ++pass) {                 // not unrolled: the last two passes share their code
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const uint32_t bins = pass == 2 ? 1024u : 2048u;
+    for (int b = tid; b < kSelBins; b += kSelThreads) hist[b] = 0;
+    __syncthreads();
+    if (pass == 0) {
+#pragma unroll
+      for (int u = 0; u < E; ++u)
+        if (u < per) hist_add<true>(hist, kk[u] >> 21, u * 64 < left);
+    } else {
+#pragma unroll
+      for (int u = 0; u < E; ++u)
+        if (u < per) {
+          const bool cand = u * 64 < left && (kk[u] & mask) == prefix;
+          if (__ballot(cand)) hist_add<true>(hist, (kk[u] >> shift) & (bins - 1), cand);
+        }
+    }
+    __syncthreads();
+    const unsigned int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    unsigned int incl = h0 + h1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    const unsigned int end1 = before + incl, end0 = end1 - h1, start0 = end0 - h0;
+    if (start0 < remaining && remaining <= end0) { s_bin = 2 * tid; s_before = start0; }
+    else if (end0 < remaining && remaining <= end1) { s_bin = 2 * tid + 1; s_before = end0; }
+    __syncthreads();
+    prefix |= s_bin << shift;
+    mask |= (bins - 1) << shift;
+    remaining -= s_before;
+    __syncthreads();
+  }
+  // prefix: key of the k-th element; remaining: how many elements equal to it are taken
+  const uint32_t T = prefix;
+  unsigned int c_lt = 0, c_eq = 0;                       // wave-uniform
+#pragma unroll
+  for (int u = 0; u < E; ++u)
+    if (u < per) {
+      const bool valid = u * 64 < left;
+      c_lt += __popcll(__ballot(valid && kk[u] < T));
+      c_eq += __popcll(__ballot(valid && kk[u] == T));
+    }
+  if (lane == 0) { wcnt[wave][0] = c_lt; wcnt[wave][1] = c_eq; }
+  __syncthreads();
+  unsigned int off_lt = 0, off_eq = 0;
+  for (int w = 0; w < wave; ++w) { off_lt += wcnt[w][0]; off_eq += wcnt[w][1]; }
+#pragma unroll
+  for (int u = 0; u < E; ++u)
+    if (u < per) {
+      const bool valid = u * 64 < left;
+      const bool lt = valid && kk[u] < T, eq = valid && kk[u] == T;
+      const unsigned long long blt = __ballot(lt), beq = __ballot(eq);
+      if (blt | beq) {
+        const unsigned int my_lt = off_lt + __builtin_amdgcn_mbcnt_hi((unsigned int)(blt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)blt, 0u));
+        const unsigned int my_eq = off_eq + __builtin_amdgcn_mbcnt_hi((unsigned int)(beq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)beq, 0u));
+        const int i = first + u * 64;
+        if (lt) out[my_lt + min(my_eq, remaining)] = i;
+        else if (eq && my_eq < remaining) out[my_lt + my_eq] = i;
+        off_lt += __popcll(blt);
+        off_eq += __popcll(beq);
+      }
+    }
+}
+
 }  // namespace
+
+// evox_hip_select for n <= 65 536 with the keys resident in registers (one read of the keys).
+EVOX_API int evox_hip_select_reg(const float* x, int n, int k, int largest, int64_t* out, void* stream) {
+  if (n <= 0 || k < 1 || k > n || n > (1 << 16)) return (int)hipErrorInvalidValue;
+  const int per = (n + kSelThreads - 1) / kSelThreads;
+  hipStream_t s = (hipStream_t)stream;
+  if (per <= 8) select_reg_kernel<8><<<1, kSelThreads, 0, s>>>(x, n, per, k, largest, out);
+  else if (per <= 16) select_reg_kernel<16><<<1, kSelThreads, 0, s>>>(x, n, per, k, largest, out);
+  else if (per <= 32) select_reg_kernel<32><<<1, kSelThreads, 0, s>>>(x, n, per, k, largest, out);
+  else select_reg_kernel<64><<<1, kSelThreads, 0, s>>>(x, n, per, k, largest, out);
+  return evox::last_launch_status();
+}
 
 // out: k indices (int64, ascending) of the k smallest (largest != 0: largest) of the n keys; 1 <= k <= n <= 2^20.
 EVOX_API int evox_hip_select(const float* x, int n, int k, int largest, int64_t* out, void* stream) {
@@ -815,6 +924,172 @@ __global__ __launch_bounds__(kMsThreads) void ms_emit_kernel(const float* __rest
 }
 
 }  // namespace
+
+// The chip-wide selection in ONE launch for up to 262 144 keys: at most 64 workgroups of 256 threads, each with its
+// 4096 keys in registers, meet at four grid-wide barriers (after each histogram pass has been added to the global
+// histogram, and after the per-block counts are stored).  Five launches and their gaps cost ≈45 µs on the stream for
+// work that takes a few µs; a barrier is one atomic and a poll per workgroup.  All workgroups of so small a grid
+// are resident together, so the barrier completes as soon as the slowest one arrives; the wait is nevertheless
+// bounded (spin_limit polls): a workgroup that gives up counts itself in `timeouts`, zero-fills its share of the
+// output and leaves, and so do all others when their own wait runs out.
+namespace {
+
+constexpr int kGsThreads = 256;
+constexpr int kGsE = 16;                                 // keys per lane
+constexpr int kGsPerBlock = kGsThreads * kGsE;
+constexpr int kGsMaxBlocks = 64;                         // one lane per preceding workgroup in the offset sum
+
+struct GridSel {
+  unsigned int arrive;                                   // barrier arrivals, monotonic over the barriers of a call
+  unsigned int timeouts;                                 // workgroups that gave up waiting
+  unsigned int pad[2];
+  unsigned int hist[3][kSelBins];
+  unsigned int blockcnt[kGsMaxBlocks][2];
+};
+
+// true when all workgroups have arrived; the same value in every thread of the workgroup
+__device__ __forceinline__ bool grid_wait(GridSel* g, unsigned int target, unsigned int* s_ok, int spin_limit) {
+  // Everything the workgroups exchange is written with device-scope atomics, which are performed where all of them
+  // see it; what the arrival needs is that this workgroup's own atomics have been acknowledged, so every thread
+  // waits for its outstanding memory operations — no cache write-back, which a fence of device scope would add.
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int budget = spin_limit;
+    if (atomicAdd(&g->arrive, 1u) + 1u < target)
+      while (agent_load(&g->arrive) < target && --budget > 0) __builtin_amdgcn_s_sleep(2);
+    if (budget <= 0) atomicAdd(&g->timeouts, 1u);
+    *s_ok = budget > 0 ? 1u : 0u;
+  }
+  __syncthreads();
+  return *s_ok != 0u;
+}
+
+__global__ __launch_bounds__(kGsThreads) void select_grid_kernel(const float* __restrict__ x, int n, int k, int largest,
+                                                                 int64_t* __restrict__ out, GridSel* __restrict__ g,
+                                                                 int spin_limit) {
+  __shared__ unsigned int hist[kSelBins];
+  __shared__ unsigned int wave_tot[kGsThreads / 64];
+  __shared__ unsigned int wcnt[kGsThreads / 64][2];
+  __shared__ unsigned int s_bin, s_before, s_ok;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blocks = gridDim.x;
+  const bool lg = largest != 0;
+  // wave w of block b owns the contiguous keys [b*4096 + w*1024, +1024): ascending index = (block, wave, u, lane)
+  const int first = blockIdx.x * kGsPerBlock + wave * (64 * kGsE) + lane;
+  const int left = n - first;
+  uint32_t kk[kGsE];
+#pragma unroll
+  for (int u = 0; u < kGsE; ++u) {
+    const int i = first + u * 64;
+    kk[u] = i < n ? select_key(x[i], lg) : 0xffffffffu;
+  }
+  auto give_up = [&]() {
+    for (int j = blockIdx.x * kGsThreads + tid; j < k; j += blocks * kGsThreads) out[j] = 0;
+  };
+  uint32_t prefix = 0, mask = 0;
+  unsigned int remaining = (unsigned int)k, arrivals = 0;
+#pragma nounroll
+  for (int pass = 0; pass < 3; ++pass) {
+    const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+    const uint32_t bins = pass == 2 ? 1024u : 2048u;
+    for (int b = tid; b < kSelBins; b += kGsThreads) hist[b] = 0;
+    __syncthreads();
+    if (pass == 0) {
+#pragma unroll
+      for (int u = 0; u < kGsE; ++u) hist_add<true>(hist, kk[u] >> 21, u * 64 < left);
+    } else {
+#pragma unroll
+      for (int u = 0; u < kGsE; ++u) {
+        const bool cand = u * 64 < left && (kk[u] & mask) == prefix;
+        if (__ballot(cand)) hist_add<true>(hist, (kk[u] >> shift) & (bins - 1), cand);
+      }
+    }
+    __syncthreads();
+    for (int b = tid; b < kSelBins; b += kGsThreads)
+      if (hist[b]) atomicAdd(&g->hist[pass][b], hist[b]);
+    arrivals += blocks;
+    if (!grid_wait(g, arrivals, &s_ok, spin_limit)) { give_up(); return; }
+    // every workgroup scans the complete histogram (eight bins per thread) and refines the prefix the same way
+    unsigned int h[kSelBins / kGsThreads], incl = 0;
+#pragma unroll
+    for (int q = 0; q < kSelBins / kGsThreads; ++q) { h[q] = agent_load(&g->hist[pass][tid * (kSelBins / kGsThreads) + q]); incl += h[q]; }
+    const unsigned int mine = incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned int start = incl - mine;
+    for (int w = 0; w < wave; ++w) start += wave_tot[w];
+#pragma unroll
+    for (int q = 0; q < kSelBins / kGsThreads; ++q) {
+      if (start < remaining && remaining <= start + h[q]) { s_bin = tid * (kSelBins / kGsThreads) + q; s_before = start; }
+      start += h[q];
+    }
+    __syncthreads();
+    prefix |= s_bin << shift;
+    mask |= (bins - 1) << shift;
+    remaining -= s_before;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;
+  unsigned int c_lt = 0, c_eq = 0;                       // wave-uniform
+#pragma unroll
+  for (int u = 0; u < kGsE; ++u) {
+    const bool valid = u * 64 < left;
+    c_lt += __popcll(__ballot(valid && kk[u] < T));
+    c_eq += __popcll(__ballot(valid && kk[u] == T));
+  }
+  if (lane == 0) { wcnt[wave][0] = c_lt; wcnt[wave][1] = c_eq; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int a = 0, b = 0;
+    for (int w = 0; w < kGsThreads / 64; ++w) { a += wcnt[w][0]; b += wcnt[w][1]; }
+    __hip_atomic_store(&g->blockcnt[blockIdx.x][0], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&g->blockcnt[blockIdx.x][1], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  arrivals += blocks;
+  if (!grid_wait(g, arrivals, &s_ok, spin_limit)) { give_up(); return; }
+  // keys selected before this wave: the preceding workgroups (one per lane), then the preceding waves
+  unsigned int off_lt = lane < (int)blockIdx.x ? agent_load(&g->blockcnt[lane][0]) : 0u;
+  unsigned int off_eq = lane < (int)blockIdx.x ? agent_load(&g->blockcnt[lane][1]) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { off_lt += __shfl_xor(off_lt, o, 64); off_eq += __shfl_xor(off_eq, o, 64); }
+  for (int w = 0; w < wave; ++w) { off_lt += wcnt[w][0]; off_eq += wcnt[w][1]; }
+#pragma unroll
+  for (int u = 0; u < kGsE; ++u) {
+    const bool valid = u * 64 < left;
+    const bool lt = valid && kk[u] < T, eq = valid && kk[u] == T;
+    const unsigned long long blt = __ballot(lt), beq = __ballot(eq);
+    if (blt | beq) {
+      const unsigned int my_lt = off_lt + __builtin_amdgcn_mbcnt_hi((unsigned int)(blt >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)blt, 0u));
+      const unsigned int my_eq = off_eq + __builtin_amdgcn_mbcnt_hi((unsigned int)(beq >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)beq, 0u));
+      const int i = first + u * 64;
+      if (lt) out[my_lt + min(my_eq, remaining)] = i;
+      else if (eq && my_eq < remaining) out[my_lt + my_eq] = i;
+      off_lt += __popcll(blt);
+      off_eq += __popcll(beq);
+    }
+  }
+}
+
+}  // namespace
+
+// Bytes of zero-initialised workspace of evox_hip_select_grid, and the most keys it takes.
+EVOX_API int64_t evox_hip_select_grid_ws() { return (int64_t)sizeof(GridSel); }
+EVOX_API int evox_hip_select_grid_max() { return kGsMaxBlocks * kGsPerBlock; }
+
+// Like evox_hip_select, one launch of ceil(n / 4096) <= 64 co-operating workgroups; ws: zeroed workspace (its second
+// 32-bit word counts workgroups whose bounded wait ran out: the output is then zero-filled, not a selection).
+// spin_limit <= 0: the default bound (about a second).
+EVOX_API int evox_hip_select_grid(const float* x, int n, int k, int largest, int64_t* out, void* ws, int spin_limit,
+                                  void* stream) {
+  if (n <= 0 || k < 1 || k > n || ws == nullptr || n > kGsMaxBlocks * kGsPerBlock) return (int)hipErrorInvalidValue;
+  const int blocks = (n + kGsPerBlock - 1) / kGsPerBlock;
+  select_grid_kernel<<<blocks, kGsThreads, 0, (hipStream_t)stream>>>(x, n, k, largest, out, (GridSel*)ws,
+                                                                    spin_limit > 0 ? spin_limit : (1 << 20));
+  return evox::last_launch_status();
+}
 
 // Bytes of zero-initialised workspace evox_hip_select_wide needs for n keys.
 EVOX_API int64_t evox_hip_select_wide_ws(int n) {

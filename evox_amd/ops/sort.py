@@ -16,6 +16,9 @@ _native.register_hip_api({"evox_hip_rank_sort": (I, [P, I, P, P, P]),
                           "evox_hip_rank_sort_scratch": (_native.I64, [I]),
                           "evox_hip_rank_sort_sliced": (I, [P, I, P, P, P, P]),
                           "evox_hip_rank_sort_values": (I, [P, I, P, P, P, P, P, P]), "evox_hip_select": (I, [P, I, I, I, P, P]),
+                          "evox_hip_select_reg": (I, [P, I, I, I, P, P]),
+                          "evox_hip_select_grid_ws": (_native.I64, []), "evox_hip_select_grid_max": (I, []),
+                          "evox_hip_select_grid": (I, [P, I, I, I, P, P, I, P]),
                           "evox_hip_select_wide_ws": (_native.I64, [I]),
                           "evox_hip_select_wide": (I, [P, I, I, I, P, P, P])})
 
@@ -112,36 +115,62 @@ def _rank_sort(keys: torch.Tensor, want_rank: bool, form: str = None):
     return order, rank
 
 
-# Device time (µs): one workgroup 24 / 78 at 10 000 / 50 000 keys, the five-launch form ≈20 at 50 000 and 90 at 10⁶,
-# the library's top-k 37 / 50 / 222.  A DE generation is a dozen launches, so up to 65 536 keys the single launch wins
-# on the wall clock (SHADE at 50 000: 0.21 ms per generation against 0.26 with either multi-launch form).
-_SELECT_ONE_WG_MAX = 1 << 16
-_SELECT_WIDE_IN_GRAPH_MIN = 8192
+# Time per call (µs, back-to-back on one stream) at 10 000 / 50 000 / 262 144 keys: one workgroup with the keys in
+# registers 15 / 53 / -, one launch of co-operating workgroups (with the fill of its workspace) 22 / 24 / 29, one
+# workgroup re-reading the keys 22 / 76 / 327, the five-launch form 42 / 44 / 52, the library's top-k 37 / 50 / 122
+# (tools/select_timing.py).  SHADE at 50 000 individuals under graph replay: 0.163 -> 0.144 ms per generation.
+_SELECT_REG_MAX = 1 << 14
+_SELECT_ROUTE = None                   # tests: force "registers" / "grid" / "one_workgroup" / "wide"
+
+
+def _select_route(n: int) -> str:
+    if _SELECT_ROUTE is not None:
+        return _SELECT_ROUTE
+    if n <= _SELECT_REG_MAX:
+        return "registers"
+    if n <= int(hip().evox_hip_select_grid_max()):
+        return "grid"
+    return "wide"
+
+
+def select_grid(keys: torch.Tensor, k: int, largest: bool = False, spin_limit: int = 0):
+    """The one-launch chip-wide selection and its workspace (int32; word 1 counts workgroups whose bounded wait at a
+    grid-wide barrier ran out — the output is then zero-filled instead of a selection)."""
+    n = keys.shape[0]
+    out = torch.empty(k, dtype=torch.int64, device=keys.device)
+    ws = torch.zeros((int(hip().evox_hip_select_grid_ws()) + 3) // 4, dtype=torch.int32, device=keys.device)
+    check(hip().evox_hip_select_grid(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), ws.data_ptr(),
+                                     int(spin_limit), stream_of(keys)), "select_grid")
+    return out, ws
 
 
 def select_indices(keys: torch.Tensor, k: int, largest: bool = False) -> torch.Tensor:
     """Indices (int64, ascending) of the ``k`` smallest — or largest — entries of the 1-D ``keys``; NaN entries are
     taken last, ties at the threshold go to the lower index.
 
-    On the GPU a radix select (``csrc/sort.hip``) instead of a sort: up to 65 536 keys ONE launch of one persistent
-    workgroup (three histogram passes in LDS, then an ordered write-out); longer vectors the same passes spread over
-    the chip, five launches whose last-finishing workgroup scans the global histogram / the per-block counts."""
+    On the GPU a radix select (``csrc/sort.hip``) instead of a sort, always ONE launch up to 262 144 keys: three
+    histogram passes over 11 + 11 + 10 bits of the keys' integer image, then an ordered write-out, with the keys held
+    in registers throughout — by one workgroup up to 16 384 keys, above that by up to 64 workgroups that meet at
+    grid-wide barriers.  Longer vectors: the same passes as five launches whose last-finishing workgroup scans the
+    global histogram / the per-block counts."""
     n = keys.shape[0]
     k = int(k)
     if not 1 <= k <= n:
         raise ValueError("k must be in [1, n]")
     if keys.is_cuda and keys.dtype == torch.float32 and keys.dim() == 1:
         keys = keys.contiguous()
+        route = _select_route(n)
+        if route == "grid":
+            return select_grid(keys, k, largest)[0]
         out = torch.empty(k, dtype=torch.int64, device=keys.device)
-        # while a generation is being recorded into a graph the host cost of the five launches of the chip-wide form
-        # is paid once, and the single workgroup's 24-84 µs would sit on every replay's critical path
-        wide_in_graph = n > _SELECT_WIDE_IN_GRAPH_MIN and torch.cuda.is_current_stream_capturing()
-        if n <= _SELECT_ONE_WG_MAX and not wide_in_graph:
-            check(hip().evox_hip_select(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), stream_of(keys)), "select")
+        args = (keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr())
+        if route == "registers":
+            check(hip().evox_hip_select_reg(*args, stream_of(keys)), "select_reg")
+        elif route == "one_workgroup":
+            check(hip().evox_hip_select(*args, stream_of(keys)), "select")
         else:
             ws = torch.zeros((int(hip().evox_hip_select_wide_ws(n)) + 3) // 4, dtype=torch.int32, device=keys.device)
-            check(hip().evox_hip_select_wide(keys.data_ptr(), n, k, int(bool(largest)), out.data_ptr(), ws.data_ptr(),
-                                             stream_of(keys)), "select_wide")
+            check(hip().evox_hip_select_wide(*args, ws.data_ptr(), stream_of(keys)), "select_wide")
         return out
     clean = torch.where(torch.isnan(keys), torch.full_like(keys, float("-inf") if largest else float("inf")), keys)
     # stable order: ties at the threshold go to the lower index, as in the kernels

@@ -1127,15 +1127,20 @@ def test_graph_replay_follows_a_wrapping_de_window():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (1000, 50), (4097, 4000), (50000, 2500), (50000, 1), (50000, 50000),
+@pytest.mark.parametrize("n,k", [(1, 1), (5, 5), (1000, 50), (4097, 4000), (8192, 100), (8193, 8000), (16385, 5),
+                                 (33000, 1000), (50000, 2500), (50000, 1), (50000, 50000), (65535, 65535), (65536, 3000),
                                  (262144, 13107), (1000003, 77777)])
 @pytest.mark.parametrize("largest", [False, True])
-@pytest.mark.parametrize("route", ["one_workgroup", "wide"])
+@pytest.mark.parametrize("route", ["registers", "grid", "one_workgroup", "wide"])
 def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch):
     from evox_amd.ops import sort as _sort
 
     if route == "one_workgroup" and n > (1 << 20):
         pytest.skip("the single-workgroup kernel takes at most 2^20 keys")
+    if route == "registers" and n > (1 << 16):
+        pytest.skip("the register-resident kernel takes at most 2^16 keys")
+    if route == "grid" and n > (1 << 18):
+        pytest.skip("the co-operating workgroups take at most 2^18 keys")
     g = torch.Generator().manual_seed(n + k)
     x = torch.randn(n, generator=g)
     if n >= 1000:
@@ -1143,13 +1148,16 @@ def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch
         x[5::501] = float("nan")
         x[11] = float("inf"); x[12] = float("-inf"); x[13] = 0.0; x[14] = -0.0
     want = _sort.select_indices(x, k, largest=largest)       # host formulation (stable sort)
-    monkeypatch.setattr(_sort, "_SELECT_ONE_WG_MAX", (1 << 20) if route == "one_workgroup" else 0)
+    monkeypatch.setattr(_sort, "_SELECT_ROUTE", route)
     got = _sort.select_indices(x.cuda(), k, largest=largest).cpu()
     assert got.shape == (k,)
     assert torch.equal(got, want)
     clustered = (torch.rand(n, generator=g) * 600 + 400).cuda()     # keys that share their leading bits
     got = _sort.select_indices(clustered, k, largest=largest).cpu()
     assert torch.equal(got, _sort.select_indices(clustered.cpu(), k, largest=largest))
+    if route == "grid":
+        got, ws = _sort.select_grid(clustered, k, largest)
+        assert int(ws[1]) == 0                               # no workgroup's wait at a barrier ran out
 
 
 @pytest.mark.gpu
