@@ -1161,6 +1161,30 @@ def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(12000, 600), (50000, 2500), (200000, 50)])
+def test_radix_select_replays_from_a_graph(n, k):
+    """The one-launch selections recorded into a graph (the workspace fill included) give the host result on every
+    replay, with new keys and eager work between the replays."""
+    from evox_amd.ops import sort as _sort
+
+    g = torch.Generator().manual_seed(n)
+    keys = torch.rand(n, generator=g).cuda()
+    _sort.select_indices(keys, k)                            # first use outside the recording
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        top = _sort.select_indices(keys, k)
+    for rep in range(4):
+        fresh = torch.randn(n, generator=g)
+        fresh[::11] = fresh[1]
+        keys.copy_(fresh.cuda())
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(top.cpu(), _sort.select_indices(fresh, k)), rep
+        assert torch.equal(_sort.select_indices(keys, k).cpu(), top.cpu())       # eager work between the replays
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("func", [1, 2, 4, 5])
 @pytest.mark.parametrize("d", [2, 10, 20])
 def test_cec2022_fused_simple_functions(func, d):

@@ -73,7 +73,7 @@ for _ in range(2):
     x3, ok3 = linalg_small.solve_small(torch.rand(3, 3, device=dev) + torch.eye(3, device=dev), torch.ones(3, device=dev))
     zb = _rnd.normal(key, (lam, n), dtype=torch.bfloat16)                    # normal_bf16_kernel
     keys50k = torch.rand(50000, device=dev) * 600 + 400
-    top = sort.select_indices(keys50k, 2500)                                 # select_kernel (one workgroup)
+    top = sort.select_indices(keys50k, 2500)                                 # select_grid_kernel (co-operating workgroups, keys in registers)
     top = sort.select_indices(torch.rand(1000000, device=dev), 50000)        # ms_hist / ms_count / ms_emit kernels
     fz1, _ = problems.numerical.ZDT1(n=30).evaluate(None, torch.rand(100000, 30, device=dev))   # zdt_kernel
     fc1, _ = cec.evaluate(None, pop20)                                       # cec_simple_kernel<20>
