@@ -11,6 +11,12 @@
 // The random numbers are the same Philox elements the PyTorch formulation draws, so both produce the
 // same trial vectors (up to floating-point association).  A row is handled by LPR lanes of a
 // wavefront (coalesced row gathers); the picks are recomputed by each lane - a few dozen integer ops.
+//
+// Blocked populations (`blocks` > 1): a row of the n_pop x (blocks * dim) population is `blocks` independent
+// sub-vectors, each evolving with its own picks, crossover mask, F and CR — the stacked members of a decomposition
+// container.  The kernel then works on virtual rows v = row * blocks + block (the population viewed as
+// (n_pop * blocks) x dim): picks are individuals in [0, n_pop), mapped to the virtual row of the same block; `rows`,
+// F, CR, the pbest rows and the random elements are indexed by the virtual row, lb / ub by block * dim + column.
 #include "hip_common.h"
 #include "philox.h"
 
@@ -33,12 +39,16 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
     const int64_t* __restrict__ best_index, const int64_t* __restrict__ pbest_rows, const float* __restrict__ F, int f_is_vec,
     const float* __restrict__ CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
     const int32_t* __restrict__ row_codes, int n_picks, const int32_t* __restrict__ key_sel, const int32_t* __restrict__ key_jrand, const int32_t* __restrict__ key_mask,
-    const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out) {
+    const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out, int blocks) {
   constexpr int RPB = 256 / LPR;                       // rows per block
   const int sub = threadIdx.x % LPR;
   const int r = blockIdx.x * RPB + threadIdx.x / LPR;
   if (r >= b) return;
-  const int64_t self = rows ? rows[r] : r;
+  const int64_t self_v = rows ? rows[r] : r;           // virtual row: individual * blocks + block
+  const int64_t self = self_v / blocks;
+  const int64_t blk = self_v - self * blocks;
+  lb += blk * dim;
+  ub += blk * dim;
   if (row_codes) {                                     // per-row strategy: (primary, secondary, #differences, crossover)
     prim = row_codes[4 * r]; sec = row_codes[4 * r + 1]; num_diff = row_codes[4 * r + 2]; cross = row_codes[4 * r + 3];
   }
@@ -68,19 +78,19 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
 
   auto base_row = [&](int code) -> const float* {
     switch (code) {
-      case kRand: return pop + (int64_t)picks[0] * ldpop;
-      case kBest: return pop + best_index[0] * ldpop;
-      case kPbest: return pop + pbest_rows[r] * ldpop;
-      default: return pop + self * ldpop;
+      case kRand: return pop + ((int64_t)picks[0] * blocks + blk) * ldpop;
+      case kBest: return pop + (best_index[0] * blocks + blk) * ldpop;
+      case kPbest: return pop + (pbest_rows[r] * blocks + blk) * ldpop;
+      default: return pop + self_v * ldpop;
     }
   };
   const float* p_row = base_row(prim);
   const float* s_row = base_row(sec);
-  const float* cur = pop + self * ldpop;
-  const float* d1a = pop + (int64_t)picks[1] * ldpop;
-  const float* d1b = pop + (int64_t)picks[2] * ldpop;
-  const float* d2a = num_diff > 1 ? pop + (int64_t)picks[3] * ldpop : cur;
-  const float* d2b = num_diff > 1 ? pop + (int64_t)picks[4] * ldpop : cur;
+  const float* cur = pop + self_v * ldpop;
+  const float* d1a = pop + ((int64_t)picks[1] * blocks + blk) * ldpop;
+  const float* d1b = pop + ((int64_t)picks[2] * blocks + blk) * ldpop;
+  const float* d2a = num_diff > 1 ? pop + ((int64_t)picks[3] * blocks + blk) * ldpop : cur;
+  const float* d2b = num_diff > 1 ? pop + ((int64_t)picks[4] * blocks + blk) * ldpop : cur;
 
   for (int c = sub; c < dim; c += LPR) {
     const float p = p_row[c];
@@ -100,12 +110,14 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
 
 }  // namespace
 
+// pop: (n_pop * blocks) virtual rows of `dim` columns, ldpop apart (blocks = 1: the plain population); rows: b virtual rows.
 EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int dim, const int64_t* rows, int b,
                                const int64_t* best_index, const int64_t* pbest_rows, const float* F, int f_is_vec,
                                const float* CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
                                const int32_t* row_codes, int n_picks, const int32_t* key_sel, const int32_t* key_jrand, const int32_t* key_mask, const float* lb,
-                               const float* ub, float* out, void* stream) {
+                               const float* ub, float* out, int blocks, void* stream) {
   if (b <= 0 || dim <= 0) return 0;
+  if (blocks < 1) return (int)hipErrorInvalidValue;
   if (row_codes) num_diff = 2;                          // per-row values are 1 or 2 (checked by the caller)
   if (n_picks > kMaxPicks || n_picks < 2 * num_diff + 1 || num_diff < 1 || num_diff > 2 || n_pop <= n_picks)
     return (int)hipErrorInvalidValue;
@@ -116,7 +128,7 @@ EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int d
   de_trial_kernel<LPR><<<(b + 256 / LPR - 1) / (256 / LPR), 256, 0, s>>>(                                              \
       pop, ldpop, n_pop, dim, rows, b, best_index, pbest_rows, F, f_is_vec, CR, cr_is_vec, prim, sec, num_diff, cross,   \
       row_codes, n_picks,                                                                                              \
-      key_sel, key_jrand, key_mask, lb, ub, out)
+      key_sel, key_jrand, key_mask, lb, ub, out, blocks)
   if (dim <= 8) EVOX_DE_LAUNCH(8);
   else if (dim <= 16) EVOX_DE_LAUNCH(16);
   else if (dim <= 32) EVOX_DE_LAUNCH(32);

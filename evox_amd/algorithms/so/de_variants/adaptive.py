@@ -31,24 +31,31 @@ class JaDE(DEBase):
         self.c = c
         self.num_diff_vects = 1
 
+    # A blocked instance (``DEBase.blocked``) keeps one pair of means per block — ``F_u`` / ``CR_u`` of shape (blocks,) —
+    # and control parameters per virtual row individual * blocks + block; its bookkeeping is the tensor formulation
+    # with a block axis (the fused adaptation kernels handle the single-member layout).
     def setup(self, key):
         dev = self.lb.device
-        return self._base_state(key, F_u=torch.tensor(0.5, device=dev), CR_u=torch.tensor(0.5, device=dev),
-                                F_vect=torch.zeros(self.pop_size, device=dev),
-                                CR_vect=torch.zeros(self.pop_size, device=dev))
+        shape = () if self.blocks == 1 else (self.blocks,)
+        return self._base_state(key, F_u=torch.full(shape, 0.5, device=dev), CR_u=torch.full(shape, 0.5, device=dev),
+                                F_vect=torch.zeros(self.pop_size * self.blocks, device=dev),
+                                CR_vect=torch.zeros(self.pop_size * self.blocks, device=dev))
 
     def _draw_params(self, state, kF, kCR, loc_F, loc_CR):
-        F = torch.clamp(rnd.normal(kF, (self.pop_size,)) * 0.1 + loc_F, 0.0, 1.0)
-        CR = torch.clamp(rnd.cauchy(kCR, (self.pop_size,)) * 0.1 + loc_CR, 0.0, 1.0)
+        n = self.pop_size * self.blocks
+        F = torch.clamp(rnd.normal(kF, (n,)) * 0.1 + loc_F, 0.0, 1.0)
+        CR = torch.clamp(rnd.cauchy(kCR, (n,)) * 0.1 + loc_CR, 0.0, 1.0)
         return F, CR
 
     def _fused_tell_ok(self, state):
         # the fused kernels replace the whole population at once
-        return (_adapt.supported(state.population) and self.batch_size == self.pop_size)
+        return (_adapt.supported(state.population) and self.batch_size == self.pop_size and self.blocks == 1)
 
     def ask(self, state):
         key, k_var, kF, kCR = rnd.split(state.key, 4)
-        if _adapt.supported(state.population):
+        if self.blocks > 1:
+            F, CR = self._draw_params(state, kF, kCR, state.F_u.repeat(self.pop_size), state.CR_u.repeat(self.pop_size))
+        elif _adapt.supported(state.population):
             F, CR = _adapt.draw_params(kF, kF, kCR, state.F_u, state.CR_u, self.pop_size)
         else:
             F, CR = self._draw_params(state, kF, kCR, state.F_u, state.CR_u)
@@ -66,9 +73,15 @@ class JaDE(DEBase):
         population, fitness, best_index, start, ok, _ = self._select(state, state.trial_vectors, trial_fitness)
         okf = ok.to(torch.float32)
         n_ok = okf.sum()
-        sF, sF2 = (okf * state.F_vect).sum(), (okf * state.F_vect ** 2).sum()
+        if self.blocks > 1:
+            # the success mask is shared by the blocks (one fitness), the parameters are per block: sums over individuals
+            Fm, CRm = state.F_vect.reshape(self.pop_size, -1), state.CR_vect.reshape(self.pop_size, -1)
+            sF, sF2 = (okf[:, None] * Fm).sum(0), (okf[:, None] * Fm ** 2).sum(0)
+            mean_cr = (okf[:, None] * CRm).sum(0) / n_ok
+        else:
+            sF, sF2 = (okf * state.F_vect).sum(), (okf * state.F_vect ** 2).sum()
+            mean_cr = (okf * state.CR_vect).sum() / n_ok
         lehmer = sF2 / sF
-        mean_cr = (okf * state.CR_vect).sum() / n_ok
         # with no success the reference's nansum/nanmean give NaN and poison the means; keep
         # the previous means instead
         F_u = torch.where(n_ok > 0, (1 - self.c) * state.F_u + self.c * _nan_to(lehmer), state.F_u)
@@ -93,13 +106,19 @@ class SHADE(JaDE):
 
     def setup(self, key):
         dev = self.lb.device
-        return self._base_state(key, Memory_FCR=torch.full((2, self.H), 0.5, device=dev),
-                                F_vect=torch.zeros(self.pop_size, device=dev),
-                                CR_vect=torch.zeros(self.pop_size, device=dev))
+        shape = (2, self.H) if self.blocks == 1 else (2, self.blocks, self.H)      # a blocked instance: one memory per block
+        return self._base_state(key, Memory_FCR=torch.full(shape, 0.5, device=dev),
+                                F_vect=torch.zeros(self.pop_size * self.blocks, device=dev),
+                                CR_vect=torch.zeros(self.pop_size * self.blocks, device=dev))
 
     def ask(self, state):
         key, k_var, k_slot, kF, kCR = rnd.split(state.key, 5)
-        if _adapt.supported(state.population):
+        if self.blocks > 1:
+            B = self.blocks
+            slot = rnd.randint(k_slot, (self.pop_size * B,), 0, self.H)
+            at = torch.arange(B, device=slot.device).repeat(self.pop_size) * self.H + slot      # (block, slot) of every virtual row
+            F, CR = self._draw_params(state, kF, kCR, state.Memory_FCR[0].reshape(-1)[at], state.Memory_FCR[1].reshape(-1)[at])
+        elif _adapt.supported(state.population):
             F, CR = _adapt.draw_params(k_slot, kF, kCR, state.Memory_FCR[0], state.Memory_FCR[1], self.pop_size)
         else:
             slot = rnd.randint(k_slot, (self.pop_size,), 0, self.H)
@@ -122,6 +141,16 @@ class SHADE(JaDE):
         delta = torch.where(torch.isfinite(delta), delta, torch.zeros_like(delta))
         total = delta.sum()
         w = delta / total
+        if self.blocks > 1:
+            # improvements (hence weights) are shared by the blocks; every block averages its own parameters
+            Fm, CRm = state.F_vect.reshape(self.pop_size, -1), state.CR_vect.reshape(self.pop_size, -1)
+            M_CR = (w[:, None] * CRm).sum(0)
+            M_F = (w[:, None] * Fm ** 2).sum(0) / (w[:, None] * Fm).sum(0)
+            rolled = torch.cat([torch.stack([M_F, M_CR])[:, :, None], state.Memory_FCR[:, :, :-1]], dim=2)
+            valid = (total > 0) & torch.isfinite(M_F) & torch.isfinite(M_CR)
+            memory = torch.where(valid[None, :, None], rolled, state.Memory_FCR)
+            return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
+                                 start_index_dev=self._next_start_dev(state), Memory_FCR=memory)
         M_CR = (w * state.CR_vect).sum()
         M_F = (w * state.F_vect ** 2).sum() / (w * state.F_vect).sum()
         rolled = torch.roll(state.Memory_FCR, 1, dims=1)

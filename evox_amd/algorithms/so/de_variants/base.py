@@ -32,6 +32,27 @@ class DEBase(Algorithm):
         self.dim = self.lb.shape[0]
         self.pop_size = int(pop_size)
         self.batch_size = int(batch_size) if batch_size else self.pop_size
+        self.blocks = 1
+
+    def blocked(self, times: int):
+        """``times`` independent copies of this algorithm, all told the same fitness, as ONE instance over the
+        concatenated decision vector (what a decomposition container runs; the reference vmaps the member,
+        ``src/evox/algorithms/containers/clustered_algorithm.py:10-42``).  A row of the population is ``times``
+        sub-vectors; every sub-vector draws its own parents, crossover mask and control parameters, and keeps its own
+        adaptation memory, while fitness, replacement decisions, the best index and the p-best set — functions of the
+        shared fitness alone — exist once.  A generation costs the launches of one member."""
+        from ....core.module import clone_module
+
+        if self.blocks != 1:
+            raise ValueError("already a blocked instance")
+        wide = clone_module(self)
+        wide.lb, wide.ub = self.lb.repeat(times), self.ub.repeat(times)
+        wide.dim, wide.blocks = self.dim * times, int(times)
+        for name in ("mean", "stdvar"):
+            v = getattr(self, name, None)
+            if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == self.dim:
+                setattr(wide, name, v.repeat(times))
+        return wide
 
     def _init_population(self, key, mean=None, stdvar=None):
         dev = self.lb.device
@@ -109,56 +130,79 @@ class DEBase(Algorithm):
             trial = crossover(v, current; CR)   clipped to the bounds
         """
         from ....operators.crossover.differential_evolution import de_arith_recom, de_bin_cross, de_exp_cross
-        from ....operators.selection.misc import select_rand_pbest
 
         pop, fit = state.population, state.fitness
-        b = idx.shape[0]
         dev = pop.device
         k_sel, k_pb, k_x = rnd.split(key, 3)
+        # Blocked instance: everything below runs over virtual rows (individual, block) -> individual * B + block of
+        # the population viewed as (pop_size * B, block_dim); parents are individuals, taken from the row's own block.
+        B = self.blocks
+        rows_out = idx.shape[0]
+        if B > 1:
+            blk = torch.arange(B, device=dev).repeat(rows_out)
+            who = idx.repeat_interleave(B)                # the individual of every virtual row
+            idx = who * B + blk
+            pop_v = pop.reshape(self.pop_size * B, self.dim // B)
+
+            def rows_of(ind):                             # rows of individuals `ind` (one per virtual row) in the row's block
+                return pop_v[ind * B + (blk if ind.dim() == 1 else blk[:, None])]
+        else:
+            who, pop_v = idx, pop
+
+            def rows_of(ind):
+                return pop_v[ind]
+        b = idx.shape[0]
         # Host-known settings stay on the host: no scalar ever crosses to the device here, so the
         # whole routine is free of synchronisations (and can be recorded into a graph).
         static_nd = isinstance(num_diff, int)
         n_picks = min(diff_padding_num, 2 * num_diff + 1) if static_nd else diff_padding_num
+
+        def pbest_individuals():
+            top = max(int(self.pop_size * 0.05), 1)
+            best = _sort.select_indices(fit, top)              # the p-best set, in index order
+            return best[rnd.randint(k_pb, (b,), 0, top)]
+
+        def finish(trial_v):
+            return torch.clamp(trial_v.reshape(rows_out, self.dim), self.lb, self.ub)
+
         from ....ops import de as _de
         if _de.supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets):
             # GPU: one fused launch (same random elements as the formulation below)
-            pbest_rows = None
-            if not static_nd or PBEST in (prim, sec):
-                top = max(int(self.pop_size * 0.05), 1)
-                best = _sort.select_indices(fit, top)          # the p-best set, in index order
-                pbest_rows = best[rnd.randint(k_pb, (b,), 0, top)]
+            pbest_rows = pbest_individuals() if (not static_nd or PBEST in (prim, sec)) else None
             return _de.de_trial(key, pop, idx, state.best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks,
-                                self.lb, self.ub, cross)
+                                self.lb, self.ub, cross, blocks=B).reshape(rows_out, self.dim)
         if replace:
             picks = rnd.randint(k_sel, (b, n_picks), 0, self.pop_size)
-            picks = torch.where(picks == idx[:, None], torch.full_like(picks, self.pop_size - 1), picks)
+            picks = torch.where(picks == who[:, None], torch.full_like(picks, self.pop_size - 1), picks)
         else:
-            picks = rnd.choice_distinct(k_sel, self.pop_size, b, n_picks, exclude=idx)
+            picks = rnd.choice_distinct(k_sel, self.pop_size, b, n_picks, exclude=who)
         if static_nd:
-            diff = pop[picks[:, 1]] - pop[picks[:, 2]]
+            diff = rows_of(picks[:, 1]) - rows_of(picks[:, 2])
             for t in range(1, num_diff):
-                diff = diff + (pop[picks[:, 2 * t + 1]] - pop[picks[:, 2 * t + 2]])
+                diff = diff + (rows_of(picks[:, 2 * t + 1]) - rows_of(picks[:, 2 * t + 2]))
         else:
             nd = num_diff.to(dev).reshape(-1, 1)
             pos = torch.arange(n_picks, device=dev)[None, :]
             live = (pos >= 1) & (pos < 2 * nd + 1)
             sign = (torch.where(pos % 2 == 1, 1.0, -1.0) * live).to(pop.dtype)
-            diff = torch.einsum("bk,bkd->bd", sign.expand(b, -1), pop[picks])
-        current = pop[idx]
+            diff = torch.einsum("bk,bkd->bd", sign.expand(b, -1), rows_of(picks))
+        current = pop_v[idx]
+
+        def best_rows():
+            return rows_of(state.best_index.expand(b)) if B > 1 else pop[state.best_index].expand(b, -1)
 
         def base_of(code):
             if isinstance(code, int):
                 c = code
                 if c == RAND:
-                    return pop[picks[:, 0]]
+                    return rows_of(picks[:, 0])
                 if c == BEST:
-                    return pop[state.best_index].expand(b, -1)
+                    return best_rows()
                 if c == PBEST:
-                    return select_rand_pbest(k_pb, 0.05, pop, fit, num=b)
+                    return rows_of(pbest_individuals())
                 return current
             code_t = code.to(dev)
-            cands = torch.stack([pop[picks[:, 0]], pop[state.best_index].expand(b, -1),
-                                 select_rand_pbest(k_pb, 0.05, pop, fit, num=b), current], dim=1)
+            cands = torch.stack([rows_of(picks[:, 0]), best_rows(), rows_of(pbest_individuals()), current], dim=1)
             return cands[torch.arange(b, device=dev), code_t]
 
         Fc = F[:, None] if isinstance(F, torch.Tensor) and F.dim() == 1 else F
@@ -179,4 +223,4 @@ class DEBase(Algorithm):
             t_exp = de_exp_cross(ke, mutant, current, CR)
             t_ari = de_arith_recom(mutant, current, CR)
             trial = torch.where((cross_t == BIN)[:, None], t_bin, torch.where((cross_t == EXP)[:, None], t_exp, t_ari))
-        return torch.clamp(trial, self.lb, self.ub)
+        return finish(trial)

@@ -582,15 +582,52 @@ class CMAES(Algorithm):
 
 
 class SepCMAES(CMAES):
-    """Separable CMA-ES: diagonal covariance, O(n) per individual, no eigendecomposition."""
+    """Separable CMA-ES: diagonal covariance, O(n) per individual, no eigendecomposition.
+
+    ``blocked(times)``: ``times`` independent copies told the same fitness as ONE instance over the concatenated vector
+    (what a decomposition container runs; the reference vmaps the member,
+    ``src/evox/algorithms/containers/clustered_algorithm.py:10-42``): mean, paths and variances are simply wider, the
+    step size, the norm of its path and the stall indicator exist once per block, and the learning rates stay those of
+    the member's dimension."""
+
+    blocks = 1
+
+    def blocked(self, times: int):
+        from ....core.module import clone_module
+
+        if self.blocks != 1:
+            raise ValueError("already a blocked instance")
+        wide = clone_module(self)
+        wide.center_init = self.center_init.repeat(times)
+        wide.block_dim, wide.blocks, wide.dim = self.dim, int(times), self.dim * times
+        return wide
+
+    def _wide(self, per_block):
+        """A per-block quantity spread over the block's variables."""
+        return per_block if self.blocks == 1 else per_block.repeat_interleave(self.block_dim)
 
     def setup(self, key):
         dev = self.center_init.device
         return State(pc=torch.zeros(self.dim, device=dev), ps=torch.zeros(self.dim, device=dev),
                      C=torch.ones(self.dim, device=dev), count_iter=0, mean=self.center_init,
                      count_iter_dev=torch.zeros((), device=dev),
-                     sigma=torch.tensor(self.init_stdev, device=dev), key=key.to(dev),
-                     population=torch.empty((self.pop_size, self.dim), device=dev))
+                     sigma=torch.full(() if self.blocks == 1 else (self.blocks,), float(self.init_stdev), device=dev),
+                     key=key.to(dev), population=torch.empty((self.pop_size, self.dim), device=dev))
+
+    def _paths(self, state, mean, order=None):
+        if self.blocks == 1:
+            return super()._paths(state, mean, order)
+        d = self.block_dim
+        sigma_w = self._wide(state.sigma)
+        delta = mean - state.mean
+        z = self._whiten(state, delta) / sigma_w
+        ps = (1 - self.cs) * state.ps + math.sqrt(self.cs * (2 - self.cs) * self.mueff) * z
+        ps_norm = torch.linalg.vector_norm(ps.reshape(self.blocks, d), dim=1)                      # one per block
+        denom = torch.sqrt(1 - (1 - self.cs) ** (2 * state.count_iter_dev))
+        hsig = (ps_norm / denom < (1.4 + 2 / (d + 1)) * self.chiN).to(torch.float32)
+        pc = (1 - self.cc) * state.pc + self._wide(hsig) * math.sqrt(self.cc * (2 - self.cc) * self.mueff) * delta / sigma_w
+        sigma = state.sigma * torch.exp((self.cs / self.damps) * (ps_norm / self.chiN - 1))
+        return ps, pc, self._wide(hsig), sigma
 
     def graph_signature(self, state):
         return ()
@@ -603,7 +640,7 @@ class SepCMAES(CMAES):
         # single-process sample
         from ....ops import es as _es
         noise = _es.noise_rows(sample_key, rows, self.dim, row_offset)
-        return state.mean + state.sigma * torch.sqrt(state.C) * noise
+        return state.mean + self._wide(state.sigma) * torch.sqrt(state.C) * noise
 
     def ask(self, state):
         key, sample_key = rnd.split(state.key)
@@ -626,7 +663,7 @@ class SepCMAES(CMAES):
     def tell(self, state, fitness):
         order = _sort.argsort(fitness)
         d = state.population[order[: self.mu]] - state.mean
-        y = d / state.sigma
+        y = d / self._wide(state.sigma)
         return self._update(state, self.weights @ d, self.weights @ (y * y))
 
     # Row-sharded: 2·dim floats per generation (the two weighted sums), nothing of size dim² anywhere.
@@ -647,7 +684,7 @@ class SepCMAES(CMAES):
         padded = torch.cat([self.weights, self.weights.new_zeros(self.pop_size - self.mu)])
         w_local = padded[ranking[rank * local:(rank + 1) * local]]          # 0 outside the best μ
         d = state.population - state.mean
-        y = d / state.sigma
+        y = d / self._wide(state.sigma)
         packed = dist.all_reduce(torch.cat([w_local @ d, w_local @ (y * y)]))
         return self._update(state, packed[: self.dim], packed[self.dim:])
 

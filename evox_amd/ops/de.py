@@ -11,7 +11,7 @@ from ._util import check, hip, stream_of
 
 P, I, I64 = _native.P, _native.I, _native.I64
 _native.register_hip_api({
-    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P]),
+    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, I, P]),
 })
 
 
@@ -40,11 +40,20 @@ def supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets=None)
             and n_picks >= 5)
 
 
-def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub, cross=BIN):
+def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub, cross=BIN, blocks=1):
     """Trial vectors for the rows ``idx`` of ``pop``; ``key`` is split exactly as the PyTorch path does
     (selection / pbest / crossover → jrand, mask).  ``prim, sec, num_diff, cross`` are ints, or all four
-    per-row integer tensors."""
+    per-row integer tensors.
+
+    ``blocks`` > 1: every row of ``pop`` is ``blocks`` independent sub-vectors (stacked members of a container);
+    ``idx``, ``F``, ``CR`` and ``pbest_rows`` then run over the virtual rows ``individual * blocks + block``
+    (``pbest_rows`` still names individuals), and the result has one row per entry of ``idx``."""
     dev = pop.device
+    if pop.stride(1) != 1 or (blocks > 1 and not pop.is_contiguous()):
+        pop = pop.contiguous()
+    n_pop = pop.shape[0]
+    if blocks > 1:
+        pop = pop.view(n_pop * blocks, pop.shape[1] // blocks)
     b, dim = idx.shape[0], pop.shape[1]
     k_sel, _k_pb, k_x = rnd.split(key, 3)
     per_row = isinstance(prim, torch.Tensor)
@@ -54,16 +63,14 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
         codes = torch.stack([prim, sec, num_diff, cross], dim=1).to(device=dev, dtype=torch.int32).contiguous()
         prim = sec = num_diff = cross = 0
     k_r, k_m = rnd.split(k_x)
-    if pop.stride(1) != 1:
-        pop = pop.contiguous()
     f, f_vec = _vec(F, b, dev)
     cr, cr_vec = _vec(CR, b, dev)
     out = torch.empty((b, dim), dtype=torch.float32, device=dev)
     check(hip().evox_hip_de_trial(
-        pop.data_ptr(), pop.stride(0), pop.shape[0], dim, idx.contiguous().data_ptr(), b,
+        pop.data_ptr(), pop.stride(0), n_pop, dim, idx.contiguous().data_ptr(), b,
         best_index.reshape(1).contiguous().data_ptr(), pbest_rows.contiguous().data_ptr() if pbest_rows is not None else None,
         f.data_ptr(), f_vec, cr.data_ptr(), cr_vec, int(prim), int(sec), int(num_diff), int(cross),
         codes.data_ptr() if per_row else None, int(n_picks),
         k_sel.contiguous().data_ptr(), k_r.contiguous().data_ptr(), k_m.contiguous().data_ptr(),
-        lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), out.data_ptr(), stream_of(pop)), "de_trial")
+        lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), out.data_ptr(), int(blocks), stream_of(pop)), "de_trial")
     return out

@@ -37,8 +37,8 @@ def test_clustered_separable_base_runs_as_one_fused_instance():
         assert pop.shape == (100, 80 if algo.fused else 10)
     assert results["auto"] < 6 and results[False] < 6
     with pytest.raises(TypeError):
-        algorithms.ClusterdAlgorithm(algorithms.SepCMAES(torch.zeros(10), init_stdev=1.0, pop_size=10), dim=40,
-                                     num_cluster=4, fuse=True)
+        algorithms.ClusterdAlgorithm(algorithms.MAES(torch.zeros(10), init_stdev=1.0, pop_size=10), dim=40,
+                                     num_cluster=4, fuse=True)             # neither separable nor available batched
 
 
 @pytest.mark.parametrize("name", ["OpenES", "PGPE", "SNES", "DES", "ARS", "ESMC", "PersistentES", "Noise_reuse_es"])
@@ -107,6 +107,111 @@ def test_batched_cma_es_follows_the_member_update(per_block_fitness):
             brecon = (bstate.B[s] * bstate.D[s] ** 2) @ bstate.B[s].T
             torch.testing.assert_close(brecon, recon, rtol=2e-4, atol=2e-5)
     assert bstate.count_eigen == mstates[0].count_eigen == 3
+
+
+@pytest.mark.parametrize("name", ["DE", "JaDE", "SHADE"])
+def test_blocked_de_family_follows_the_member_update(name):
+    """One blocked instance = B members told the same fitness: given the instance's trial vectors and control
+    parameters block by block, every member's own tell() reproduces the block's population and adaptation memory,
+    generation after generation."""
+    B, d, P = 3, 4, 24
+    lb, ub = torch.linspace(-3, -1, d), torch.linspace(1, 3, d)
+    member = {"DE": lambda: algorithms.DE(lb, ub, P, batch_size=8), "JaDE": lambda: algorithms.JaDE(lb, ub, P),
+              "SHADE": lambda: algorithms.SHADE(lb, ub, P, memory_size=5)}[name]()
+    blocked = member.blocked(B)
+    assert (blocked.blocks, blocked.dim, member.blocks, member.dim) == (B, B * d, 1, d)
+    assert torch.equal(blocked.lb, lb.repeat(B))
+    bstate = blocked.init(ex.PRNGKey(5))
+    mstates = [member.init(ex.PRNGKey(50 + s)).replace(population=bstate.population.reshape(P, B, d)[:, s].clone())
+               for s in range(B)]
+    target = torch.randn(B * d, generator=torch.Generator().manual_seed(1)) * 0.5
+    for gen in range(12):
+        trial, bstate = blocked.ask(bstate)
+        rows = trial.shape[0]
+        assert trial.shape == (8 if name == "DE" else P, B * d)
+        assert bool((trial >= blocked.lb).all() and (trial <= blocked.ub).all())
+        fitness = ((trial - target) ** 2).sum(1)
+        after = blocked.tell(bstate, fitness)
+        for s in range(B):
+            ms = mstates[s].replace(trial_vectors=trial.reshape(rows, B, d)[:, s].clone(), start_index=bstate.start_index,
+                                    start_index_dev=bstate.start_index_dev.clone())
+            if name != "DE":
+                ms = ms.replace(F_vect=bstate.F_vect.reshape(P, B)[:, s].clone(), CR_vect=bstate.CR_vect.reshape(P, B)[:, s].clone())
+            ms = member.tell(ms, fitness)
+            mstates[s] = ms
+            assert torch.equal(after.population.reshape(P, B, d)[:, s], ms.population), (gen, s)
+            assert torch.equal(after.fitness, ms.fitness) and int(after.best_index) == int(ms.best_index)
+            if name == "JaDE":
+                torch.testing.assert_close(after.F_u[s], ms.F_u, rtol=1e-5, atol=1e-6)
+                torch.testing.assert_close(after.CR_u[s], ms.CR_u, rtol=1e-5, atol=1e-6)
+            if name == "SHADE":
+                torch.testing.assert_close(after.Memory_FCR[:, s], ms.Memory_FCR, rtol=1e-5, atol=1e-6)
+        bstate = after
+    if name == "SHADE":
+        mem = bstate.Memory_FCR
+        assert mem.shape == (2, B, 5) and not torch.equal(mem[:, 0], mem[:, 1])      # the blocks adapt on their own
+
+
+def test_blocked_sep_cma_es_follows_the_member_update():
+    """One blocked SepCMAES = B members: fed the instance's candidates block by block and the shared fitness, every
+    member's mean, step size, paths and variances follow the block's."""
+    B, d, P = 3, 5, 14
+    member = algorithms.SepCMAES(torch.linspace(-1, 1, d), 0.8, pop_size=P)
+    blocked = member.blocked(B)
+    assert (blocked.blocks, blocked.dim, blocked.block_dim, member.blocks) == (B, B * d, d, 1)
+    for name in ("cc", "cs", "c1", "cmu", "damps", "chiN", "mueff", "mu"):
+        assert getattr(blocked, name) == getattr(member, name)
+    bstate = blocked.init(ex.PRNGKey(2))
+    mstates = [member.init(ex.PRNGKey(20 + s)) for s in range(B)]
+    target = torch.randn(B * d, generator=torch.Generator().manual_seed(3))
+    for gen in range(15):
+        pop, bstate = blocked.ask(bstate)
+        assert pop.shape == (P, B * d)
+        fitness = ((pop - target) ** 2).sum(1) + 0.1 * torch.sin(5 * pop).sum(1)
+        bstate = blocked.tell(bstate, fitness)
+        for s in range(B):
+            _, ms = member.ask(mstates[s])
+            mstates[s] = ms = member.tell(ms.replace(population=pop.reshape(P, B, d)[:, s].clone()), fitness)
+            for name in ("mean", "ps", "pc", "C"):
+                torch.testing.assert_close(getattr(bstate, name).reshape(B, d)[s], getattr(ms, name), rtol=1e-4, atol=1e-6,
+                                           msg=f"{name} gen {gen}")
+            torch.testing.assert_close(bstate.sigma[s], ms.sigma, rtol=1e-4, atol=1e-7)
+    assert bstate.sigma.shape == (B,) and len({round(float(v), 6) for v in bstate.sigma}) == B
+
+
+def test_blocked_de_draws_parents_per_block():
+    """DE/rand/1 with CR = 1: every block of every trial row is x[r1] + F (x[r2] - x[r3]) of THAT block's sub-vectors,
+    with r1, r2, r3 distinct and different from the row, and the blocks of a row use different parents."""
+    import itertools
+
+    B, d, P, F = 4, 3, 7, 0.5
+    member = algorithms.DE(torch.full((d,), -100.0), torch.full((d,), 100.0), P, differential_weight=F, cross_probability=1.0,
+                           batch_size=P, mean=0.0, stdvar=1.0)              # far inside the bounds: nothing is clipped
+    blocked = member.blocked(B)
+    state = blocked.init(ex.PRNGKey(11))
+    trial, _ = blocked.ask(state)
+    pop = state.population.reshape(P, B, d)
+    found = {}
+    for i in range(P):
+        for s in range(B):
+            hits = [(a, b, c) for a, b, c in itertools.permutations([j for j in range(P) if j != i], 3)
+                    if torch.allclose(pop[a, s] + F * (pop[b, s] - pop[c, s]), trial.reshape(P, B, d)[i, s], rtol=1e-5, atol=1e-4)]
+            assert len(hits) == 1, (i, s, hits)
+            found[i, s] = hits[0]
+    assert any(len({found[i, s] for s in range(B)}) > 1 for i in range(P))
+
+
+@pytest.mark.parametrize("name", ["DE", "SHADE", "SepCMAES"])
+def test_clustered_de_family_runs_as_one_blocked_instance(name):
+    results = {}
+    for fuse in (False, "auto"):
+        lb, ub = torch.full((5,), -10.0), torch.full((5,), 10.0)
+        base = {"DE": lambda: algorithms.DE(lb, ub, 40), "SHADE": lambda: algorithms.SHADE(lb, ub, 40),
+                "SepCMAES": lambda: algorithms.SepCMAES(torch.full((5,), 4.0), 3.0, pop_size=40)}[name]()
+        algo = algorithms.ClusterdAlgorithm(base_algorithm=base, dim=20, num_cluster=4, fuse=fuse)
+        assert len(algo.members) == (1 if fuse == "auto" else 4) and algo.fused == (fuse == "auto")
+        results[fuse], _ = _run(algo, 150, problems.numerical.Sphere())
+    assert results["auto"] < 1.0 and results[False] < 1.0
 
 
 def test_clustered_cma_es_runs_as_one_batched_instance():
@@ -215,7 +320,7 @@ def test_member_loop_container_records_with_its_members_host_counters(base):
             "SepCMAES": lambda: algorithms.SepCMAES(torch.full((5,), 3.0, device=dev), 1.0, pop_size=64)}[base]
     out = {}
     for mode in (False, True):
-        algo = algorithms.ClusterdAlgorithm(make(), dim=40, num_cluster=8)
+        algo = algorithms.ClusterdAlgorithm(make(), dim=40, num_cluster=8, fuse=False)
         assert not algo.fused and len(algo.members) == 8
         wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), graph_step=mode)
         state = wf.init(ex.PRNGKey(7).to(dev))
@@ -226,4 +331,54 @@ def test_member_loop_container_records_with_its_members_host_counters(base):
         out[mode] = (m0.mean if base == "SepCMAES" else m0.population).clone()
         if mode:
             assert wf.graph_replays >= 15
+    assert torch.equal(out[True], out[False])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["DE", "DE_best2", "JaDE", "SHADE"])
+def test_blocked_de_trial_kernel_matches_tensor_formulation(name, monkeypatch):
+    """The fused variation launch over virtual rows (individual, block) draws the same random elements as the tensor
+    formulation of the blocked instance."""
+    from evox_amd.ops import de as de_ops
+
+    dev = torch.device("cuda")
+    B, d, P = 7, 10, 300
+    lb, ub = torch.linspace(-5, -4, d, device=dev), torch.linspace(4, 5, d, device=dev)
+    member = {"DE": lambda: algorithms.DE(lb, ub, P, batch_size=64), "JaDE": lambda: algorithms.JaDE(lb, ub, P),
+              "DE_best2": lambda: algorithms.DE(lb, ub, P, base_vector="best", num_difference_vectors=2),
+              "SHADE": lambda: algorithms.SHADE(lb, ub, P)}[name]()
+    blocked = member.blocked(B)
+    state = blocked.init(ex.PRNGKey(4).to(dev))
+    state = state.replace(fitness=torch.rand(P, device=dev), best_index=torch.tensor(17, device=dev))
+    fused, _ = blocked.ask(state)
+    monkeypatch.setattr(de_ops, "supported", lambda *a, **k: False)
+    plain, _ = blocked.ask(state)
+    assert fused.shape == plain.shape == ({"DE": 64, "DE_best2": 100}.get(name, P), B * d)      # DE varies a window
+    torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-5)
+    assert bool((fused >= blocked.lb).all() and (fused <= blocked.ub).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["DE", "SHADE", "SepCMAES"])
+def test_blocked_container_replays_from_a_graph(name):
+    """ClusterdAlgorithm over a DE-family base is one blocked instance; its recorded generation equals eager issue."""
+    dev = torch.device("cuda")
+    lb, ub = torch.full((10,), -10.0, device=dev), torch.full((10,), 10.0, device=dev)
+    out = {}
+    for mode in (False, True):
+        base = {"DE": lambda: algorithms.DE(lb, ub, 256), "SHADE": lambda: algorithms.SHADE(lb, ub, 256),
+                "SepCMAES": lambda: algorithms.SepCMAES(torch.full((10,), 3.0, device=dev), 2.0, pop_size=256)}[name]()
+        algo = algorithms.ClusterdAlgorithm(base, dim=1000, num_cluster=100)
+        assert algo.fused and len(algo.members) == 1
+        monitor = EvalMonitor()
+        wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), monitors=[monitor], graph_step=mode)
+        state = wf.init(ex.PRNGKey(7).to(dev))
+        for _ in range(40):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        inner = state.get_child_state("algorithm").get_child_state("members").get_child_state("m0000")
+        out[mode] = inner.population.clone()
+        if mode:
+            assert wf.graph_replays >= 25
+        assert inner.population.shape == (256, 1000)
     assert torch.equal(out[True], out[False])

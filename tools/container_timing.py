@@ -1,5 +1,6 @@
-"""Generation time of decomposition containers over bases without a batched or widened form (member loop), eager and
-replayed from a HIP graph.  usage: container_timing.py [num_cluster] [dim] [pop]"""
+"""Generation time of decomposition containers, eager and replayed from a HIP graph: the member loop (fuse=False) and,
+where the base has one, the blocked / batched single instance (fuse="auto").
+usage: container_timing.py [num_cluster] [dim] [pop]"""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,10 +15,11 @@ sub = dim // S
 lb, ub = torch.full((sub,), -10.0, device=dev), torch.full((sub,), 10.0, device=dev)
 for name, make in (("SHADE", lambda: A.SHADE(lb, ub, pop)), ("DE", lambda: A.DE(lb, ub, pop)),
                    ("SepCMAES", lambda: A.SepCMAES(torch.zeros(sub, device=dev), 1.0, pop_size=pop))):
-    row = {"base": name, "num_cluster": S, "dim": dim, "pop": pop}
+  for fuse in (False, "auto"):
+    row = {"base": name, "num_cluster": S, "dim": dim, "pop": pop, "fuse": fuse}
     for mode in (False, True):
         try:
-            algo = A.ClusterdAlgorithm(make(), dim=dim, num_cluster=S)
+            algo = A.ClusterdAlgorithm(make(), dim=dim, num_cluster=S, fuse=fuse)
             wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), graph_step=mode, graph_mode="ring")
             s = wf.init(ex.PRNGKey(1).to(dev))
             for _ in range(12):
