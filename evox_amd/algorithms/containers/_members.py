@@ -37,19 +37,19 @@ def member_tell(member, state, fitness, first):
 def batch(base, times: int, concat: bool = True):
     """``times`` copies of ``base`` as ONE algorithm whose state carries a leading block axis, or None when no batched
     form of the algorithm exists.  Plain :class:`~evox_amd.algorithms.so.es_variants.cma_es.CMAES` (exact class, fp32,
-    eigendecomposition mode) has one: :class:`~evox_amd.algorithms.so.es_variants.batched_cma.BatchedCMAES`; DE, JaDE,
-    SHADE and SepCMAES (exact classes) have one for blocks that share their fitness (``concat=True``):
+    eigendecomposition mode) has one: :class:`~evox_amd.algorithms.so.es_variants.batched_cma.BatchedCMAES`; DE, ODE,
+    JaDE, SHADE, CoDE and SepCMAES (exact classes) have one for blocks that share their fitness (``concat=True``):
     ``DEBase.blocked`` — every block draws its own parents, masks and control parameters and keeps its own adaptation
     memory in one pass over the concatenated population —, ``SepCMAES.blocked`` — one step size and path norm per
     block."""
-    from ..so.de_variants.adaptive import SHADE, JaDE
-    from ..so.de_variants.de import DE
+    from ..so.de_variants.adaptive import SHADE, CoDE, JaDE
+    from ..so.de_variants.de import DE, ODE
     from ..so.es_variants.batched_cma import BatchedCMAES
     from ..so.es_variants.cma_es import CMAES, SepCMAES
 
     if type(base) is CMAES and base.decomposition == "eigh" and base.precision == "fp32":
         return BatchedCMAES.of(base, times, concat)
-    if type(base) in (DE, JaDE, SHADE, SepCMAES) and concat and base.blocks == 1:
+    if type(base) in (DE, ODE, JaDE, SHADE, CoDE, SepCMAES) and concat and base.blocks == 1:
         return base.blocked(times)
     return None
 

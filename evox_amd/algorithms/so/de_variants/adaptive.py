@@ -269,7 +269,8 @@ class CoDE(DEBase):
         key, k_var, k_par = rnd.split(state.key, 3)
         idx = self._window(state)
         keys = rnd.split(k_var, 3)
-        pid = rnd.randint(k_par, (3, self.batch_size), 0, self.param_pool.shape[0])
+        # one parameter pair per trial vector — of a blocked instance: per block of every trial vector
+        pid = rnd.randint(k_par, (3, self.batch_size * self.blocks), 0, self.param_pool.shape[0])
         trials = []
         for s, (prim, sec, nd, cross) in enumerate(self.strategies):
             par = self.param_pool[pid[s]]

@@ -61,8 +61,14 @@ class ODE(DE):
         if self.base_vector == "best":
             base = state.population[state.best_index].expand(idx.shape[0], -1)
         else:
-            pick = rnd.choice_distinct(k_var, self.pop_size, idx.shape[0], 1, exclude=idx)[:, 0]
-            base = state.population[pick]
+            B = self.blocks
+            who = idx.repeat_interleave(B) if B > 1 else idx
+            pick = rnd.choice_distinct(k_var, self.pop_size, who.shape[0], 1, exclude=who)[:, 0]
+            if B > 1:                                       # a blocked instance: one random individual per (row, block)
+                blk = torch.arange(B, device=pick.device).repeat(idx.shape[0])
+                base = state.population.reshape(self.pop_size * B, -1)[pick * B + blk].reshape(idx.shape[0], self.dim)
+            else:
+                base = state.population[pick]
         trial = self.ub + self.lb - base
         return trial, state.replace(trial_vectors=trial, key=key)
 

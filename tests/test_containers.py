@@ -109,7 +109,7 @@ def test_batched_cma_es_follows_the_member_update(per_block_fitness):
     assert bstate.count_eigen == mstates[0].count_eigen == 3
 
 
-@pytest.mark.parametrize("name", ["DE", "JaDE", "SHADE"])
+@pytest.mark.parametrize("name", ["DE", "ODE", "JaDE", "SHADE", "CoDE"])
 def test_blocked_de_family_follows_the_member_update(name):
     """One blocked instance = B members told the same fitness: given the instance's trial vectors and control
     parameters block by block, every member's own tell() reproduces the block's population and adaptation memory,
@@ -117,6 +117,7 @@ def test_blocked_de_family_follows_the_member_update(name):
     B, d, P = 3, 4, 24
     lb, ub = torch.linspace(-3, -1, d), torch.linspace(1, 3, d)
     member = {"DE": lambda: algorithms.DE(lb, ub, P, batch_size=8), "JaDE": lambda: algorithms.JaDE(lb, ub, P),
+              "ODE": lambda: algorithms.ODE(lb, ub, P, batch_size=8), "CoDE": lambda: algorithms.CoDE(lb, ub, P),
               "SHADE": lambda: algorithms.SHADE(lb, ub, P, memory_size=5)}[name]()
     blocked = member.blocked(B)
     assert (blocked.blocks, blocked.dim, member.blocks, member.dim) == (B, B * d, 1, d)
@@ -128,14 +129,21 @@ def test_blocked_de_family_follows_the_member_update(name):
     for gen in range(12):
         trial, bstate = blocked.ask(bstate)
         rows = trial.shape[0]
-        assert trial.shape == (8 if name == "DE" else P, B * d)
+        assert trial.shape == ({"DE": 8, "ODE": 8, "CoDE": 3 * P}.get(name, P), B * d)
         assert bool((trial >= blocked.lb).all() and (trial <= blocked.ub).all())
+        if name == "ODE" and gen % 2 == 1:                # opposition generation: every block mirrors an individual of its own
+            mirrored = (blocked.ub + blocked.lb - trial).reshape(rows, B, d)
+            blocks_pop = bstate.population.reshape(P, B, d)
+            for s in range(B):
+                assert all(bool(torch.isclose(blocks_pop[:, s], mirrored[r, s], atol=1e-5).all(1).any()) for r in range(rows))
         fitness = ((trial - target) ** 2).sum(1)
         after = blocked.tell(bstate, fitness)
         for s in range(B):
             ms = mstates[s].replace(trial_vectors=trial.reshape(rows, B, d)[:, s].clone(), start_index=bstate.start_index,
                                     start_index_dev=bstate.start_index_dev.clone())
-            if name != "DE":
+            if name == "ODE":
+                ms = ms.replace(counter=bstate.counter)
+            if name in ("JaDE", "SHADE"):
                 ms = ms.replace(F_vect=bstate.F_vect.reshape(P, B)[:, s].clone(), CR_vect=bstate.CR_vect.reshape(P, B)[:, s].clone())
             ms = member.tell(ms, fitness)
             mstates[s] = ms
@@ -335,7 +343,7 @@ def test_member_loop_container_records_with_its_members_host_counters(base):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["DE", "DE_best2", "JaDE", "SHADE"])
+@pytest.mark.parametrize("name", ["DE", "DE_best2", "JaDE", "SHADE", "CoDE"])
 def test_blocked_de_trial_kernel_matches_tensor_formulation(name, monkeypatch):
     """The fused variation launch over virtual rows (individual, block) draws the same random elements as the tensor
     formulation of the blocked instance."""
@@ -346,14 +354,14 @@ def test_blocked_de_trial_kernel_matches_tensor_formulation(name, monkeypatch):
     lb, ub = torch.linspace(-5, -4, d, device=dev), torch.linspace(4, 5, d, device=dev)
     member = {"DE": lambda: algorithms.DE(lb, ub, P, batch_size=64), "JaDE": lambda: algorithms.JaDE(lb, ub, P),
               "DE_best2": lambda: algorithms.DE(lb, ub, P, base_vector="best", num_difference_vectors=2),
-              "SHADE": lambda: algorithms.SHADE(lb, ub, P)}[name]()
+              "CoDE": lambda: algorithms.CoDE(lb, ub, P), "SHADE": lambda: algorithms.SHADE(lb, ub, P)}[name]()
     blocked = member.blocked(B)
     state = blocked.init(ex.PRNGKey(4).to(dev))
     state = state.replace(fitness=torch.rand(P, device=dev), best_index=torch.tensor(17, device=dev))
     fused, _ = blocked.ask(state)
     monkeypatch.setattr(de_ops, "supported", lambda *a, **k: False)
     plain, _ = blocked.ask(state)
-    assert fused.shape == plain.shape == ({"DE": 64, "DE_best2": 100}.get(name, P), B * d)      # DE varies a window
+    assert fused.shape == plain.shape == ({"DE": 64, "DE_best2": 100, "CoDE": 3 * P}.get(name, P), B * d)      # DE varies a window
     torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-5)
     assert bool((fused >= blocked.lb).all() and (fused <= blocked.ub).all())
 
