@@ -118,7 +118,7 @@ def _rank_sort(keys: torch.Tensor, want_rank: bool, form: str = None):
 # Time per call (µs, back-to-back on one stream) at 10 000 / 50 000 / 262 144 keys: one workgroup with the keys in
 # registers 15 / 53 / -, one launch of co-operating workgroups (with the fill of its workspace) 22 / 24 / 29, one
 # workgroup re-reading the keys 22 / 76 / 327, the five-launch form 42 / 44 / 52, the library's top-k 37 / 50 / 122
-# (tools/select_timing.py).  SHADE at 50 000 individuals under graph replay: 0.163 -> 0.144 ms per generation.
+# (tools/select_timing.py).  SHADE at 50 000 individuals under graph replay (island workflow): 0.163 -> 0.144 ms per generation.
 _SELECT_REG_MAX = 1 << 14
 _SELECT_ROUTE = None                   # tests: force "registers" / "grid" / "one_workgroup" / "wide"
 
