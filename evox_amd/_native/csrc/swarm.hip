@@ -156,3 +156,131 @@ EVOX_API int evox_hip_cso_step(const int32_t* key, const float* pop, const float
       key, pop, vel, fit, perm, center, phi, lb, ub, half, dim, new_pop, new_vel, cand, students);
   return last_launch_status();
 }
+
+// The move shared by the swarm variants (CLPSO, SL-PSO, DMS-PSO-EL, small-world PSO, FS-PSO's elite half): up to three
+// attractors, each a table row chosen per particle, each weighted by a constant and a Philox uniform,
+//     v' = s_i * ( a * u0 * v  +  sum_k (c_k * u_k) * (T_k[row_k(i)][c] - x) ),   x' = clip(x + v'),
+// u_k = element offset_k + i * dim + c of the stream of key_k (the layout of the tensor formulation's draws; a null
+// key stands for the factor 1), row_k(i) = i, index_k[i] or 0 (one row for all), s_i an optional per-particle factor
+// (constriction).  One launch in place of the dozen elementwise launches of the tensor formulation, same random numbers.
+namespace {
+
+constexpr int kMaxAttract = 3;
+
+struct AttractTerm {
+  const float* table;
+  const int64_t* index;
+  const int32_t* key;
+  long long offset;
+  int mode;                                            // 0: row i, 1: row index[i], 2: row 0
+  float coef;
+};
+
+struct Attract {
+  const float* x; const float* v; const float* lb; const float* ub; const float* row_scale;
+  float* ox; float* ov;
+  const int32_t* inertia_key;
+  long long inertia_offset;
+  long long n;
+  int dim, nterms;
+  float inertia;
+  AttractTerm t[kMaxAttract];
+};
+
+__device__ __forceinline__ float unit_at(const int32_t* key, uint64_t e) {
+  const u32x4 blk = philox_block((uint32_t)key[0], (uint32_t)key[1], e >> 2, kStreamDraw);
+  return bits_to_unit(lane_of(blk, (int)(e & 3)));
+}
+
+__global__ __launch_bounds__(256) void swarm_attract_kernel(Attract a) {
+  const int64_t total = a.n * (int64_t)a.dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / a.dim;
+    const int c = (int)(e - r * a.dim);
+    const float x = a.x[e];
+    float w = a.inertia;
+    if (a.inertia_key) w = w * unit_at(a.inertia_key, (uint64_t)(a.inertia_offset + e));
+    float nv = w * a.v[e];
+#pragma unroll
+    for (int k = 0; k < kMaxAttract; ++k) {
+      if (k < a.nterms) {
+        const AttractTerm& t = a.t[k];
+        const int64_t row = t.mode == 0 ? r : (t.mode == 1 ? t.index[r] : 0);
+        float f = t.coef;
+        if (t.key) f = f * unit_at(t.key, (uint64_t)(t.offset + e));
+        nv = nv + f * (t.table[row * a.dim + c] - x);
+      }
+    }
+    if (a.row_scale) nv = a.row_scale[r] * nv;
+    a.ov[e] = nv;
+    a.ox[e] = fminf(fmaxf(x + nv, a.lb[c]), a.ub[c]);
+  }
+}
+
+}  // namespace
+
+// terms: nterms records of (table, index, key, offset, mode, coef) given as parallel arrays.
+EVOX_API int evox_hip_swarm_attract(const float* x, const float* v, const float* lb, const float* ub, const float* row_scale,
+                                    float* ox, float* ov, int64_t n, int dim, float inertia, const int32_t* inertia_key,
+                                    int64_t inertia_offset, int nterms, const void* const* tables, const void* const* indices,
+                                    const void* const* keys, const int64_t* offsets, const int* modes, const float* coefs,
+                                    void* stream) {
+  if (n <= 0 || dim <= 0) return 0;
+  if (nterms < 0 || nterms > kMaxAttract) return (int)hipErrorInvalidValue;
+  Attract a{};
+  a.x = x; a.v = v; a.lb = lb; a.ub = ub; a.row_scale = row_scale; a.ox = ox; a.ov = ov;
+  a.inertia_key = inertia_key; a.inertia_offset = inertia_offset; a.n = n; a.dim = dim; a.nterms = nterms; a.inertia = inertia;
+  for (int k = 0; k < nterms; ++k) {
+    if (tables[k] == nullptr || modes[k] < 0 || modes[k] > 2 || (modes[k] == 1 && indices[k] == nullptr))
+      return (int)hipErrorInvalidValue;
+    a.t[k].table = (const float*)tables[k];
+    a.t[k].index = (const int64_t*)indices[k];
+    a.t[k].key = (const int32_t*)keys[k];
+    a.t[k].offset = offsets[k];
+    a.t[k].mode = modes[k];
+    a.t[k].coef = coefs[k];
+  }
+  swarm_attract_kernel<<<stream_grid(n * (int64_t)dim, 256), 256, 0, (hipStream_t)stream>>>(a);
+  return last_launch_status();
+}
+
+// Fully informed particle swarm: a particle is drawn to the randomly weighted centroid of its neighbours' personal bests,
+//     pm = sum_k (w_ik * phi_ik) * pbest[nbr_ik][c] / sum_k (w_ik * phi_ik),   phi_ik = u * max_phi * mask_ik,
+//     v' = chi_i * (v + phi_i * (pm - x)),   x' = clip(x + v'),
+// u = element (i * K + k) * dim + c of the key's uniform stream (the (n, K, dim) draw of the tensor formulation).
+namespace {
+__global__ __launch_bounds__(256) void fips_move_kernel(const int32_t* __restrict__ key, const float* __restrict__ x,
+                                                        const float* __restrict__ v, const float* __restrict__ pbest,
+                                                        const int64_t* __restrict__ nbr, const float* __restrict__ mask,
+                                                        const float* __restrict__ w, const float* __restrict__ chi,
+                                                        const float* __restrict__ phi, const float* __restrict__ lb,
+                                                        const float* __restrict__ ub, float* __restrict__ ox,
+                                                        float* __restrict__ ov, int64_t n, int K, int dim, float max_phi) {
+  const int64_t total = n * (int64_t)dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / dim;
+    const int c = (int)(e - i * dim);
+    float num = 0.f, den = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float ph = unit_at(key, (uint64_t)((i * K + k) * dim + c)) * max_phi * mask[i * K + k];
+      const float wp = w[i * K + k] * ph;
+      num += pbest[nbr[i * K + k] * dim + c] * wp;
+      den += wp;
+    }
+    const float xv = x[e];
+    const float nv = chi[i] * (v[e] + phi[i] * (num / den - xv));
+    ov[e] = nv;
+    ox[e] = fminf(fmaxf(xv + nv, lb[c]), ub[c]);
+  }
+}
+}  // namespace
+
+EVOX_API int evox_hip_fips_move(const int32_t* key, const float* x, const float* v, const float* pbest, const int64_t* nbr,
+                                const float* mask, const float* w, const float* chi, const float* phi, const float* lb,
+                                const float* ub, float* ox, float* ov, int64_t n, int K, int dim, float max_phi, void* stream) {
+  if (n <= 0 || dim <= 0) return 0;
+  if (K <= 0) return (int)hipErrorInvalidValue;
+  fips_move_kernel<<<stream_grid(n * (int64_t)dim, 256), 256, 0, (hipStream_t)stream>>>(key, x, v, pbest, nbr, mask, w, chi, phi,
+                                                                                       lb, ub, ox, ov, n, K, dim, max_phi);
+  return last_launch_status();
+}

@@ -11,6 +11,7 @@ import torch
 from ....core import random as rnd
 from ....core.algorithm import Algorithm
 from ....core.state import State
+from ....ops import swarm as _swarm
 from . import topology_utils as topo
 from .utils import get_distance_matrix, init_swarm, update_bests
 
@@ -28,6 +29,11 @@ class _SwarmBase(Algorithm):
 
     def _inf(self, n=None):
         return torch.full((self.pop_size if n is None else n,), float("inf"), device=self.lb.device)
+
+    def _fused(self, state, *coefficients):
+        """The velocity / position move runs as one launch (``ops.swarm.attract``) on the GPU when every coefficient is a
+        host number; the tensor formulation next to each call is the host path and the oracle of the kernel's tests."""
+        return _swarm.attract_supported(state.population) and all(isinstance(c, (int, float)) for c in coefficients)
 
 
 class CLPSO(_SwarmBase):
@@ -55,9 +61,15 @@ class CLPSO(_SwarmBase):
         exemplar = torch.where(pbest_fit[r1] < pbest_fit[r2], r1, r2)
         learn = rnd.uniform(k_p, (n,)) < self.P_c
         # as in the reference, the exemplar position is read from the previous personal bests
-        target = torch.where(learn[:, None], state.pbest_position[exemplar], state.pbest_position)
-        vel = self.w * state.velocity + self.c * rnd.uniform(k_c, (n, self.dim)) * (target - state.population)
-        pop = torch.clamp(state.population + vel, self.lb, self.ub)
+        if self._fused(state, self.w, self.c):
+            # one launch: the particle's attractor is a row of the previous personal bests, its own or the exemplar's
+            rows = torch.where(learn, exemplar, torch.arange(n, device=exemplar.device))
+            pop, vel = _swarm.attract(state.population, state.velocity, self.lb, self.ub,
+                                      [(state.pbest_position, rows, self.c, k_c, 0)], inertia=self.w)
+        else:
+            target = torch.where(learn[:, None], state.pbest_position[exemplar], state.pbest_position)
+            vel = self.w * state.velocity + self.c * rnd.uniform(k_c, (n, self.dim)) * (target - state.population)
+            pop = torch.clamp(state.population + vel, self.lb, self.ub)
         return state.replace(population=pop, velocity=vel, pbest_position=pbest, pbest_fitness=pbest_fit,
                              gbest_position=gbest, gbest_fitness=gbest_fit, key=key)
 
@@ -83,14 +95,22 @@ class _SLPSO(_SwarmBase):
     def tell(self, state, fitness):
         key, k_r, k_d = rnd.split(state.key, 3)
         n = self.pop_size
-        r = rnd.uniform(k_r, (3, n, self.dim))
         best_fit, i = torch.min(fitness, dim=0)               # 0-d tensors; no index is read back to the host
         take = best_fit < state.global_best_fitness.reshape(())
         gbest = torch.where(take, state.population.index_select(0, i.reshape(1))[0], state.global_best_location)
         gfit = torch.where(take, best_fit, state.global_best_fitness.reshape(())).reshape(1)
-        ranked = state.population[torch.argsort(fitness, descending=True, stable=True)]
-        x_k = ranked[self._demonstrator_index(k_d)]
+        order = torch.argsort(fitness, descending=True, stable=True)
         x_avg = state.population.mean(0)
+        if self._fused(state, self.social_influence_factor):
+            nd = n * self.dim                                   # the three factors are consecutive (n, dim) draws of k_r
+            pop, vel = _swarm.attract(state.population, state.velocity, self.lb, self.ub,
+                                      [(state.population, order[self._demonstrator_index(k_d)], 1.0, k_r, nd),
+                                       (x_avg, "all", self.social_influence_factor, k_r, 2 * nd)],
+                                      inertia=1.0, inertia_key=k_r, inertia_offset=0)
+            return state.replace(population=pop, velocity=vel, global_best_location=gbest, global_best_fitness=gfit,
+                                 key=key)
+        r = rnd.uniform(k_r, (3, n, self.dim))
+        x_k = state.population[order][self._demonstrator_index(k_d)]
         vel = r[0] * state.velocity + r[1] * (x_k - state.population) \
             + r[2] * self.social_influence_factor * (x_avg - state.population)
         pop = torch.clamp(state.population + vel, self.lb, self.ub)
@@ -188,6 +208,21 @@ class DMSPSOEL(_SwarmBase):
         dyn_fit = fitness[:nd].reshape(ns, ss)
         lbest_fit, lbest_i = dyn_fit.min(1)
         lbest = dyn_pos[torch.arange(ns, device=dyn_pos.device), lbest_i]
+        if self._fused(state, self.w, self.c_pbest, self.c_lbest, self.c_rbest):
+            # two launches: the dynamic swarms follow their own and their swarm's best, the followers their own and a
+            # regroup-time elite; both write their rows of the new swarm
+            x, v = state.population, state.velocity
+            pop, vel = torch.empty_like(x), torch.empty_like(v)
+            swarm_of = torch.arange(nd, device=x.device) // ss
+            _swarm.attract(x[:nd], v[:nd], self.lb, self.ub,
+                           [(pbest[:nd], None, self.c_pbest, k_p, 0), (lbest, swarm_of, self.c_lbest, k_l, 0)],
+                           inertia=self.w, out=(pop[:nd], vel[:nd]))
+            if self.following_sub_swarm_size > 0:
+                _swarm.attract(x[nd:], v[nd:], self.lb, self.ub,
+                               [(pbest[nd:], None, self.c_pbest, k_p, nd * self.dim), (x, state.rbest_index, self.c_rbest, k_r, 0)],
+                               inertia=self.w, out=(pop[nd:], vel[nd:]))
+            return state.replace(iteration=state.iteration + 1, population=pop, velocity=vel, pbest_position=pbest,
+                                 pbest_fitness=pbest_fit, lbest_position=lbest, lbest_fitness=lbest_fit, key=key)
         rbest = state.population[state.rbest_index]
         rp = rnd.uniform(k_p, (self.pop_size, self.dim))
         dyn_vel = self.w * state.velocity[:nd].reshape(ns, ss, self.dim) \
@@ -209,9 +244,14 @@ class DMSPSOEL(_SwarmBase):
         g = torch.argmin(pbest_fit).reshape(1)              # gathered on the device: no index read-back
         gbest, gfit = pbest.index_select(0, g)[0], pbest_fit.index_select(0, g)[0]
         shape = (self.pop_size, self.dim)
-        vel = self.w * state.velocity + self.c_pbest * rnd.uniform(k_p, shape) * (pbest - state.population) \
-            + self.c_gbest * rnd.uniform(k_g, shape) * (gbest - state.population)
-        pop = torch.clamp(state.population + vel, self.lb, self.ub)
+        if self._fused(state, self.w, self.c_pbest, self.c_gbest):
+            pop, vel = _swarm.attract(state.population, state.velocity, self.lb, self.ub,
+                                      [(pbest, None, self.c_pbest, k_p, 0), (gbest, "all", self.c_gbest, k_g, 0)],
+                                      inertia=self.w)
+        else:
+            vel = self.w * state.velocity + self.c_pbest * rnd.uniform(k_p, shape) * (pbest - state.population) \
+                + self.c_gbest * rnd.uniform(k_g, shape) * (gbest - state.population)
+            pop = torch.clamp(state.population + vel, self.lb, self.ub)
         return state.replace(iteration=state.iteration + 1, population=pop, velocity=vel, pbest_position=pbest,
                              pbest_fitness=pbest_fit, gbest_position=gbest, gbest_fitness=gfit, key=key)
 
@@ -267,11 +307,15 @@ class FIPS(_SwarmBase):
             w = torch.linalg.vector_norm(lbest[nbr] - lbest[:, None, :], dim=-1)
         else:
             raise ValueError(self.weight_type)
-        phik = rnd.uniform(k_phi, (n, k, self.dim)) * self.max_phi * mask[:, :, None].to(torch.float32)
-        wphi = w[:, :, None] * phik
-        pm = (lbest[nbr] * wphi).sum(1) / wphi.sum(1)
-        vel = state.chi * (state.velocity + state.phi * (pm - state.population))
-        pop = torch.clamp(state.population + vel, self.lb, self.ub)
+        if self._fused(state, self.max_phi):
+            pop, vel = _swarm.fips_move(k_phi, state.population, state.velocity, lbest, nbr, mask, w, state.chi, state.phi,
+                                        self.lb, self.ub, self.max_phi)
+        else:
+            phik = rnd.uniform(k_phi, (n, k, self.dim)) * self.max_phi * mask[:, :, None].to(torch.float32)
+            wphi = w[:, :, None] * phik
+            pm = (lbest[nbr] * wphi).sum(1) / wphi.sum(1)
+            vel = state.chi * (state.velocity + state.phi * (pm - state.population))
+            pop = torch.clamp(state.population + vel, self.lb, self.ub)
         return state.replace(population=pop, velocity=vel, local_best_location=lbest, local_best_fitness=lbest_fit,
                              key=key)
 
@@ -303,16 +347,21 @@ class SwmmPSO(_SwarmBase):
     def tell(self, state, fitness):
         key, k1, k2 = rnd.split(state.key, 3)
         shape = (self.pop_size, self.dim)
-        phi1 = rnd.uniform(k1, shape) * self.max_phi_1
-        phi2 = rnd.uniform(k2, shape) * self.max_phi_2
         better = fitness < state.local_best_fitness
         lbest = torch.where(better[:, None], state.population, state.local_best_location)
         lbest_fit = torch.minimum(state.local_best_fitness, fitness)
         nbr = state.adjacancy_list
         nbest_fit, nbest_i = topo.get_neighbour_best_fitness(lbest_fit, nbr)
         nbest = lbest[nbest_i]
-        vel = state.chi * (state.velocity + phi1 * (lbest - state.population) + phi2 * (nbest - state.population))
-        pop = torch.clamp(state.population + vel, self.lb, self.ub)
+        if self._fused(state, self.max_phi_1, self.max_phi_2):
+            pop, vel = _swarm.attract(state.population, state.velocity, self.lb, self.ub,
+                                      [(lbest, None, self.max_phi_1, k1, 0), (lbest, nbest_i.reshape(-1), self.max_phi_2, k2, 0)],
+                                      inertia=1.0, row_scale=state.chi)
+        else:
+            phi1 = rnd.uniform(k1, shape) * self.max_phi_1
+            phi2 = rnd.uniform(k2, shape) * self.max_phi_2
+            vel = state.chi * (state.velocity + phi1 * (lbest - state.population) + phi2 * (nbest - state.population))
+            pop = torch.clamp(state.population + vel, self.lb, self.ub)
         return state.replace(population=pop, velocity=vel, local_best_location=lbest, local_best_fitness=lbest_fit,
                              neighbour_best_location=nbest, neighbour_best_fitness=nbest_fit, key=key)
 
@@ -342,11 +391,16 @@ class FSPSO(_SwarmBase):
         elite = torch.argsort(fitness, stable=True)[:half]
         e_pop, e_vel, e_fit = state.population[elite], state.velocity[elite], fitness[elite]
         e_lb, e_lbfit = state.local_best_location[elite], state.local_best_fitness[elite]
-        r = rnd.uniform(k_r, (2, half, self.dim))
         lbest, lbest_fit, gbest, gfit = update_bests(e_pop, e_fit, e_lb, e_lbfit, state.global_best_location,
                                                      state.global_best_fitness)
-        new_vel = self.w * e_vel + self.phi_p * r[0] * (e_lb - e_pop) + self.phi_g * r[1] * (gbest - e_pop)
-        new_pop = torch.clamp(e_pop + new_vel, self.lb, self.ub)
+        if self._fused(state, self.w, self.phi_p, self.phi_g):
+            new_pop, new_vel = _swarm.attract(e_pop, e_vel, self.lb, self.ub,
+                                              [(e_lb, None, self.phi_p, k_r, 0), (gbest, "all", self.phi_g, k_r, half * self.dim)],
+                                              inertia=self.w)
+        else:
+            r = rnd.uniform(k_r, (2, half, self.dim))
+            new_vel = self.w * e_vel + self.phi_p * r[0] * (e_lb - e_pop) + self.phi_g * r[1] * (gbest - e_pop)
+            new_pop = torch.clamp(e_pop + new_vel, self.lb, self.ub)
         t = rnd.randint(k_t, (2, rest), 0, half)
         pool = torch.where(e_fit[t[0]] < e_fit[t[1]], t[0], t[1])
         base = e_pop[pool]

@@ -1161,6 +1161,50 @@ def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["CLPSO", "SLPSOGS", "SLPSOUS", "DMSPSOEL", "FIPS", "FIPS_pbest", "SwmmPSO", "FSPSO"])
+def test_swarm_variant_fused_move_matches_tensor_formulation(name, monkeypatch):
+    """The one-launch velocity / position move of the swarm variants (``swarm_attract_kernel``, ``fips_move_kernel``)
+    draws the same random factors as the tensor formulation: both tell() from the same state agree, generation after
+    generation (DMS-PSO-EL: regrouping generations, plain multi-swarm generations and the final global phase)."""
+    import evox_amd as ex
+    from evox_amd import algorithms as A
+    from evox_amd.ops import swarm as swarm_ops
+
+    dev = torch.device("cuda")
+    d, n = 37, 300
+    lb, ub = torch.full((d,), -10.0, device=dev), torch.full((d,), 10.0, device=dev)
+    algo = {"CLPSO": lambda: A.CLPSO(lb, ub, n, 0.5, 1.5, torch.full((n,), 0.2, device=dev)),
+            "SLPSOGS": lambda: A.SLPSOGS(lb, ub, n, 0.2, 0.7), "SLPSOUS": lambda: A.SLPSOUS(lb, ub, n, 0.2, 0.7),
+            "DMSPSOEL": lambda: A.DMSPSOEL(lb, ub, 10, 24, 60, 3, 10, 0.7, 1.5, 1.5, 1.0, 1.0),
+            "FIPS": lambda: A.FIPS(lb, ub, 256), "FIPS_pbest": lambda: A.FIPS(lb, ub, 256, topology="Ring", weight_type="Pbest"),
+            "SwmmPSO": lambda: A.SwmmPSO(lb, ub, n, shortcut=5), "FSPSO": lambda: A.FSPSO(lb, ub, n + 1)}[name]()
+    state = algo.init(ex.PRNGKey(21).to(dev))
+    calls = {"fused": 0}
+    real_attract, real_fips = swarm_ops.attract, swarm_ops.fips_move
+
+    def counted(fn):
+        def wrapper(*a, **k):
+            calls["fused"] += 1
+            return fn(*a, **k)
+        return wrapper
+
+    monkeypatch.setattr(swarm_ops, "attract", counted(real_attract))
+    monkeypatch.setattr(swarm_ops, "fips_move", counted(real_fips))
+    for gen in range(12):
+        pop, state = algo.ask(state)
+        fit = (pop ** 2).sum(1) + 3.0 * torch.sin(pop).sum(1) + 50.0
+        fused = algo.tell(state, fit)
+        with monkeypatch.context() as m:
+            m.setattr(swarm_ops, "attract_supported", lambda x: False)
+            plain = algo.tell(state, fit)
+        for field in ("population", "velocity"):
+            torch.testing.assert_close(getattr(fused, field), getattr(plain, field), rtol=2e-5, atol=2e-5, msg=f"{field} gen {gen}")
+        assert bool((fused.population >= lb).all() and (fused.population <= ub).all())
+        state = fused
+    assert calls["fused"] >= 12
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(12000, 600), (50000, 2500), (200000, 50)])
 def test_radix_select_replays_from_a_graph(n, k):
     """The one-launch selections recorded into a graph (the workspace fill included) give the host result on every
