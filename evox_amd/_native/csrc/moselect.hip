@@ -424,6 +424,106 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_packed_kernel(const u
   }
 }
 
+// The packed sort over SEVERAL workgroups.  One workgroup is bound by the instruction issue of its compute unit
+// (2·10⁸ compare-swaps at n = 20 000); the systolic schedule — logical thread t runs sweep s at macro step t + 2s, reading
+// the carry of t−1 and the first entry of t+1 from the step before — lets information travel one thread per step, so a
+// window of 1024 logical threads computes its middle 1024 − 2·halo threads EXACTLY for `halo` steps without hearing
+// from outside (the outer threads go stale one per step from each end, and are discarded).  Every launch advances all
+// windows by up to `halo` macro steps: a workgroup loads its window (owned threads plus a halo of the neighbours'
+// state), steps, and stores its owned threads into the OTHER state buffer, which the next launch reads.  The overlap costs
+// 2·halo / 1024 redundant work and buys ⌈threads / own⌉ compute units instead of one; the launch boundary is the only
+// synchronisation between workgroups.  State per logical thread: its B entries and the element it last carried out
+// (its first entry, which the left neighbour reads, is x[0]).  Same coins, same schedule, same permutation.
+template <int B, bool FRESH>
+__global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
+    const uint32_t* __restrict__ src_x, int n_src, const uint32_t* __restrict__ src_c, uint32_t* __restrict__ dst_x, int n_dst,
+    uint32_t* __restrict__ dst_c, const float* __restrict__ u, float pc, int n, const int32_t* __restrict__ seed_ptr,
+    const float* __restrict__ pc_dev, int step0, int nsteps, int halo) {
+  static_assert(B % 4 == 0, "coin groups hold four positions");
+  if (pc_dev) pc = *pc_dev;
+  constexpr int T = 1024;
+  __shared__ uint32_t c_w[T], f_w[T];
+  const int own = T - 2 * halo;
+  // local index l: threads of equal parity share wavefronts; the window starts at an even logical thread
+  const int l = 2 * ((threadIdx.x >> 7) * 64 + (threadIdx.x & 63)) + ((threadIdx.x >> 6) & 1);
+  const int t = (int)blockIdx.x * own - halo + l;
+  const int threads = (n + B - 1) / B;
+  const bool real = t >= 0 && t < threads;
+  uint32_t x[B];
+  uint32_t offs[FRESH ? 1 : B];
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    const int p = t * B + q;
+    x[q] = real && p < n_src ? src_x[p] : 0u;
+    if constexpr (!FRESH) offs[q] = real && p < n - 1 && u[p] < pc ? 16u : 0u;
+  }
+  const uint32_t seed = FRESH ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
+  c_w[l] = real && src_c ? src_c[t] : 0u;
+  f_w[l] = x[0];
+  __syncthreads();
+  const int sweeps = (n + 1) / 2;
+  for (int step = step0; step < step0 + nsteps; ++step) {
+    const int d = step - t;
+    if (real && d >= 0 && !(d & 1) && (d >> 1) < sweeps) {
+      uint32_t a = t == 0 ? x[0] : (l > 0 ? c_w[l - 1] : 0u);
+      const uint32_t nx = (t == threads - 1 || l == T - 1) ? 0u : f_w[l + 1];
+      uint32_t masks[B / 4];
+      if constexpr (FRESH) {
+#pragma unroll
+        for (int w = 0; w < B / 4; ++w)
+          masks[w] = sr_coin_mask(sr_coin_group(seed, (uint32_t)(d >> 1), (uint32_t)(t * (B / 4) + w)), pc7);
+      }
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const uint32_t b = q + 1 < B ? x[q + 1] : nx;
+        const uint32_t off = FRESH ? (masks[q >> 2] >> (8 * (q & 3) + 3)) & 16u : offs[q];
+        const bool lt = __builtin_amdgcn_ubfe(a, off, 16u) < __builtin_amdgcn_ubfe(b, off, 16u);
+        x[q] = lt ? b : a;
+        a = lt ? a : b;
+      }
+      c_w[l] = a;
+      f_w[l] = x[0];
+    }
+    __syncthreads();
+  }
+  if (real && l >= halo && l < halo + own) {
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      const int p = t * B + q;
+      if (p < n_dst) dst_x[p] = x[q];
+    }
+    if (dst_c) dst_c[t] = c_w[l];
+  }
+}
+
+// ws: 2 * (threads * B + threads) words, threads = ceil(n / B); halo: even, 2 * halo < 1024.
+template <int B>
+int launch_ranking_window(const uint32_t* packed, const float* u, float pc, int n, uint32_t* out, const int32_t* seed,
+                          const float* pc_dev, uint32_t* ws, int halo, hipStream_t st) {
+  const int threads = (n + B - 1) / B, own = 1024 - 2 * halo, groups = (threads + own - 1) / own;
+  const int cap = threads * B;
+  uint32_t* xs[2] = {ws, ws + cap};
+  uint32_t* cs[2] = {ws + 2 * cap, ws + 2 * cap + threads};
+  const int steps = threads + 2 * ((n + 1) / 2);
+  int cur = 0;
+  for (int step0 = 0; step0 < steps; step0 += halo) {
+    const int nsteps = steps - step0 < halo ? steps - step0 : halo;
+    const bool first = step0 == 0, last = step0 + halo >= steps;
+    const uint32_t* sx = first ? packed : xs[cur];
+    const uint32_t* sc = first ? nullptr : cs[cur];
+    uint32_t* dx = last ? out : xs[cur ^ 1];
+    uint32_t* dc = last ? nullptr : cs[cur ^ 1];
+    if (seed)
+      stochastic_ranking_window_kernel<B, true><<<groups, 1024, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
+                                                                        seed, pc_dev, step0, nsteps, halo);
+    else
+      stochastic_ranking_window_kernel<B, false><<<groups, 1024, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
+                                                                         seed, pc_dev, step0, nsteps, halo);
+    cur ^= 1;
+  }
+  return last_launch_status();
+}
+
 template <int B>
 int launch_ranking_packed(const uint32_t* packed, const float* u, float pc, int n, uint32_t* out, const int32_t* seed,
                           const float* pc_dev, hipStream_t st) {
@@ -677,6 +777,24 @@ EVOX_API int evox_hip_stochastic_ranking_packed(const uint32_t* packed, const fl
   if (n <= 1024 * 8) return launch_ranking_packed<8>(packed, u, pc, n, out, seed, pc_dev, st);
   if (n <= 1024 * 16) return launch_ranking_packed<16>(packed, u, pc, n, out, seed, pc_dev, st);
   return launch_ranking_packed<24>(packed, u, pc, n, out, seed, pc_dev, st);
+}
+
+// The packed ranking over several workgroups (see stochastic_ranking_window_kernel): a chain of launches, each advancing
+// every window by `halo` macro steps.  ws: evox_hip_stochastic_ranking_window_ws(n) words of scratch (any content).
+EVOX_API int64_t evox_hip_stochastic_ranking_window_ws(int n) {
+  const int threads = (n + 3) / 4;                       // the finer of the two block sizes
+  return 2 * ((int64_t)threads * 4 + 4 + threads);
+}
+
+// block: entries per logical thread, 4 or 8.
+EVOX_API int evox_hip_stochastic_ranking_window(const uint32_t* packed, const float* u, const int32_t* seed, float pc,
+                                                const float* pc_dev, int n, uint32_t* out, uint32_t* ws, int halo, int block,
+                                                void* stream) {
+  if (n <= 1 || n > 65535 || packed == nullptr || out == nullptr || ws == nullptr || (u == nullptr && seed == nullptr))
+    return (int)hipErrorInvalidValue;
+  if (halo < 2 || (halo & 1) || 2 * halo >= 1024 || (block != 4 && block != 8)) return (int)hipErrorInvalidValue;
+  if (block == 4) return launch_ranking_window<4>(packed, u, pc, n, out, seed, pc_dev, ws, halo, (hipStream_t)stream);
+  return launch_ranking_window<8>(packed, u, pc, n, out, seed, pc_dev, ws, halo, (hipStream_t)stream);
 }
 
 // MOEA/D replacement as a scatter: entry e = (row, slot) offers values[e] to sub-problem target[e]; a sub-problem takes

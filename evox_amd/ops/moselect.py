@@ -29,6 +29,8 @@ _native.register_hip_api({
     "evox_hip_stochastic_ranking_fresh": (I, [P, P, P, F, I, P, P, P]),
     "evox_hip_stochastic_ranking_fresh_dev": (I, [P, P, P, P, I, P, P, P]),
     "evox_hip_stochastic_ranking_packed": (I, [P, P, P, F, P, I, P, P]),
+    "evox_hip_stochastic_ranking_window_ws": (_native.I64, [I]),
+    "evox_hip_stochastic_ranking_window": (I, [P, P, P, F, P, I, P, P, I, I, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
@@ -451,15 +453,34 @@ def _stochastic_ranking_packed(I1, I2, u, pc, seed, pc_dev):
     n = I1.shape[0]
     packed = (_dense_ranks(I1) << 16) | _dense_ranks(I2)
     out = torch.empty(n, dtype=torch.int32, device=I1.device)
-    check(hip().evox_hip_stochastic_ranking_packed(packed.data_ptr(), u.data_ptr() if u is not None else None,
-                                                   seed.data_ptr() if seed is not None else None, float(pc) if pc_dev is None else 0.5,
-                                                   pc_dev.data_ptr() if pc_dev is not None else None, n, out.data_ptr(),
-                                                   stream_of(I1)), "stochastic_ranking_packed")
+    args = (packed.data_ptr(), u.data_ptr() if u is not None else None, seed.data_ptr() if seed is not None else None,
+            float(pc) if pc_dev is None else 0.5, pc_dev.data_ptr() if pc_dev is not None else None, n, out.data_ptr())
+    halo = _ranking_window_halo(n)
+    if halo:
+        # several workgroups, each stepping a window of the systolic schedule; one launch per `halo` macro steps
+        ws = torch.empty(int(hip().evox_hip_stochastic_ranking_window_ws(n)), dtype=torch.int32, device=I1.device)
+        import os
+        check(hip().evox_hip_stochastic_ranking_window(*args, ws.data_ptr(), halo, int(os.environ.get("EVOX_AMD_SRA_WINDOW_BLOCK", "4")),
+                                                       stream_of(I1)), "stochastic_ranking_window")
+    else:
+        check(hip().evox_hip_stochastic_ranking_packed(*args, stream_of(I1)), "stochastic_ranking_packed")
     by_word = _sort.radix_argsort(packed, bits=(0, 32))            # elements, by word then index
     positions = _sort.radix_argsort(out, bits=(0, 32))             # final positions, by word then position
     rank = torch.empty(n, dtype=torch.int64, device=I1.device)
     rank[positions] = by_word
     return rank
+
+
+def _ranking_window_halo(n: int) -> int:
+    """Halo width of the multi-workgroup form of the packed sort, 0 for the single workgroup (``EVOX_AMD_SRA_WINDOW``: a
+    halo width, or 0 to switch the form off; ``EVOX_AMD_SRA_WINDOW_BLOCK``: 4 or 8 entries per logical thread).  Below
+    8192 entries the windows would be too few to pay for their overlap.  20 000 entries, one coin per comparison: 30.8 ms
+    in one workgroup, 15.7 ms in windows of 8-entry threads, 11.0 ms with 4-entry threads (ten workgroups, halo 256;
+    halo 128: 11.5, halo 384: 10.8 — `profiles/sra_rank_timing_n20000.jsonl`)."""
+    import os
+
+    halo = int(os.environ.get("EVOX_AMD_SRA_WINDOW", "256"))
+    return halo if n >= 8192 and halo > 0 else 0
 
 
 def _packed_ranking_applies(I1) -> bool:

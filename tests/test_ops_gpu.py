@@ -1807,7 +1807,7 @@ def test_stochastic_ranking_with_fresh_coins_equals_host_twin(cuda, n):
     assert torch.equal(got_dev, got)
 
 
-@pytest.mark.parametrize("n", [4100, 9000, 20000])
+@pytest.mark.parametrize("n", [4100, 8192, 9000, 20000, 24575])
 def test_stochastic_ranking_on_packed_ranks_handles_equal_elements(cuda, n, monkeypatch):
     """Long permutations are sorted on one-word entries (both keys replaced by dense ranks): with many elements whose
     two keys are BOTH equal — indistinguishable to the sort, recovered by occurrence order — and with -0 / +0 and
@@ -1825,12 +1825,15 @@ def test_stochastic_ranking_on_packed_ranks_handles_equal_elements(cuda, n, monk
     u = torch.rand(n, generator=g)
     ref_fresh = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
     ref_pos = moselect.stochastic_ranking(I1, I2, u, 0.45)
-    for packed in ("1", "0"):
+    # packed words in several workgroups (windows with halos of two widths), in one workgroup, three-word entries
+    for packed, window, block in (("1", "256", "4"), ("1", "130", "8"), ("1", "384", "4"), ("1", "0", "4"), ("0", "0", "4")):
         monkeypatch.setenv("EVOX_AMD_SRA_PACKED", packed)
+        monkeypatch.setenv("EVOX_AMD_SRA_WINDOW", window)
+        monkeypatch.setenv("EVOX_AMD_SRA_WINDOW_BLOCK", block)
         got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), None, 0.47, seed=seed.to(cuda))
-        assert torch.equal(got.cpu(), ref_fresh), packed
+        assert torch.equal(got.cpu(), ref_fresh), (packed, window, block)
         got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), u.to(cuda), 0.45)
-        assert torch.equal(got.cpu(), ref_pos), packed
+        assert torch.equal(got.cpu(), ref_pos), (packed, window, block)
 
 
 @pytest.mark.parametrize("n,mu", [(1000, 5632), (64, 128), (260, 300)])

@@ -1,4 +1,4 @@
-"""Time of SRA's stochastic ranking at n keys: three-word entries against packed one-word entries, one coin per position
+"""Time of SRA's stochastic ranking at n keys: three-word entries against packed one-word entries in one workgroup and in windows over several workgroups, one coin per position
 against one per comparison.  usage: sra_rank_timing.py [n]"""
 import json, os, sys, time
 import torch
@@ -10,8 +10,11 @@ dev = torch.device("cuda")
 g = torch.Generator().manual_seed(1)
 I1, I2, u = (torch.rand(n, generator=g).to(dev) for _ in range(3))
 seed = torch.tensor([5], dtype=torch.int32, device=dev)
-for packed in ("0", "1"):
+for packed, window, block in (("0", "0", "8"), ("1", "0", "8"), ("1", "128", "8"), ("1", "256", "8"), ("1", "384", "8"),
+                              ("1", "128", "4"), ("1", "256", "4"), ("1", "384", "4")):
     os.environ["EVOX_AMD_SRA_PACKED"] = packed
+    os.environ["EVOX_AMD_SRA_WINDOW"] = window
+    os.environ["EVOX_AMD_SRA_WINDOW_BLOCK"] = block
     for coins in ("per_position", "per_comparison"):
         f = (lambda: moselect.stochastic_ranking(I1, I2, u, 0.45)) if coins == "per_position" else \
             (lambda: moselect.stochastic_ranking(I1, I2, None, 0.45, seed=seed))
@@ -20,4 +23,4 @@ for packed in ("0", "1"):
         for _ in range(3):
             f()
         torch.cuda.synchronize()
-        print(json.dumps({"n": n, "packed": packed == "1", "coins": coins, "ms": (time.perf_counter() - t0) / 3 * 1e3}), flush=True)
+        print(json.dumps({"n": n, "packed": packed == "1", "window_halo": int(window), "block": int(block), "coins": coins, "ms": (time.perf_counter() - t0) / 3 * 1e3}), flush=True)
