@@ -446,6 +446,9 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
   const int own = T - 2 * halo;
   // local index l: threads of equal parity share wavefronts; the window starts at an even logical thread
   const int l = 2 * ((threadIdx.x >> 7) * 64 + (threadIdx.x & 63)) + ((threadIdx.x >> 6) & 1);
+  // LDS slot of local thread i: the lanes of a wave hold every second thread, so the two parities are kept in separate
+  // halves and a wave's reads of its neighbours' words are consecutive (no bank conflicts)
+  auto slot = [](int i) { return (i & 1) * (T / 2) + (i >> 1); };
   const int t = (int)blockIdx.x * own - halo + l;
   const int threads = (n + B - 1) / B;
   const bool real = t >= 0 && t < threads;
@@ -458,15 +461,15 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
     if constexpr (!FRESH) offs[q] = real && p < n - 1 && u[p] < pc ? 16u : 0u;
   }
   const uint32_t seed = FRESH ? (uint32_t)*seed_ptr : 0u, pc7 = sr_pc7(pc);
-  c_w[l] = real && src_c ? src_c[t] : 0u;
-  f_w[l] = x[0];
+  c_w[slot(l)] = real && src_c ? src_c[t] : 0u;
+  f_w[slot(l)] = x[0];
   __syncthreads();
   const int sweeps = (n + 1) / 2;
   for (int step = step0; step < step0 + nsteps; ++step) {
     const int d = step - t;
     if (real && d >= 0 && !(d & 1) && (d >> 1) < sweeps) {
-      uint32_t a = t == 0 ? x[0] : (l > 0 ? c_w[l - 1] : 0u);
-      const uint32_t nx = (t == threads - 1 || l == T - 1) ? 0u : f_w[l + 1];
+      uint32_t a = t == 0 ? x[0] : (l > 0 ? c_w[slot(l - 1)] : 0u);
+      const uint32_t nx = (t == threads - 1 || l == T - 1) ? 0u : f_w[slot(l + 1)];
       uint32_t masks[B / 4];
       if constexpr (FRESH) {
 #pragma unroll
@@ -481,8 +484,8 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
         x[q] = lt ? b : a;
         a = lt ? a : b;
       }
-      c_w[l] = a;
-      f_w[l] = x[0];
+      c_w[slot(l)] = a;
+      f_w[slot(l)] = x[0];
     }
     __syncthreads();
   }
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
       const int p = t * B + q;
       if (p < n_dst) dst_x[p] = x[q];
     }
-    if (dst_c) dst_c[t] = c_w[l];
+    if (dst_c) dst_c[t] = c_w[slot(l)];
   }
 }
 

@@ -127,5 +127,34 @@ from evox_amd.ops import _nds_hip as _nh
 for _ in range(2):
     r2d = _nh.rank(torch.rand(20000, 2, device=dev), 10000)                               # nds2_scan_kernel
     kp2 = moselect.knee_suppress(front, torch.randperm(20000, device=dev), torch.full((3,), 0.01, device=dev))   # knee_state / knee_tail
+# selection with the keys in registers, the blocked DE launch, the swarm moves, the windowed stochastic ranking, the
+# one-workgroup factorisations and the physics steps
+from evox_amd import algorithms as _AL
+from evox_amd.ops import linalg_small as _ls, swarm as _sw
+from evox_amd.problems.neuroevolution.reinforcement_learning.tensor_env import make_tensor_env
+for _ in range(2):
+    top = sort.select_indices(torch.rand(12000, device=dev), 600)                         # select_reg_kernel
+    top = sort.select_indices(torch.rand(50000, device=dev), 2500)                        # select_grid_kernel
+    shade = _AL.SHADE(torch.full((10,), -5.0, device=dev), torch.full((10,), 5.0, device=dev), 256).blocked(100)
+    sst = shade.init(rnd.PRNGKey(3).to(dev))
+    tr, sst = shade.ask(sst)                                                              # de_trial_kernel, 100 blocks
+    xs, vs = torch.rand(1024, 100, device=dev), torch.rand(1024, 100, device=dev)
+    lo, hi = torch.zeros(100, device=dev), torch.ones(100, device=dev)
+    nx, nv = _sw.attract(xs, vs, lo, hi, [(xs, torch.randint(0, 1024, (1024,), device=dev), 1.5, key, 0),
+                                          (xs.mean(0), "all", 0.2, key, 102400)], inertia=0.6)      # swarm_attract_kernel
+    nbr = torch.randint(0, 1024, (1024, 5), device=dev)
+    nx, nv = _sw.fips_move(key, xs, vs, xs, nbr, torch.ones(1024, 5, device=dev), torch.rand(1024, 5, device=dev) + 0.1,
+                           torch.full((1024,), 0.73, device=dev), torch.full((1024,), 4.1, device=dev), lo, hi, 4.1)   # fips_move_kernel
+    rk4 = moselect.stochastic_ranking(torch.rand(20000, device=dev), torch.rand(20000, device=dev), None, 0.45,
+                                      seed=torch.tensor([9], dtype=torch.int32, device=dev))       # stochastic_ranking_window_kernel
+    A100 = torch.randn(100, 100, device=dev); C100 = A100 @ A100.T / 100 + 0.1 * torch.eye(100, device=dev)
+    ev, V = _ls.eigh_small(C100, None, spd=True)                                          # cholesky_lds + eigh_spd_kernel
+    ev, V = _ls.eigh_small(C100 * 1.01, V, spd=True)                                      # warm start
+    for task in ("hopper", "ant"):
+        env = make_tensor_env(task)
+        est, ob = env.reset(rnd.PRNGKey(5).to(dev), 4096, dev)
+        tot, dn = torch.zeros(4096, device=dev), torch.zeros(4096, dtype=torch.bool, device=dev)
+        for _ in range(3):
+            est, ob, tot, dn = env.step_accumulate(est, torch.rand(4096, env.act_dim, device=dev) * 2 - 1, tot, dn)   # planar_step / spatial_step kernels
 torch.cuda.synchronize()
 print("done")
