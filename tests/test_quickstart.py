@@ -42,7 +42,7 @@ def test_examples_run():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
-    for name in ("pso_ackley.py", "cmaes_multi_gpu.py", "island_shade.py"):       # the last two as single processes
+    for name in ("pso_ackley.py", "cmaes_multi_gpu.py", "island_shade.py", "clustered_shade.py"):       # multi-process ones as single processes
         out = subprocess.run([sys.executable, os.path.join(root, "examples", name)], env=env, capture_output=True, text=True,
                              timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
