@@ -11,11 +11,11 @@ from evox_amd import algorithms, monitors, problems, workflows
 
 device = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
 block = 10
-member = algorithms.SHADE(torch.full((block,), -5.12, device=device), torch.full((block,), 5.12, device=device), pop_size=100)
+member = algorithms.SHADE(torch.full((block,), -32.0, device=device), torch.full((block,), 32.0, device=device), pop_size=100)
 algorithm = algorithms.ClusterdAlgorithm(member, dim=200, num_cluster=20)
 monitor = monitors.EvalMonitor()
 # a generation is a dozen short launches: replayed from a HIP graph on the GPU (ignored on the CPU)
-workflow = workflows.StdWorkflow(algorithm, problems.numerical.Rastrigin(), monitors=[monitor], graph_step="auto")
+workflow = workflows.StdWorkflow(algorithm, problems.numerical.Ackley(), monitors=[monitor], graph_step="auto")
 state = workflow.init(ex.PRNGKey(5).to(device))
 for _ in range(300):
     state = workflow.step(state)
