@@ -434,14 +434,13 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_packed_kernel(const u
 // 2·halo / 1024 redundant work and buys ⌈threads / own⌉ compute units instead of one; the launch boundary is the only
 // synchronisation between workgroups.  State per logical thread: its B entries and the element it last carried out
 // (its first entry, which the left neighbour reads, is x[0]).  Same coins, same schedule, same permutation.
-template <int B, bool FRESH>
-__global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
+template <int B, bool FRESH, int T>
+__global__ __launch_bounds__(T) void stochastic_ranking_window_kernel(
     const uint32_t* __restrict__ src_x, int n_src, const uint32_t* __restrict__ src_c, uint32_t* __restrict__ dst_x, int n_dst,
     uint32_t* __restrict__ dst_c, const float* __restrict__ u, float pc, int n, const int32_t* __restrict__ seed_ptr,
     const float* __restrict__ pc_dev, int step0, int nsteps, int halo) {
   static_assert(B % 4 == 0, "coin groups hold four positions");
   if (pc_dev) pc = *pc_dev;
-  constexpr int T = 1024;
   __shared__ uint32_t c_w[T], f_w[T];
   const int own = T - 2 * halo;
   // local index l: threads of equal parity share wavefronts; the window starts at an even logical thread
@@ -499,11 +498,11 @@ __global__ __launch_bounds__(1024) void stochastic_ranking_window_kernel(
   }
 }
 
-// ws: 2 * (threads * B + threads) words, threads = ceil(n / B); halo: even, 2 * halo < 1024.
-template <int B>
+// ws: 2 * (threads * B + threads) words, threads = ceil(n / B); T: logical threads per window; halo: even, 2 * halo < T.
+template <int B, int T>
 int launch_ranking_window(const uint32_t* packed, const float* u, float pc, int n, uint32_t* out, const int32_t* seed,
                           const float* pc_dev, uint32_t* ws, int halo, hipStream_t st) {
-  const int threads = (n + B - 1) / B, own = 1024 - 2 * halo, groups = (threads + own - 1) / own;
+  const int threads = (n + B - 1) / B, own = T - 2 * halo, groups = (threads + own - 1) / own;
   const int cap = threads * B;
   uint32_t* xs[2] = {ws, ws + cap};
   uint32_t* cs[2] = {ws + 2 * cap, ws + 2 * cap + threads};
@@ -517,10 +516,10 @@ int launch_ranking_window(const uint32_t* packed, const float* u, float pc, int 
     uint32_t* dx = last ? out : xs[cur ^ 1];
     uint32_t* dc = last ? nullptr : cs[cur ^ 1];
     if (seed)
-      stochastic_ranking_window_kernel<B, true><<<groups, 1024, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
+      stochastic_ranking_window_kernel<B, true, T><<<groups, T, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
                                                                         seed, pc_dev, step0, nsteps, halo);
     else
-      stochastic_ranking_window_kernel<B, false><<<groups, 1024, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
+      stochastic_ranking_window_kernel<B, false, T><<<groups, T, 0, st>>>(sx, first ? n : cap, sc, dx, last ? n : cap, dc, u, pc, n,
                                                                          seed, pc_dev, step0, nsteps, halo);
     cur ^= 1;
   }
@@ -789,15 +788,26 @@ EVOX_API int64_t evox_hip_stochastic_ranking_window_ws(int n) {
   return 2 * ((int64_t)threads * 4 + 4 + threads);
 }
 
-// block: entries per logical thread, 4 or 8.
+// block: entries per logical thread, 4 or 8; window: logical threads per workgroup, 256, 512 or 1024 (2 * halo < window).
 EVOX_API int evox_hip_stochastic_ranking_window(const uint32_t* packed, const float* u, const int32_t* seed, float pc,
                                                 const float* pc_dev, int n, uint32_t* out, uint32_t* ws, int halo, int block,
-                                                void* stream) {
+                                                int window, void* stream) {
   if (n <= 1 || n > 65535 || packed == nullptr || out == nullptr || ws == nullptr || (u == nullptr && seed == nullptr))
     return (int)hipErrorInvalidValue;
-  if (halo < 2 || (halo & 1) || 2 * halo >= 1024 || (block != 4 && block != 8)) return (int)hipErrorInvalidValue;
-  if (block == 4) return launch_ranking_window<4>(packed, u, pc, n, out, seed, pc_dev, ws, halo, (hipStream_t)stream);
-  return launch_ranking_window<8>(packed, u, pc, n, out, seed, pc_dev, ws, halo, (hipStream_t)stream);
+  if ((window != 256 && window != 512 && window != 1024) || halo < 2 || (halo & 1) || 2 * halo >= window ||
+      (block != 4 && block != 8))
+    return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (window == 256) {
+    if (block == 4) return launch_ranking_window<4, 256>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
+    return launch_ranking_window<8, 256>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
+  }
+  if (window == 512) {
+    if (block == 4) return launch_ranking_window<4, 512>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
+    return launch_ranking_window<8, 512>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
+  }
+  if (block == 4) return launch_ranking_window<4, 1024>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
+  return launch_ranking_window<8, 1024>(packed, u, pc, n, out, seed, pc_dev, ws, halo, st);
 }
 
 // MOEA/D replacement as a scatter: entry e = (row, slot) offers values[e] to sub-problem target[e]; a sub-problem takes

@@ -30,7 +30,7 @@ _native.register_hip_api({
     "evox_hip_stochastic_ranking_fresh_dev": (I, [P, P, P, P, I, P, P, P]),
     "evox_hip_stochastic_ranking_packed": (I, [P, P, P, F, P, I, P, P]),
     "evox_hip_stochastic_ranking_window_ws": (_native.I64, [I]),
-    "evox_hip_stochastic_ranking_window": (I, [P, P, P, F, P, I, P, P, I, I, P]),
+    "evox_hip_stochastic_ranking_window": (I, [P, P, P, F, P, I, P, P, I, I, I, P]),
     "evox_hip_spea2_fitness": (I, [P, I, I, P, P, P, P]),
     "evox_hip_crowd_remove": (I, [P, I, I, P, P, P, P]),
     "evox_hip_ibea_fitness": (I, [P, I, I, F, P, P, P]),
@@ -461,7 +461,7 @@ def _stochastic_ranking_packed(I1, I2, u, pc, seed, pc_dev):
         ws = torch.empty(int(hip().evox_hip_stochastic_ranking_window_ws(n)), dtype=torch.int32, device=I1.device)
         import os
         check(hip().evox_hip_stochastic_ranking_window(*args, ws.data_ptr(), halo, int(os.environ.get("EVOX_AMD_SRA_WINDOW_BLOCK", "4")),
-                                                       stream_of(I1)), "stochastic_ranking_window")
+                                                       int(os.environ.get("EVOX_AMD_SRA_WINDOW_THREADS", "256")), stream_of(I1)), "stochastic_ranking_window")
     else:
         check(hip().evox_hip_stochastic_ranking_packed(*args, stream_of(I1)), "stochastic_ranking_packed")
     by_word = _sort.radix_argsort(packed, bits=(0, 32))            # elements, by word then index
@@ -473,13 +473,16 @@ def _stochastic_ranking_packed(I1, I2, u, pc, seed, pc_dev):
 
 def _ranking_window_halo(n: int) -> int:
     """Halo width of the multi-workgroup form of the packed sort, 0 for the single workgroup (``EVOX_AMD_SRA_WINDOW``: a
-    halo width, or 0 to switch the form off; ``EVOX_AMD_SRA_WINDOW_BLOCK``: 4 or 8 entries per logical thread).  Below
-    8192 entries the windows would be too few to pay for their overlap.  20 000 entries, one coin per comparison: 30.8 ms
-    in one workgroup, 15.7 ms in windows of 8-entry threads, 11.0 ms with 4-entry threads (ten workgroups, halo 256;
-    halo 128: 11.5, halo 384: 10.8 — `profiles/sra_rank_timing_n20000.jsonl`)."""
+    halo width, or 0 to switch the form off; ``EVOX_AMD_SRA_WINDOW_THREADS``: 256, 512 or 1024 logical threads per window;
+    ``EVOX_AMD_SRA_WINDOW_BLOCK``: 4 or 8 entries per logical thread).  Below 8192 entries the windows would be too few
+    to pay for their overlap.  A macro step costs a workgroup barrier, so small windows win although they repeat more
+    work and need more launches — 20 000 entries, one coin per comparison: 30.9 ms in one workgroup; windows of 1024
+    threads (halo 256) 10.7 ms, of 512 threads (halo 128) 7.7 ms, of 256 threads (halo 96: 79 workgroups, 261 launches,
+    three quarters of the work redundant) 6.5 ms; 8-entry threads are slower throughout
+    (`profiles/sra_rank_timing_n20000.jsonl`)."""
     import os
 
-    halo = int(os.environ.get("EVOX_AMD_SRA_WINDOW", "256"))
+    halo = int(os.environ.get("EVOX_AMD_SRA_WINDOW", "96"))
     return halo if n >= 8192 and halo > 0 else 0
 
 

@@ -1826,14 +1826,16 @@ def test_stochastic_ranking_on_packed_ranks_handles_equal_elements(cuda, n, monk
     ref_fresh = moselect.stochastic_ranking(I1, I2, None, 0.47, seed=seed)
     ref_pos = moselect.stochastic_ranking(I1, I2, u, 0.45)
     # packed words in several workgroups (windows with halos of two widths), in one workgroup, three-word entries
-    for packed, window, block in (("1", "256", "4"), ("1", "130", "8"), ("1", "384", "4"), ("1", "0", "4"), ("0", "0", "4")):
+    for packed, window, block, threads in (("1", "96", "4", "256"), ("1", "64", "8", "256"), ("1", "130", "8", "1024"),
+                                           ("1", "192", "4", "512"), ("1", "0", "4", "256"), ("0", "0", "4", "256")):
         monkeypatch.setenv("EVOX_AMD_SRA_PACKED", packed)
         monkeypatch.setenv("EVOX_AMD_SRA_WINDOW", window)
         monkeypatch.setenv("EVOX_AMD_SRA_WINDOW_BLOCK", block)
+        monkeypatch.setenv("EVOX_AMD_SRA_WINDOW_THREADS", threads)
         got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), None, 0.47, seed=seed.to(cuda))
-        assert torch.equal(got.cpu(), ref_fresh), (packed, window, block)
+        assert torch.equal(got.cpu(), ref_fresh), (packed, window, block, threads)
         got = moselect.stochastic_ranking(I1.to(cuda), I2.to(cuda), u.to(cuda), 0.45)
-        assert torch.equal(got.cpu(), ref_pos), (packed, window, block)
+        assert torch.equal(got.cpu(), ref_pos), (packed, window, block, threads)
 
 
 @pytest.mark.parametrize("n,mu", [(1000, 5632), (64, 128), (260, 300)])
