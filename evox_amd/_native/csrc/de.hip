@@ -16,7 +16,8 @@
 // sub-vectors, each evolving with its own picks, crossover mask, F and CR — the stacked members of a decomposition
 // container.  The kernel then works on virtual rows v = row * blocks + block (the population viewed as
 // (n_pop * blocks) x dim): picks are individuals in [0, n_pop), mapped to the virtual row of the same block; `rows`,
-// F, CR, the pbest rows and the random elements are indexed by the virtual row, lb / ub by block * dim + column.
+// F, CR, the pbest rows and the random elements are indexed by the virtual row, lb / ub by block * dim + column;
+// best_per_block: best_index holds one individual per block (blocks with a fitness of their own).
 #include "hip_common.h"
 #include "philox.h"
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
     const int64_t* __restrict__ best_index, const int64_t* __restrict__ pbest_rows, const float* __restrict__ F, int f_is_vec,
     const float* __restrict__ CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
     const int32_t* __restrict__ row_codes, int n_picks, const int32_t* __restrict__ key_sel, const int32_t* __restrict__ key_jrand, const int32_t* __restrict__ key_mask,
-    const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out, int blocks) {
+    const float* __restrict__ lb, const float* __restrict__ ub, float* __restrict__ out, int blocks, int best_per_block) {
   constexpr int RPB = 256 / LPR;                       // rows per block
   const int sub = threadIdx.x % LPR;
   const int r = blockIdx.x * RPB + threadIdx.x / LPR;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
   auto base_row = [&](int code) -> const float* {
     switch (code) {
       case kRand: return pop + ((int64_t)picks[0] * blocks + blk) * ldpop;
-      case kBest: return pop + (best_index[0] * blocks + blk) * ldpop;
+      case kBest: return pop + (best_index[best_per_block ? blk : 0] * blocks + blk) * ldpop;
       case kPbest: return pop + (pbest_rows[r] * blocks + blk) * ldpop;
       default: return pop + self_v * ldpop;
     }
@@ -115,7 +116,7 @@ EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int d
                                const int64_t* best_index, const int64_t* pbest_rows, const float* F, int f_is_vec,
                                const float* CR, int cr_is_vec, int prim, int sec, int num_diff, int cross,
                                const int32_t* row_codes, int n_picks, const int32_t* key_sel, const int32_t* key_jrand, const int32_t* key_mask, const float* lb,
-                               const float* ub, float* out, int blocks, void* stream) {
+                               const float* ub, float* out, int blocks, int best_per_block, void* stream) {
   if (b <= 0 || dim <= 0) return 0;
   if (blocks < 1) return (int)hipErrorInvalidValue;
   if (row_codes) num_diff = 2;                          // per-row values are 1 or 2 (checked by the caller)
@@ -128,7 +129,7 @@ EVOX_API int evox_hip_de_trial(const float* pop, int64_t ldpop, int n_pop, int d
   de_trial_kernel<LPR><<<(b + 256 / LPR - 1) / (256 / LPR), 256, 0, s>>>(                                              \
       pop, ldpop, n_pop, dim, rows, b, best_index, pbest_rows, F, f_is_vec, CR, cr_is_vec, prim, sec, num_diff, cross,   \
       row_codes, n_picks,                                                                                              \
-      key_sel, key_jrand, key_mask, lb, ub, out, blocks)
+      key_sel, key_jrand, key_mask, lb, ub, out, blocks, best_per_block)
   if (dim <= 8) EVOX_DE_LAUNCH(8);
   else if (dim <= 16) EVOX_DE_LAUNCH(16);
   else if (dim <= 32) EVOX_DE_LAUNCH(32);

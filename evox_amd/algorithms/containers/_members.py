@@ -41,7 +41,9 @@ def batch(base, times: int, concat: bool = True):
     JaDE, SHADE, CoDE and SepCMAES (exact classes) have one for blocks that share their fitness (``concat=True``):
     ``DEBase.blocked`` — every block draws its own parents, masks and control parameters and keeps its own adaptation
     memory in one pass over the concatenated population —, ``SepCMAES.blocked`` — one step size and path norm per
-    block."""
+    block.  With ``concat=False`` (one fitness per block: co-evolution) DE, JaDE, SHADE and SepCMAES have the blocked
+    form with a fitness column, a best individual and a p-best set per block (``blocked(times, shared_fitness=False)``:
+    ``ask`` returns ``(pop_size, times · dim)``, ``tell`` takes ``(pop_size, times)``)."""
     from ..so.de_variants.adaptive import SHADE, CoDE, JaDE
     from ..so.de_variants.de import DE, ODE
     from ..so.es_variants.batched_cma import BatchedCMAES
@@ -51,18 +53,31 @@ def batch(base, times: int, concat: bool = True):
         return BatchedCMAES.of(base, times, concat)
     if type(base) in (DE, ODE, JaDE, SHADE, CoDE, SepCMAES) and concat and base.blocks == 1:
         return base.blocked(times)
+    if type(base) in (DE, JaDE, SHADE, SepCMAES) and not concat and base.blocks == 1:
+        return base.blocked(times, shared_fitness=False)      # one fitness column per block (co-evolution)
     return None
 
 
 def same_configuration(members) -> bool:
-    """True when all members are plain CMA-ES instances with identical settings (then one batched instance stands for
-    them all)."""
+    """True when all members are instances of one class with identical settings (then one batched or blocked instance
+    can stand for them all): plain CMA-ES by its hyper-parameters, the DE family and SepCMAES attribute by attribute."""
     from ..so.es_variants.cma_es import CMAES
     import torch
 
     first = members[0]
-    if not all(type(m) is CMAES for m in members):
+    if not all(type(m) is type(first) for m in members):
         return False
+    if type(first) is not CMAES:
+        def same(a, b):
+            if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+                return isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and bool(torch.equal(a, b))
+            if isinstance(a, (int, float, str, bool, type(None), tuple)):
+                return a == b
+            return True                                        # sub-modules and operators: compared by the attributes above
+
+        keys = [k for k in vars(first) if not k.startswith("_")]
+        return all(set(vars(m)) == set(vars(first)) and all(same(getattr(first, k), getattr(m, k)) for k in keys)
+                   for m in members[1:])
     for m in members[1:]:
         if (m.dim, m.pop_size, m.mu, m.cm, m.decomp_per_iter, m.init_stdev, m.decomposition, m.precision) != \
                 (first.dim, first.pop_size, first.mu, first.cm, first.decomp_per_iter, first.init_stdev, first.decomposition,

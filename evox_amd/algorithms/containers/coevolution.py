@@ -6,9 +6,10 @@ Reference: ``src/evox/algorithms/containers/coevolution.py:11-274``.
 evaluates ``num_subpops × pop_size`` context vectors at once); ``Coevolution`` evolves them
 round-robin, one per generation.
 
-When the members of a ``VectorizedCoevolution`` are identically configured plain CMA-ES instances they are replaced by
-ONE batched instance (``_members.batch``) told a ``(num_subpops, pop_size)`` fitness matrix: the generation then costs
-the launches of one member instead of ``num_subpops`` times that (``fuse=False`` keeps the member loop)."""
+When the members of a ``VectorizedCoevolution`` are identically configured plain CMA-ES, DE, JaDE, SHADE or SepCMAES
+instances they are replaced by ONE batched / blocked instance (``_members.batch``) told one fitness per sub-population
+and individual: the generation then costs the launches of one member instead of ``num_subpops`` times that
+(``fuse=False`` keeps the member loop)."""
 from __future__ import annotations
 
 import torch
@@ -26,17 +27,25 @@ class _CoevolutionBase(Algorithm):
         assert dim % num_subpops == 0
         self.base_algorithms = as_stack(base_algorithms, num_subpops, stacked=True)
         assert len(self.base_algorithms) == num_subpops
-        self.batched = None
+        one = None
         if fuse in ("auto", True) and self._can_batch and same_configuration(list(self.base_algorithms)):
-            self.batched = batch(self.base_algorithms[0], num_subpops, concat=False)
-        if fuse is True and self.batched is None:
+            one = batch(self.base_algorithms[0], num_subpops, concat=False)
+        if fuse is True and one is None:
             raise TypeError("the members have no common batched form")
-        if self.batched is not None:
-            self.base_algorithms = as_stack([self.batched])
+        if one is not None:
+            # the instance is a child of this module once, as the only member of the stack (its state, host counters and
+            # recording variants are found under that path)
+            self.base_algorithms = as_stack([one])
+        self._one_instance = one is not None
         self.dim, self.num_subpops, self.random_subpop, self.dtype = dim, num_subpops, random_subpop, dtype
         self.sub_dim = dim // num_subpops
 
     _can_batch = False           # round-robin co-evolution steps one member per generation: nothing to batch
+
+    @property
+    def batched(self):
+        """The one batched / blocked instance that stands for all members, or None (member loop)."""
+        return self.base_algorithms[0] if self._one_instance else None
 
     def _base_state(self, key, **extra):
         permutation = rnd.permutation(key, self.dim) if self.random_subpop else None
@@ -53,10 +62,24 @@ class _CoevolutionBase(Algorithm):
     def _gather(self, state, vec):
         return vec[..., state.permutation.to(vec.device)] if self.random_subpop else vec
 
+    # One instance standing for all members is either a BatchedCMAES (blocks (S, P, d) out, fitness (S, P) in) or a
+    # blocked instance of the DE family / SepCMAES (candidates (P, S·d) out, fitness (P, S) in).
+    def _batched_ask(self, state, first):
+        """``blocks (S, P, d), the same side by side (P, S·d), state``"""
+        out, state = member_ask(self.batched, state, first)
+        if hasattr(self.batched, "as_candidates"):
+            return out, self.batched.as_candidates(out), state
+        return out.reshape(out.shape[0], self.num_subpops, self.sub_dim).permute(1, 0, 2), out, state
+
+    def _batched_tell(self, state, fit, first):
+        if not hasattr(self.batched, "as_candidates") and fit.dim() == 2:
+            fit = fit.T.contiguous()
+        return member_tell(self.batched, state, fit, first)
+
     def init_ask(self, state):
         if self.batched is not None:
-            blocks, state = member_ask(self.batched, state, True)            # (S, P, d)
-            init_pop = self._scatter(state, self.batched.as_candidates(blocks))
+            _, wide, state = self._batched_ask(state, True)
+            init_pop = self._scatter(state, wide)
             return init_pop, state.replace(coop_pops=init_pop)
         pops = []
         for m in self.base_algorithms:
@@ -83,7 +106,7 @@ class VectorizedCoevolution(MemberRecording, _CoevolutionBase):
 
     def ask(self, state):
         if self.batched is not None:
-            blocks, state = member_ask(self.batched, state, False)           # (S, P, d)
+            blocks, _, state = self._batched_ask(state, False)               # (S, P, d)
             pop_size = blocks.shape[1]
             coop = state.best_dec.expand(self.num_subpops, pop_size, self.dim).clone()
             # block i of the i-th group of context vectors: the diagonal of a (S, P, S, d) view
@@ -106,7 +129,7 @@ class VectorizedCoevolution(MemberRecording, _CoevolutionBase):
         fit = fitness.reshape(self.num_subpops, -1)
         pop_size = fit.shape[1]
         if self.batched is not None:
-            state = member_tell(self.batched, state, fit, False)
+            state = self._batched_tell(state, fit, False)
         else:
             for i, m in enumerate(self.base_algorithms):
                 state = member_tell(m, state, fit[i], False)
@@ -114,7 +137,7 @@ class VectorizedCoevolution(MemberRecording, _CoevolutionBase):
         coop = state.coop_pops.reshape(self.num_subpops, pop_size, self.dim)
         best_rows = self._gather(state, coop[torch.arange(self.num_subpops, device=coop.device), arg])   # (S, dim)
         blocks = best_rows.reshape(self.num_subpops, self.num_subpops, self.sub_dim)
-        own_block = blocks[torch.arange(self.num_subpops), torch.arange(self.num_subpops)]             # (S, sub_dim)
+        own_block = torch.diagonal(blocks, dim1=0, dim2=1).T                                           # (S, sub_dim)
         improved = state.best_fit > min_fit
         best_dec = torch.where(improved[:, None], own_block, state.best_dec.reshape(self.num_subpops, self.sub_dim))
         return state.replace(best_dec=best_dec.reshape(self.dim), best_fit=torch.minimum(state.best_fit, min_fit),

@@ -74,10 +74,13 @@ class JaDE(DEBase):
         okf = ok.to(torch.float32)
         n_ok = okf.sum()
         if self.blocks > 1:
-            # the success mask is shared by the blocks (one fitness), the parameters are per block: sums over individuals
+            # the success mask is shared by the blocks (one fitness) or one column per block, the parameters are per
+            # block: sums over individuals
             Fm, CRm = state.F_vect.reshape(self.pop_size, -1), state.CR_vect.reshape(self.pop_size, -1)
-            sF, sF2 = (okf[:, None] * Fm).sum(0), (okf[:, None] * Fm ** 2).sum(0)
-            mean_cr = (okf[:, None] * CRm).sum(0) / n_ok
+            okm = okf.reshape(self.pop_size, -1)
+            n_ok = okm.sum(0)
+            sF, sF2 = (okm * Fm).sum(0), (okm * Fm ** 2).sum(0)
+            mean_cr = (okm * CRm).sum(0) / n_ok
         else:
             sF, sF2 = (okf * state.F_vect).sum(), (okf * state.F_vect ** 2).sum()
             mean_cr = (okf * state.CR_vect).sum() / n_ok
@@ -137,20 +140,26 @@ class SHADE(JaDE):
             return state.replace(population=population, fitness=fitness, best_index=best_index,
                                  Memory_FCR=memory)
         population, fitness, best_index, start, ok, parent_fit = self._select(state, state.trial_vectors, trial_fitness)
-        delta = torch.where(ok, parent_fit - trial_fitness, torch.zeros_like(trial_fitness))
+        if parent_fit.dim() == 2 and trial_fitness.dim() == 1:          # one fitness column per block, told one vector
+            trial_fitness = trial_fitness[:, None].expand_as(parent_fit)
+        delta = torch.where(ok, parent_fit - trial_fitness, torch.zeros_like(parent_fit))
         delta = torch.where(torch.isfinite(delta), delta, torch.zeros_like(delta))
-        total = delta.sum()
-        w = delta / total
         if self.blocks > 1:
-            # improvements (hence weights) are shared by the blocks; every block averages its own parameters
+            # improvements (hence weights) are shared by the blocks or one column per block; every block averages its
+            # own parameters
             Fm, CRm = state.F_vect.reshape(self.pop_size, -1), state.CR_vect.reshape(self.pop_size, -1)
-            M_CR = (w[:, None] * CRm).sum(0)
-            M_F = (w[:, None] * Fm ** 2).sum(0) / (w[:, None] * Fm).sum(0)
+            dm = delta.reshape(self.pop_size, -1)
+            total = dm.sum(0)
+            w = dm / total
+            M_CR = (w * CRm).sum(0)
+            M_F = (w * Fm ** 2).sum(0) / (w * Fm).sum(0)
             rolled = torch.cat([torch.stack([M_F, M_CR])[:, :, None], state.Memory_FCR[:, :, :-1]], dim=2)
             valid = (total > 0) & torch.isfinite(M_F) & torch.isfinite(M_CR)
             memory = torch.where(valid[None, :, None], rolled, state.Memory_FCR)
             return state.replace(population=population, fitness=fitness, best_index=best_index, start_index=start,
                                  start_index_dev=self._next_start_dev(state), Memory_FCR=memory)
+        total = delta.sum()
+        w = delta / total
         M_CR = (w * state.CR_vect).sum()
         M_F = (w * state.F_vect ** 2).sum() / (w * state.F_vect).sum()
         rolled = torch.roll(state.Memory_FCR, 1, dims=1)

@@ -33,21 +33,27 @@ class DEBase(Algorithm):
         self.pop_size = int(pop_size)
         self.batch_size = int(batch_size) if batch_size else self.pop_size
         self.blocks = 1
+        self.block_fitness = False
 
-    def blocked(self, times: int):
+    def blocked(self, times: int, shared_fitness: bool = True):
         """``times`` independent copies of this algorithm, all told the same fitness, as ONE instance over the
         concatenated decision vector (what a decomposition container runs; the reference vmaps the member,
         ``src/evox/algorithms/containers/clustered_algorithm.py:10-42``).  A row of the population is ``times``
         sub-vectors; every sub-vector draws its own parents, crossover mask and control parameters, and keeps its own
         adaptation memory, while fitness, replacement decisions, the best index and the p-best set — functions of the
-        shared fitness alone — exist once.  A generation costs the launches of one member."""
+        shared fitness alone — exist once.  A generation costs the launches of one member.
+
+        ``shared_fitness=False``: every block is told a fitness of its own (cooperative co-evolution,
+        ``src/evox/algorithms/containers/coevolution.py:12-136``): ``tell`` takes ``(pop_size, times)`` values — or a
+        vector, meaning the same value for every block —, ``fitness`` has that shape, ``best_index`` and the p-best set
+        exist per block and every sub-vector is replaced on its own."""
         from ....core.module import clone_module
 
         if self.blocks != 1:
             raise ValueError("already a blocked instance")
         wide = clone_module(self)
         wide.lb, wide.ub = self.lb.repeat(times), self.ub.repeat(times)
-        wide.dim, wide.blocks = self.dim * times, int(times)
+        wide.dim, wide.blocks, wide.block_fitness = self.dim * times, int(times), not shared_fitness
         for name in ("mean", "stdvar"):
             v = getattr(self, name, None)
             if isinstance(v, torch.Tensor) and v.dim() == 1 and v.shape[0] == self.dim:
@@ -66,7 +72,10 @@ class DEBase(Algorithm):
         dev = self.lb.device
         state_key, init_key = rnd.split(key.to(dev))
         pop, fit = self._init_population(init_key, getattr(self, "mean", None), getattr(self, "stdvar", None))
-        return State(population=pop, fitness=fit, best_index=torch.zeros((), dtype=torch.int64, device=dev),
+        if self.block_fitness:                       # one fitness column and one best index per block
+            fit = fit[:, None].repeat(1, self.blocks)
+        return State(population=pop, fitness=fit,
+                     best_index=torch.zeros((self.blocks,) if self.block_fitness else (), dtype=torch.int64, device=dev),
                      start_index=0, start_index_dev=torch.zeros((), dtype=torch.int64, device=dev), key=state_key,
                      trial_vectors=torch.zeros((trial_rows or self.batch_size, self.dim), device=dev), **extra)
 
@@ -88,6 +97,22 @@ class DEBase(Algorithm):
         next start_index, success mask, parent fitness)."""
         idx = self._window(state)
         parent_fit = state.fitness[idx]
+        if self.block_fitness:
+            # every sub-vector competes with its own parent on its block's fitness: (rows, blocks) decisions
+            B, b = self.blocks, idx.shape[0]
+            if trial_fitness.dim() == 1:
+                trial_fitness = trial_fitness[:, None].expand(b, B)
+            better = trial_fitness < parent_fit if self.strict_improvement else trial_fitness <= parent_fit
+            new_rows = torch.where(better[:, :, None], trial_vectors.reshape(b, B, -1),
+                                   state.population[idx].reshape(b, B, -1)).reshape(b, self.dim)
+            new_fit = torch.where(better, trial_fitness, parent_fit)
+            if self.batch_size == self.pop_size:
+                population, fitness = new_rows, new_fit
+            else:
+                population = state.population.index_copy(0, idx, new_rows)
+                fitness = state.fitness.index_copy(0, idx, new_fit)
+            start = (state.start_index + self.batch_size) % self.pop_size
+            return population, fitness, torch.argmin(fitness, dim=0), start, better, parent_fit
         better = trial_fitness < parent_fit if self.strict_improvement else trial_fitness <= parent_fit
         new_rows = torch.where(better[:, None], trial_vectors, state.population[idx])
         new_fit = torch.where(better, trial_fitness, parent_fit)
@@ -106,6 +131,8 @@ class DEBase(Algorithm):
         (``src/evox/workflows/std_workflow.py:230-244``)."""
         from ....ops import sort as _sort
 
+        if self.block_fitness:
+            raise NotImplementedError("migration into an instance with one fitness per block is not defined")
         k = foreign_fitness.shape[0]
         worst = _sort.select_indices(state.fitness, k, largest=True)
         better = foreign_fitness < state.fitness[worst]
@@ -159,8 +186,12 @@ class DEBase(Algorithm):
 
         def pbest_individuals():
             top = max(int(self.pop_size * 0.05), 1)
+            pick = rnd.randint(k_pb, (b,), 0, top)
+            if self.block_fitness:                             # the p-best set of every block, each in index order
+                best = torch.topk(fit.T, top, dim=1, largest=False).indices.sort(dim=1).values       # (blocks, top)
+                return best[blk, pick]
             best = _sort.select_indices(fit, top)              # the p-best set, in index order
-            return best[rnd.randint(k_pb, (b,), 0, top)]
+            return best[pick]
 
         def finish(trial_v):
             return torch.clamp(trial_v.reshape(rows_out, self.dim), self.lb, self.ub)
@@ -189,6 +220,8 @@ class DEBase(Algorithm):
         current = pop_v[idx]
 
         def best_rows():
+            if self.block_fitness:
+                return rows_of(state.best_index[blk])
             return rows_of(state.best_index.expand(b)) if B > 1 else pop[state.best_index].expand(b, -1)
 
         def base_of(code):

@@ -112,6 +112,14 @@ class BatchedCMAES(Algorithm):
     def graph_signature(self, state):
         return ((state.count_iter + 1) % self.decomp_per_iter == 0,)
 
+    # Recording into a HIP graph: the generation counters live on the host (the device work reads ``count_iter_dev``),
+    # and a generation that factorises is a different recording from one that does not.
+    def graph_host_counters(self):
+        return ("count_iter", "count_eigen")
+
+    def graph_variant(self, state):
+        return self.graph_signature(state)[0]
+
     # ------------------------------------------------------------------------------------
     def sample(self, state, z):
         """Candidates of standard normal draws ``z`` (S, P, d): ``m + σ · B (D ∘ z)`` per block."""

@@ -591,8 +591,12 @@ class SepCMAES(CMAES):
     the member's dimension."""
 
     blocks = 1
+    block_fitness = False
 
-    def blocked(self, times: int):
+    def blocked(self, times: int, shared_fitness: bool = True):
+        """``shared_fitness=False``: ``tell`` takes one fitness column per block, ``(pop_size, times)`` (cooperative
+        co-evolution, ``src/evox/algorithms/containers/coevolution.py:12-136``): every block ranks the population on
+        its own column."""
         from ....core.module import clone_module
 
         if self.blocks != 1:
@@ -600,6 +604,7 @@ class SepCMAES(CMAES):
         wide = clone_module(self)
         wide.center_init = self.center_init.repeat(times)
         wide.block_dim, wide.blocks, wide.dim = self.dim, int(times), self.dim * times
+        wide.block_fitness = not shared_fitness
         return wide
 
     def _wide(self, per_block):
@@ -661,8 +666,15 @@ class SepCMAES(CMAES):
         return state.replace(mean=mean, ps=ps, pc=pc, C=C, sigma=sigma)
 
     def tell(self, state, fitness):
-        order = _sort.argsort(fitness)
-        d = state.population[order[: self.mu]] - state.mean
+        if self.block_fitness and fitness.dim() == 2:
+            # every block selects its own best mu sub-vectors
+            B, bd = self.blocks, self.block_dim
+            order = torch.argsort(fitness, dim=0, stable=True)[: self.mu]                              # (mu, blocks)
+            chosen = torch.gather(state.population.reshape(self.pop_size, B, bd), 0, order[:, :, None].expand(self.mu, B, bd))
+            d = chosen.reshape(self.mu, self.dim) - state.mean
+        else:
+            order = _sort.argsort(fitness)
+            d = state.population[order[: self.mu]] - state.mean
         y = d / self._wide(state.sigma)
         return self._update(state, self.weights @ d, self.weights @ (y * y))
 

@@ -11,7 +11,7 @@ from ._util import check, hip, stream_of
 
 P, I, I64 = _native.P, _native.I, _native.I64
 _native.register_hip_api({
-    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, I, P]),
+    "evox_hip_de_trial": (I, [P, I64, I, I, P, I, P, P, P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, I, I, P]),
 })
 
 
@@ -47,8 +47,11 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
 
     ``blocks`` > 1: every row of ``pop`` is ``blocks`` independent sub-vectors (stacked members of a container);
     ``idx``, ``F``, ``CR`` and ``pbest_rows`` then run over the virtual rows ``individual * blocks + block``
-    (``pbest_rows`` still names individuals), and the result has one row per entry of ``idx``."""
+    (``pbest_rows`` still names individuals), and the result has one row per entry of ``idx``; a ``best_index`` of
+    ``blocks`` entries names the best individual of every block."""
     dev = pop.device
+    if best_index.numel() not in (1, blocks):
+        raise ValueError("best_index: one individual, or one per block")
     if pop.stride(1) != 1 or (blocks > 1 and not pop.is_contiguous()):
         pop = pop.contiguous()
     n_pop = pop.shape[0]
@@ -68,9 +71,9 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
     out = torch.empty((b, dim), dtype=torch.float32, device=dev)
     check(hip().evox_hip_de_trial(
         pop.data_ptr(), pop.stride(0), n_pop, dim, idx.contiguous().data_ptr(), b,
-        best_index.reshape(1).contiguous().data_ptr(), pbest_rows.contiguous().data_ptr() if pbest_rows is not None else None,
+        best_index.reshape(-1).contiguous().data_ptr(), pbest_rows.contiguous().data_ptr() if pbest_rows is not None else None,
         f.data_ptr(), f_vec, cr.data_ptr(), cr_vec, int(prim), int(sec), int(num_diff), int(cross),
         codes.data_ptr() if per_row else None, int(n_picks),
         k_sel.contiguous().data_ptr(), k_r.contiguous().data_ptr(), k_m.contiguous().data_ptr(),
-        lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), out.data_ptr(), int(blocks), stream_of(pop)), "de_trial")
+        lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), out.data_ptr(), int(blocks), int(best_index.numel() > 1), stream_of(pop)), "de_trial")
     return out

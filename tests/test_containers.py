@@ -187,6 +187,67 @@ def test_blocked_sep_cma_es_follows_the_member_update():
     assert bstate.sigma.shape == (B,) and len({round(float(v), 6) for v in bstate.sigma}) == B
 
 
+@pytest.mark.parametrize("name", ["DE", "JaDE", "SHADE", "SepCMAES"])
+def test_blocked_members_with_a_fitness_per_block_follow_the_member_update(name):
+    """Co-evolution form: every block is told a fitness column of its own.  Fed the instance's candidates block by block
+    and that column, every member's own tell() reproduces the block (population, fitness, best index, memories; mean,
+    step size, paths and variances for SepCMAES)."""
+    B, d, P = 3, 4, 24
+    lb, ub = torch.linspace(-3, -1, d), torch.linspace(1, 3, d)
+    member = {"DE": lambda: algorithms.DE(lb, ub, P, batch_size=8), "JaDE": lambda: algorithms.JaDE(lb, ub, P),
+              "SHADE": lambda: algorithms.SHADE(lb, ub, P, memory_size=5),
+              "SepCMAES": lambda: algorithms.SepCMAES(torch.linspace(-1, 1, d), 0.8, pop_size=P)}[name]()
+    blocked = member.blocked(B, shared_fitness=False)
+    assert blocked.block_fitness and not member.block_fitness
+    bstate = blocked.init(ex.PRNGKey(5))
+    mstates = [member.init(ex.PRNGKey(50 + s)) for s in range(B)]
+    if name != "SepCMAES":
+        assert bstate.fitness.shape == (P, B) and bstate.best_index.shape == (B,)
+        mstates = [m.replace(population=bstate.population.reshape(P, B, d)[:, s].clone()) for s, m in enumerate(mstates)]
+    target = torch.randn(B, d, generator=torch.Generator().manual_seed(1)) * 0.5
+    for gen in range(10):
+        cand, bstate = blocked.ask(bstate)
+        rows = cand.shape[0]
+        fit = ((cand.reshape(rows, B, d) - target) ** 2).sum(-1) + 0.2 * torch.sin(7 * cand.reshape(rows, B, d)).sum(-1)   # (rows, B)
+        after = blocked.tell(bstate, fit)
+        for s in range(B):
+            if name == "SepCMAES":
+                _, ms = member.ask(mstates[s])
+                ms = member.tell(ms.replace(population=cand.reshape(P, B, d)[:, s].clone()), fit[:, s].contiguous())
+                for field in ("mean", "ps", "pc", "C"):
+                    torch.testing.assert_close(getattr(after, field).reshape(B, d)[s], getattr(ms, field), rtol=1e-4, atol=1e-6)
+                torch.testing.assert_close(after.sigma[s], ms.sigma, rtol=1e-4, atol=1e-7)
+            else:
+                ms = mstates[s].replace(trial_vectors=cand.reshape(rows, B, d)[:, s].clone(), start_index=bstate.start_index,
+                                        start_index_dev=bstate.start_index_dev.clone())
+                if name in ("JaDE", "SHADE"):
+                    ms = ms.replace(F_vect=bstate.F_vect.reshape(P, B)[:, s].clone(), CR_vect=bstate.CR_vect.reshape(P, B)[:, s].clone())
+                ms = member.tell(ms, fit[:, s].contiguous())
+                assert torch.equal(after.population.reshape(P, B, d)[:, s], ms.population), (gen, s)
+                assert torch.equal(after.fitness[:, s], ms.fitness) and int(after.best_index[s]) == int(ms.best_index)
+                if name == "JaDE":
+                    torch.testing.assert_close(after.F_u[s], ms.F_u, rtol=1e-5, atol=1e-6)
+                    torch.testing.assert_close(after.CR_u[s], ms.CR_u, rtol=1e-5, atol=1e-6)
+                if name == "SHADE":
+                    torch.testing.assert_close(after.Memory_FCR[:, s], ms.Memory_FCR, rtol=1e-5, atol=1e-6)
+            mstates[s] = ms
+        bstate = after
+    if name != "SepCMAES":
+        assert len({int(v) for v in bstate.best_index}) > 1 or B == 1        # the blocks rank the individuals differently
+
+
+@pytest.mark.parametrize("name", ["SHADE", "SepCMAES"])
+def test_vectorized_coevolution_runs_identical_members_as_one_blocked_instance(name):
+    results = {}
+    for fuse in (False, "auto"):
+        lb, ub = torch.full((5,), -10.0), torch.full((5,), 10.0)
+        base = algorithms.SHADE(lb, ub, 40) if name == "SHADE" else algorithms.SepCMAES(torch.full((5,), 4.0), 3.0, pop_size=40)
+        algo = algorithms.VectorizedCoevolution(base, dim=20, num_subpops=4, fuse=fuse)
+        assert (algo.batched is not None) == (fuse == "auto") and len(algo.base_algorithms) == (1 if fuse == "auto" else 4)
+        results[fuse], _ = _run(algo, 120, problems.numerical.Sphere())
+    assert results["auto"] < 0.5 and results[False] < 0.5
+
+
 def test_blocked_de_draws_parents_per_block():
     """DE/rand/1 with CR = 1: every block of every trial row is x[r1] + F (x[r2] - x[r3]) of THAT block's sub-vectors,
     with r1, r2, r3 distinct and different from the row, and the blocks of a row use different parents."""
@@ -340,6 +401,57 @@ def test_member_loop_container_records_with_its_members_host_counters(base):
         if mode:
             assert wf.graph_replays >= 15
     assert torch.equal(out[True], out[False])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["DE_best2", "SHADE"])
+def test_blocked_de_trial_kernel_with_a_fitness_per_block(name, monkeypatch):
+    """Blocks with a fitness of their own: the fused launch reads the best individual of every block and a p-best set
+    per block, like the tensor formulation."""
+    from evox_amd.ops import de as de_ops
+
+    dev = torch.device("cuda")
+    B, d, P = 7, 10, 300
+    lb, ub = torch.linspace(-5, -4, d, device=dev), torch.linspace(4, 5, d, device=dev)
+    member = algorithms.SHADE(lb, ub, P) if name == "SHADE" else algorithms.DE(lb, ub, P, base_vector="best",
+                                                                             num_difference_vectors=2)
+    blocked = member.blocked(B, shared_fitness=False)
+    state = blocked.init(ex.PRNGKey(4).to(dev))
+    fit = torch.rand(P, B, device=dev)
+    state = state.replace(fitness=fit, best_index=torch.argmin(fit, dim=0))
+    assert len({int(v) for v in state.best_index}) > 1
+    fused, _ = blocked.ask(state)
+    monkeypatch.setattr(de_ops, "supported", lambda *a, **k: False)
+    plain, _ = blocked.ask(state)
+    torch.testing.assert_close(fused, plain, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["SHADE", "SepCMAES", "CMAES"])
+def test_vectorized_coevolution_blocked_replays_from_a_graph(name):
+    """The one instance that stands for the members is a child of the container once: its host counters (generation
+    counts) are found by the recording, and the replayed generations equal eager issue."""
+    dev = torch.device("cuda")
+    lb, ub = torch.full((10,), -10.0, device=dev), torch.full((10,), 10.0, device=dev)
+    out = {}
+    for mode in (False, True):
+        base = {"SHADE": lambda: algorithms.SHADE(lb, ub, 128),
+                "SepCMAES": lambda: algorithms.SepCMAES(torch.full((10,), 3.0, device=dev), 2.0, pop_size=128),
+                "CMAES": lambda: algorithms.CMAES(torch.full((10,), 3.0, device=dev), 2.0, pop_size=128)}[name]()
+        algo = algorithms.VectorizedCoevolution(base, dim=200, num_subpops=20)
+        assert algo.batched is not None
+        wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), graph_step=mode)
+        state = wf.init(ex.PRNGKey(7).to(dev))
+        for _ in range(40):
+            state = wf.step(state)
+        torch.cuda.synchronize()
+        out[mode] = state.get_child_state("algorithm").best_dec.clone()
+        if mode:
+            assert wf.graph_replays >= 20
+    if name == "CMAES":                  # batched library eigendecompositions differ in the last bits between the runs
+        torch.testing.assert_close(out[True], out[False], rtol=1e-3, atol=1e-3)
+    else:
+        assert torch.equal(out[True], out[False])
 
 
 @pytest.mark.gpu

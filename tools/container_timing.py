@@ -45,3 +45,21 @@ for name, make in (("SHADE", lambda: A.SHADE(lb, ub, pop)), ("DE", lambda: A.DE(
     torch.cuda.synchronize()
     row["one_member_eager_ms"] = (time.perf_counter() - t0) / 30 * 1e3
     print(json.dumps(row), flush=True)
+
+# cooperative co-evolution: every sub-population is told a fitness of its own
+for name, make in (("SHADE", lambda: A.SHADE(lb, ub, pop)), ("SepCMAES", lambda: A.SepCMAES(torch.zeros(sub, device=dev), 1.0, pop_size=pop))):
+    for fuse in (False, "auto"):
+        row = {"container": "VectorizedCoevolution", "base": name, "num_subpops": S, "dim": dim, "pop": pop, "fuse": fuse}
+        for mode in (False, True):
+            algo = A.VectorizedCoevolution(make(), dim=dim, num_subpops=S, fuse=fuse)
+            wf = workflows.StdWorkflow(algo, problems.numerical.Sphere(), graph_step=mode, graph_mode="ring")
+            s = wf.init(ex.PRNGKey(1).to(dev))
+            for _ in range(12):
+                s = wf.step(s)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                s = wf.step(s)
+            torch.cuda.synchronize()
+            row["graph_ms" if mode else "eager_ms"] = (time.perf_counter() - t0) / 30 * 1e3
+        print(json.dumps(row), flush=True)
