@@ -371,7 +371,124 @@ int launch(const T* flat, int64_t pitch, const void* center, int center_dtype, i
   return last_launch_status();
 }
 
+// Small policies (every width <= 64: the 32- or 64-unit networks of locomotion tasks, a few thousand parameters): the
+// kernels above give an individual a whole workgroup, which for 1.5 k parameters is all latency (12.8 us per call for
+// 4096 individuals).  Here the population is read TRANSPOSED, wt[k][p] (made once per generation by the caller), so the
+// 64 lanes of a wave are 64 individuals and every weight load is one coalesced 256-byte row segment whose address is a
+// scalar base plus the lane's individual.  A workgroup is 16 waves on the same 64 individuals: wave w accumulates the
+// outputs [w·OC, w·OC + OC) of the layer over all inputs (activations are shared through LDS, one barrier per layer), so
+// sixteen waves' loads are in flight on the compute unit instead of one wave's.
+// MIRROR: the population is mirrored (row half + p = 2·centre − row p): wt holds the first half only, a lane evaluates
+// individual p AND its mirror image from one load per weight (the centre value of a weight is one scalar for the wave),
+// which halves the bytes read per individual.
+template <int MAXW, bool MIRROR>
+__global__ __launch_bounds__(1024) void mlp_small_kernel(const float* __restrict__ wt, int pitch,
+                                                         const float* __restrict__ center, const float* __restrict__ obs,
+                                                         float* __restrict__ out, MlpDesc d, int P, int E, int n_params) {
+  constexpr int NW = 16, OC = MAXW / NW, SG = MIRROR ? 2 : 1;
+  __shared__ float buf[2][SG][MAXW * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rows = MIRROR ? P / 2 : P;                       // individuals whose parameters are stored
+  const int g = blockIdx.x * 64 + lane;                      // (stored individual, observation) pair of this lane
+  const bool live = g < rows * E;
+  const unsigned p = live ? (unsigned)(g / E) : 0u;
+  const int nin0 = d.in[0];
+  const int64_t g2 = (int64_t)g + (int64_t)rows * E;         // the same observation slot of the mirror image
+  for (int i = wave; i < nin0; i += NW) {
+    buf[0][0][i * 64 + lane] = live ? obs[(int64_t)g * nin0 + i] : 0.f;
+    if constexpr (MIRROR) buf[0][1][i * 64 + lane] = live ? obs[g2 * nin0 + i] : 0.f;
+  }
+  __syncthreads();
+  // Row k of the transposed population starts at wt + k * pitch: a wave-uniform address (32-bit index arithmetic, so
+  // that it stays in scalar registers; the host checks n_params * pitch < 2^31), to which the lane adds its individual.
+  auto clampk = [&](int k) { return min(k, n_params - 1); };
+  auto weight = [&](int k) { return (wt + (unsigned)clampk(k) * (unsigned)pitch)[p]; };   // cached: a population that fits the L2 stays there between time steps
+  int cur = 0;
+  for (int l = 0; l < d.n_layers; ++l) {
+    const int nin = d.in[l], nout = d.out[l], act = d.act[l];
+    const int w_off = (int)d.w_off[l], b_off = (int)d.b_off[l];
+    const int o0 = wave * OC;
+    if (o0 < nout) {                                           // wave-uniform
+      float acc[SG][OC];
+#pragma unroll
+      for (int k = 0; k < OC; ++k) {                           // past the layer: never used
+        const float w = b_off >= 0 ? weight(b_off + o0 + k) : 0.f;
+        acc[0][k] = w;
+        if constexpr (MIRROR) acc[1][k] = b_off >= 0 ? fmaf(2.f, center[clampk(b_off + o0 + k)], -w) : 0.f;
+      }
+      const float* a = buf[cur][0];
+      const float* a2 = buf[cur][SG - 1];
+      // TRIP inputs per trip, all of their loads issued together (a trip's loads are independent); a trip that runs
+      // past the layer's inputs multiplies (clamped, in-matrix) values of the same individual by zero instead of
+      // leaving the pipelined form.
+      constexpr int TRIP = 16 / OC;                            // 16 loads in flight per wave (24 and 48 were measured slower)
+      for (int i0 = 0; i0 < nin; i0 += TRIP) {
+#pragma unroll
+        for (int u = 0; u < TRIP; ++u) {
+          const int i = i0 + u;
+          const float x = i < nin ? a[i * 64 + lane] : 0.f;
+          const float x2 = MIRROR ? (i < nin ? a2[i * 64 + lane] : 0.f) : 0.f;
+          const int base = w_off + i * nout + o0;
+#pragma unroll
+          for (int k = 0; k < OC; ++k) {
+            const float w = weight(base + k);
+            acc[0][k] = fmaf(x, w, acc[0][k]);
+            if constexpr (MIRROR) acc[1][k] = fmaf(x2, fmaf(2.f, center[clampk(base + k)], -w), acc[1][k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < OC; ++k)
+        if (o0 + k < nout) {
+          buf[cur ^ 1][0][(o0 + k) * 64 + lane] = activate(acc[0][k], act);
+          if constexpr (MIRROR) buf[cur ^ 1][1][(o0 + k) * 64 + lane] = activate(acc[1][k], act);
+        }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const int nl = d.out[d.n_layers - 1];
+  if (live)
+    for (int o = wave; o < nl; o += NW) {
+      out[(int64_t)g * nl + o] = buf[cur][0][o * 64 + lane];
+      if constexpr (MIRROR) out[g2 * nl + o] = buf[cur][1][o * 64 + lane];
+    }
+}
+
 }  // namespace
+
+// The forward pass for small networks on a TRANSPOSED fp32 population wt (n_params rows of `pitch` values): every width
+// <= 64, n_layers <= 8.  obs (P, E, sizes[0]), out (P, E, sizes[n_layers]), both fp32.  center != nullptr: the
+// population is mirrored (row P/2 + p = 2·center − row p), wt holds the first P/2 individuals only.
+EVOX_API int evox_hip_mlp_small(const float* wt, int64_t pitch, const float* center, const float* obs, float* out, int P, int E,
+                                const int* sizes, const int* acts, int n_layers, int bias, void* stream) {
+  const int rows = center ? P / 2 : P;
+  if (n_layers < 1 || n_layers > kMaxLayers || P <= 0 || E <= 0 || pitch < rows || (center && (P & 1)))
+    return (int)hipErrorInvalidValue;
+  MlpDesc d;
+  d.n_layers = n_layers;
+  d.max_width = 0;
+  int64_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    d.in[l] = sizes[l]; d.out[l] = sizes[l + 1]; d.act[l] = acts[l];
+    d.w_off[l] = off; off += (int64_t)sizes[l] * sizes[l + 1];
+    d.b_off[l] = bias ? off : -1; if (bias) off += sizes[l + 1];
+    d.vec4[l] = 0;
+    if (sizes[l] > d.max_width) d.max_width = sizes[l];
+    if (sizes[l + 1] > d.max_width) d.max_width = sizes[l + 1];
+  }
+  if (d.max_width > 64 || d.max_width < 1) return (int)hipErrorInvalidValue;
+  const int64_t pairs = (int64_t)rows * E;
+  if ((int64_t)P * E >= (1ll << 31) || off * pitch >= (1ll << 31)) return (int)hipErrorInvalidValue;   // 32-bit index arithmetic
+  hipStream_t st = (hipStream_t)stream;
+  const int groups = (int)((pairs + 63) / 64);
+#define EVOX_MLP_SMALL(W, M) mlp_small_kernel<W, M><<<groups, 1024, 0, st>>>(wt, (int)pitch, center, obs, out, d, P, E, (int)off)
+  if (center) { if (d.max_width <= 32) EVOX_MLP_SMALL(32, true); else EVOX_MLP_SMALL(64, true); }
+  else { if (d.max_width <= 32) EVOX_MLP_SMALL(32, false); else EVOX_MLP_SMALL(64, false); }
+#undef EVOX_MLP_SMALL
+  return last_launch_status();
+}
 
 // sizes: n_layers + 1 widths; acts: per layer; dtype: 0 fp32, 1 bf16.  obs (P, E, sizes[0]) fp32,
 // out (P, E, sizes[n_layers]) fp32.  E in {1, 2, 4}; every width <= 4096 / E.

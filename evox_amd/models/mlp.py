@@ -29,6 +29,9 @@ def batched_mlp_forward(flat: torch.Tensor, obs: torch.Tensor, sizes: Sequence[i
     squeeze = obs.dim() == 2
     h = obs[:, None, :] if squeeze else obs
     P = flat.shape[0]
+    if _small_ok(flat, h, sizes, activation, final_activation):
+        out = _forward_small(flat, h, sizes, activation, final_activation, bias)
+        return out[:, 0, :] if squeeze else out
     if _hip_ok(flat, h, sizes, activation, final_activation):
         out = _forward_hip(flat, h, sizes, activation, final_activation, bias)
         return out[:, 0, :] if squeeze else out
@@ -53,6 +56,69 @@ def batched_mlp_forward(flat: torch.Tensor, obs: torch.Tensor, sizes: Sequence[i
 
 
 _ACT_CODE = {"identity": 0, "tanh": 1, "relu": 2, "sigmoid": 3}
+
+
+def _small_ok(flat, obs, sizes, activation, final_activation) -> bool:
+    """Small networks (every width <= 64, e.g. the 32-unit policies of locomotion tasks) take ``mlp_small_kernel``: one
+    lane per individual on a transposed copy of the population (``EVOX_AMD_MLP_SMALL=0`` switches it off, ``=1`` forces
+    it wherever it can run).  Where it wins was measured in rollouts on an MI355X (`tools/mlp_small_timing.py`,
+    `tools/planar_es_timing.py`): from 8192 (individual, observation) pairs on always — the one-workgroup-per-pair kernel
+    takes 55 us there against 19-24 us, 213 against 38-56 us at 65 536 —; below that only for 32-unit networks whose
+    population fits the L2 (28 MB) and so stays there between the time steps of a rollout (hopper, 4096 policies: 3.02 ->
+    2.81 ms per generation; the ant's 36 MB: 11.1 -> 12.3 ms, so it keeps the other kernel)."""
+    import os
+
+    mode = os.environ.get("EVOX_AMD_MLP_SMALL", "auto")
+    if not (flat.is_cuda and obs.is_cuda and flat.dim() == 2 and flat.dtype in (torch.float32, torch.bfloat16)
+            and max(sizes) <= 64 and 1 <= len(sizes) - 1 <= 8
+            and flat.shape[0] * flat.shape[1] < 2 ** 31 and flat.shape[0] * obs.shape[1] < 2 ** 31
+            and isinstance(activation, str) and isinstance(final_activation, str)
+            and activation in _ACT_CODE and final_activation in _ACT_CODE and mode != "0"):
+        return False
+    pairs = flat.shape[0] * obs.shape[1]
+    if mode == "1":
+        return pairs >= 64
+    return pairs >= 8192 or (pairs >= 1024 and max(sizes) <= 32 and flat.shape[0] * flat.shape[1] * 4 <= 28 * 2 ** 20)
+
+
+def _forward_small(flat, obs, sizes, activation, final_activation, bias):
+    """``csrc/mlp.hip::mlp_small_kernel``.  The kernel reads the population transposed — (n_params, P), so that the lanes
+    of a wavefront are neighbouring individuals and every weight load is coalesced.  The transposed copy is made once
+    per population tensor (a rollout calls the policy once per time step with the same tensor) and kept on it."""
+    import ctypes
+    import os
+
+    from .. import _native
+    from ..ops._util import check, hip, stream_of
+    P_, I_, I64_ = _native.P, _native.I, _native.I64
+    _native.register_hip_api({"evox_hip_mlp_small": (I_, [P_, I64_, P_, P_, P_, I_, I_, P_, P_, I_, I_, P_])})
+    P, E = flat.shape[0], obs.shape[1]
+    n_layers = len(sizes) - 1
+    # a mirrored population (marked by ``ops.es.perturb``) is evaluated pair-wise from its first half and the centre
+    tag = getattr(flat, "_evox_mirror", None)
+    center = None
+    # (pairs halve the bytes read but also the lanes at work: they pay from 32 768 pairs on — 75 -> 38 us at 65 536)
+    mirror_mode = os.environ.get("EVOX_AMD_MLP_MIRROR", "auto")
+    if tag is not None and mirror_mode != "0" and (mirror_mode == "1" or P * E >= 32768):
+        c, half = tag
+        if (P == 2 * half and c.dtype == torch.float32 and c.is_contiguous() and c.device == flat.device
+                and c.numel() == flat.shape[1]):
+            center = c
+    cached = getattr(flat, "_evox_wt", None)
+    if cached is None or cached[0] != flat._version or cached[2] != (center is not None):
+        rows = flat[: P // 2] if center is not None else flat
+        wt = rows.detach().to(torch.float32).t().contiguous()
+        flat._evox_wt = cached = (flat._version, wt, center is not None)
+    wt = cached[1]
+    x = obs.to(torch.float32).contiguous()
+    out = torch.empty((P, E, sizes[-1]), dtype=torch.float32, device=flat.device)
+    c_sizes = (ctypes.c_int * (n_layers + 1))(*[int(s) for s in sizes])
+    acts = [_ACT_CODE[activation]] * (n_layers - 1) + [_ACT_CODE[final_activation]]
+    c_acts = (ctypes.c_int * n_layers)(*acts)
+    check(hip().evox_hip_mlp_small(wt.data_ptr(), wt.stride(0), center.data_ptr() if center is not None else None, x.data_ptr(),
+                                   out.data_ptr(), P, E, ctypes.addressof(c_sizes), ctypes.addressof(c_acts), n_layers,
+                                   int(bool(bias)), stream_of(flat)), "mlp_small")
+    return out
 
 
 def _hip_ok(flat, obs, sizes, activation, final_activation) -> bool:

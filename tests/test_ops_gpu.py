@@ -433,6 +433,88 @@ def test_mlp_kernel_matches_bmm(cuda, sizes, E):
     assert mlp_mod._hip_ok(buf[:, :net.n_params], obs.to(cuda), net.sizes, "tanh", "tanh")
 
 
+@pytest.mark.parametrize("sizes", [(11, 32, 32, 3), (27, 64, 8), (17, 48, 48, 6), (8, 32, 32, 2), (4, 16, 1), (60, 64, 64, 64, 8),
+                                   (3, 5)])
+@pytest.mark.parametrize("P,E", [(256, 1), (1000, 1), (333, 3)])
+def test_small_mlp_kernel_matches_bmm(cuda, sizes, P, E, monkeypatch):
+    """Small policies run one lane per individual on a transposed copy of the population: against the host formulation
+    (batched GEMMs), with other activations, without biases, with bf16 parameters, on a strided view, and after the
+    population tensor was changed in place (the transposed copy is keyed by the tensor's version)."""
+    from evox_amd.models import MLP
+    from evox_amd.models import mlp as mlp_mod
+
+    monkeypatch.setenv("EVOX_AMD_MLP_SMALL", "1")            # wherever it can run (by default: where it was measured faster)
+    g = torch.Generator().manual_seed(sum(sizes) + P + E)
+    for act, fin, bias in (("tanh", "tanh", True), ("relu", "identity", True), ("sigmoid", "tanh", False)):
+        net = MLP(list(sizes), activation=act, final_activation=fin, bias=bias)
+        pop = torch.randn(P, net.n_params, generator=g) * 0.3
+        obs = torch.randn(P, E, sizes[0], generator=g)
+        want = net.batched_apply(pop, obs)
+        dpop, dobs = pop.to(cuda), obs.to(cuda)
+        assert mlp_mod._small_ok(dpop, dobs, net.sizes, act, fin)
+        got = net.batched_apply(dpop, dobs)
+        assert got.shape == (P, E, sizes[-1])
+        torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=2e-5)
+        assert torch.equal(got, net.batched_apply(dpop, dobs))                 # same bits on every call
+        assert dpop._evox_wt[1].shape == (net.n_params, P)
+        dpop.mul_(0.5)                                                          # in place: the copy must be rebuilt
+        torch.testing.assert_close(net.batched_apply(dpop, dobs).cpu(), net.batched_apply(pop * 0.5, obs), rtol=2e-4, atol=2e-5)
+    net = MLP(list(sizes))
+    pop = torch.randn(P, net.n_params + 5, generator=g) * 0.3
+    obs = torch.randn(P, E, sizes[0], generator=g)
+    view = pop.to(cuda)[:, 2:2 + net.n_params]                                 # rows that do not start at the pitch
+    torch.testing.assert_close(net.batched_apply(view, obs.to(cuda)).cpu(), net.batched_apply(pop[:, 2:2 + net.n_params], obs),
+                               rtol=2e-4, atol=2e-5)
+    p16 = pop[:, :net.n_params].bfloat16()
+    torch.testing.assert_close(net.batched_apply(p16.to(cuda), obs.to(cuda)).cpu(), net.batched_apply(p16.float(), obs),
+                               rtol=2e-4, atol=2e-5)
+    # 2-D observations (one per individual)
+    torch.testing.assert_close(net.batched_apply(view, obs.to(cuda)[:, 0]).cpu(), net.batched_apply(pop[:, 2:2 + net.n_params], obs[:, 0]),
+                               rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("sizes", [(11, 32, 32, 3), (27, 64, 64, 8), (5, 8, 2)])
+@pytest.mark.parametrize("P,E", [(512, 1), (1000, 2)])
+def test_small_mlp_kernel_evaluates_mirrored_pairs_from_one_half(cuda, sizes, P, E, monkeypatch):
+    """A mirrored population (``ops.es.perturb`` marks it) is evaluated from its first half and the centre — the second
+    half is never read, overwriting it changes nothing — and agrees with the row-by-row evaluation and the host."""
+    import evox_amd as ex
+    from evox_amd.models import MLP
+    from evox_amd.ops import es
+
+    monkeypatch.setenv("EVOX_AMD_MLP_SMALL", "1")
+    monkeypatch.setenv("EVOX_AMD_MLP_MIRROR", "1")
+    net = MLP(list(sizes))
+    center = net.init(ex.PRNGKey(3)).to(cuda) * 0.5
+    pop = es.perturb(ex.PRNGKey(4).to(cuda), center, 0.1, P, mirrored=True)
+    assert getattr(pop, "_evox_mirror", None) is not None
+    obs = torch.randn(P, E, sizes[0], generator=torch.Generator().manual_seed(P)).to(cuda)
+    got = net.batched_apply(pop, obs)
+    assert pop._evox_wt[1].shape == (net.n_params, P // 2)
+    want = net.batched_apply(pop.cpu(), obs.cpu())
+    torch.testing.assert_close(got.cpu(), want, rtol=2e-4, atol=5e-5)
+    plain = pop.clone()                                                         # no mark: every row is read
+    torch.testing.assert_close(net.batched_apply(plain, obs), got, rtol=2e-4, atol=5e-5)
+    scrambled = pop.clone()
+    scrambled._evox_mirror = pop._evox_mirror
+    scrambled[P // 2:] = 7.0                                                    # the mirrored half is rebuilt, not read
+    assert torch.equal(net.batched_apply(scrambled, obs), got)
+
+
+def test_small_mlp_route_follows_the_measurements(cuda):
+    from evox_amd.models import MLP
+    from evox_amd.models import mlp as mlp_mod
+
+    def route(sizes, P):
+        net = MLP(list(sizes))
+        return mlp_mod._small_ok(torch.empty(P, net.n_params, device=cuda), torch.empty(P, 1, sizes[0], device=cuda), net.sizes,
+                                 "tanh", "tanh")
+
+    assert route((11, 32, 32, 3), 4096) and route((11, 32, 32, 3), 16384) and route((27, 64, 64, 8), 16384)
+    assert not route((27, 32, 32, 8), 4096)                  # 36 MB: more than the L2 holds between time steps
+    assert not route((11, 32, 32, 3), 512) and not route((27, 64, 64, 8), 4096) and not route((244, 1024, 720, 17), 16384)
+
+
 def test_cmaes_gpu_tracks_cpu(cuda):
     """The GPU tell (gather kernel, fused path kernel, library GEMMs) follows the host formulas."""
     import evox_amd as ex
