@@ -54,25 +54,46 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
     prim = row_codes[4 * r]; sec = row_codes[4 * r + 1]; num_diff = row_codes[4 * r + 2]; cross = row_codes[4 * r + 3];
   }
 
-  // ---- distinct picks (ascending list `taken` starts with the row itself) -------------------
+  // ---- the row's random draws, one per lane: draw j < n_picks is pick j, draw kMaxPicks the crossover column.  A
+  // Philox block is a hundred instructions; every lane of the row computing all ten draws made the kernel bound by
+  // them.  The lanes of a row are neighbours in the wave, so the draws are handed round with shuffles.
   const uint32_t s0 = (uint32_t)key_sel[0], s1 = (uint32_t)key_sel[1];
+  const uint32_t j0 = (uint32_t)key_jrand[0], j1 = (uint32_t)key_jrand[1];
+  constexpr int kDraws = kMaxPicks + 1;
+  constexpr int ROUNDS = (kDraws + LPR - 1) / LPR;
+  uint32_t mine[ROUNDS];
+#pragma unroll
+  for (int q = 0; q < ROUNDS; ++q) {
+    const int dno = q * LPR + sub;
+    uint32_t v = 0;
+    if (dno < n_picks) v = bits_to_range(bits_at(s0, s1, (uint64_t)r * n_picks + dno), (uint32_t)(n_pop - 1 - dno));
+    else if (dno == kMaxPicks) v = bits_to_range(bits_at(j0, j1, (uint64_t)r), (uint32_t)dim);
+    mine[q] = v;
+  }
+  const int row_lane0 = (int)(threadIdx.x & 63) - sub;       // first lane of this row in its wave
+  // ---- distinct picks (ascending list `taken` starts with the row itself) -------------------
   int picks[kMaxPicks];
   int taken[kMaxPicks + 1];
   taken[0] = (int)self;
-  int n_taken = 1;
-  for (int j = 0; j < n_picks; ++j) {
-    const uint32_t m = (uint32_t)(n_pop - 1 - j);
-    int v = (int)bits_to_range(bits_at(s0, s1, (uint64_t)r * n_picks + j), m);
-    for (int t = 0; t < n_taken; ++t) v += (v >= taken[t]) ? 1 : 0;
-    picks[j] = v;
-    int pos = n_taken;                                 // insert, keeping `taken` ascending
-    while (pos > 0 && taken[pos - 1] > v) { taken[pos] = taken[pos - 1]; --pos; }
-    taken[pos] = v;
-    ++n_taken;
+#pragma unroll
+  for (int j = 0; j < kMaxPicks; ++j) {
+    picks[j] = 0;
+    if (j < n_picks) {                                         // uniform
+      int v = (int)__shfl(mine[j / LPR], row_lane0 + j % LPR, 64);
+#pragma unroll
+      for (int t = 0; t <= j; ++t) v += (v >= taken[t]) ? 1 : 0;      // `taken` holds j + 1 values, ascending
+      picks[j] = v;
+      // insert, keeping `taken` ascending
+#pragma unroll
+      for (int t = j + 1; t > 0; --t) {
+        const bool up = taken[t - 1] > v;                      // everything above v moves one place up
+        if (t == j + 1) taken[t] = up ? taken[t - 1] : v;
+        else taken[t] = up ? taken[t - 1] : (taken[t] > v ? v : taken[t]);
+      }
+      if (taken[0] > v) taken[0] = v;
+    }
   }
-
-  const uint32_t j0 = (uint32_t)key_jrand[0], j1 = (uint32_t)key_jrand[1];
-  const int jrand = (int)bits_to_range(bits_at(j0, j1, (uint64_t)r), (uint32_t)dim);
+  const int jrand = (int)__shfl(mine[kMaxPicks / LPR], row_lane0 + kMaxPicks % LPR, 64);
   const uint32_t m0 = (uint32_t)key_mask[0], m1 = (uint32_t)key_mask[1];
   const float f = f_is_vec ? F[r] : F[0];
   const float cr = cr_is_vec ? CR[r] : CR[0];
