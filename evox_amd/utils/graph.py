@@ -8,7 +8,7 @@ a HIP graph and replaying it.
 ``GraphedStep(fn)`` wraps a function ``state -> state`` (or ``state -> (state, aux)``) whose
 tensors live on one GPU.  Two ways of feeding the recording:
 
-``mode="ring"`` (default) – pointer-stable.  ``ring`` recordings are chained: the first reads a set of static input
+``mode="ring"`` (default) – pointer-stable.  ``ring`` recordings (eight for states up to 64 MB, four up to 512 MB, else two) are chained: the first reads a set of static input
   buffers, every further one reads the outputs of its predecessor, and the last one ends (inside the recording) with
   a copy of its output state into the static input buffers, which are what it hands back.  The caller gets the
   recordings' own output tensors, not clones; as long as it passes them back unchanged (the normal
@@ -56,7 +56,7 @@ def _signature(leaves):
 
 class GraphedStep:
     def __init__(self, fn: Callable, warmup: int = 2, clone_outputs: bool = True, host_counters=(), mode: str = "ring",
-                 ring: int = 2):
+                 ring=None):
         """``host_counters``: tree paths (as reported by ``tree_paths``) of integer state leaves that
         the step advances by a constant and never uses in its device work – they are advanced on
         the host at replay; a ``(path, modulus)`` pair names a counter that wraps around.  Any other host value that
@@ -65,7 +65,8 @@ class GraphedStep:
         if mode not in ("ring", "copy"):
             raise ValueError("mode must be 'ring' or 'copy'")
         self.fn, self.warmup, self.clone_outputs = fn, warmup, clone_outputs
-        self.mode, self.ring = mode, max(1, int(ring))
+        # ring: recordings in the chain; None: chosen at capture from the size of the state (see ``_ring_length``)
+        self.mode, self.ring = mode, (None if ring is None else max(1, int(ring)))
         # path -> modulus (None: plain counter); entries are paths or (path, modulus) pairs
         self.host_counters = {(c if isinstance(c, str) else c[0]): (None if isinstance(c, str) else int(c[1]))
                               for c in host_counters}
@@ -73,6 +74,18 @@ class GraphedStep:
         self._sig = None
         self.replays = 0
         self.copies_in = 0          # replays that had to copy the caller's state into the static buffers
+
+    @staticmethod
+    def _ring_length(state_bytes: int) -> int:
+        """The state is copied back into the first recording's inputs once per turn of the ring — one copy node per leaf,
+        each a few µs on the replay's critical path (SHADE at 50 000 individuals: ten leaves, 30 µs of a 130 µs
+        generation with two recordings) — so the ring is long where memory allows: every recording keeps its own
+        outputs and intermediates, a few times the state."""
+        if state_bytes <= 64 << 20:
+            return 8
+        if state_bytes <= 512 << 20:
+            return 4
+        return 2
 
     # ------------------------------------------------------------------------------------
     def _record(self, graph, state, pool, feedback_to=None):
@@ -147,6 +160,8 @@ class GraphedStep:
                 self.fn(static_state)
         torch.cuda.current_stream(self.device).wait_stream(side)
 
+        if self.ring is None:
+            self.ring = self._ring_length(sum(l.numel() * l.element_size() for l in leaves if isinstance(l, torch.Tensor)))
         n_rec = self.ring if self.mode == "ring" else 1
         pool = torch.cuda.graph_pool_handle()
         in_tensors = [self._static_in[i] for i in self._tensor_pos]
