@@ -75,6 +75,8 @@ class GraphedStep:
         self.replays = 0
         self.copies_in = 0          # replays that had to copy the caller's state into the static buffers
 
+    _RING_BYTES = 4 << 30            # memory the recordings of one ring may hold together
+
     @staticmethod
     def _ring_length(state_bytes: int) -> int:
         """The state is copied back into the first recording's inputs once per turn of the ring — one copy node per leaf,
@@ -167,10 +169,17 @@ class GraphedStep:
         in_tensors = [self._static_in[i] for i in self._tensor_pos]
         self._graphs, self._outs, self._counter_sets = [], [], []
         cur_state, cur_leaves = static_state, list(self._static_in)
-        for j in range(n_rec):
+        j = 0
+        while j < n_rec:
             graph = torch.cuda.CUDAGraph()
             last = self.mode == "ring" and j == n_rec - 1
+            before = torch.cuda.memory_allocated(self.device)
             out = self._record(graph, cur_state, pool, feedback_to=in_tensors if last else None)
+            if j == 0 and n_rec > 2:
+                # every recording keeps its outputs and intermediates (a population can be many times the state): the
+                # ring is shortened so that all of them stay within a few GiB
+                grown = max(torch.cuda.memory_allocated(self.device) - before, 1)
+                n_rec = self.ring = max(2, min(n_rec, self._RING_BYTES // grown))
             out_leaves, out_treedef = _tree.tree_flatten(out)
             out_state = out[0] if isinstance(out, tuple) else out
             st_leaves, st_treedef = _tree.tree_flatten(out_state)
@@ -189,6 +198,7 @@ class GraphedStep:
             # (see ``graph_variant`` in the workflow) must be the same in every recording of the ring.
             cur_leaves = [n if isinstance(n, torch.Tensor) else o for o, n in zip(self._static_in, st_leaves)]
             cur_state = _tree.tree_unflatten(treedef, cur_leaves)
+            j += 1
         self._n_state_leaves = len(cur_leaves)
         self.graph = self._graphs[0]
         self._static_out = self._outs[0]

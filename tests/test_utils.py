@@ -1,5 +1,6 @@
 """``TreeAndVector`` round trips (reference ``tests/test_utils.py:9-36``), optimisers, rank
 helpers, aggregation functions and the Gaussian-process operators."""
+import pytest
 import torch
 
 import evox_amd as ex
@@ -144,3 +145,37 @@ def test_rank_launcher_relays_rank0_and_fails_fast(tmp_path):
     t0 = time.time()
     assert launch.launch_ranks(str(bad), [], 3) == 7
     assert time.time() - t0 < 30
+
+
+@pytest.mark.gpu
+def test_graph_ring_length_follows_state_size_and_memory():
+    """Pointer-stable replay chains eight recordings for a small state; a step whose outputs are large (every recording
+    keeps its own) gets a shorter ring, and replays stay correct across several turns of the ring."""
+    from evox_amd.core.state import State
+    from evox_amd.utils.graph import GraphedStep
+
+    dev = torch.device("cuda")
+
+    def small(state):
+        return state.replace(x=state.x * 1.5 + 1.0, n=state.n + 1)
+
+    g = GraphedStep(small, host_counters=("fields/n",))
+    s = State(x=torch.ones(1000, device=dev), n=0)
+    for _ in range(21):
+        s = g(s)
+    torch.cuda.synchronize()
+    ref = torch.ones((), dtype=torch.float64)
+    for _ in range(21):
+        ref = ref * 1.5 + 1.0
+    assert g.ring == 8 and s.n == 21
+    torch.testing.assert_close(s.x[0].double().cpu(), ref, rtol=1e-5, atol=0)
+
+    def big(state):                                          # 1.5 GiB of auxiliary output per recording
+        return state.replace(x=state.x + 1.0), torch.zeros(3 * 2 ** 27, device=dev) + state.x[0]
+
+    g2 = GraphedStep(big)
+    s2 = State(x=torch.zeros(8, device=dev))
+    for _ in range(7):
+        s2, aux = g2(s2)
+    torch.cuda.synchronize()
+    assert g2.ring == 2 and float(s2.x[0]) == 7.0 and float(aux[5]) == 6.0
