@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void de_trial_kernel(
 #pragma unroll
   for (int q = 0; q < ROUNDS; ++q) {
     const int dno = q * LPR + sub;
-    uint32_t v = 0;
-    if (dno < n_picks) v = bits_to_range(bits_at(s0, s1, (uint64_t)r * n_picks + dno), (uint32_t)(n_pop - 1 - dno));
-    else if (dno == kMaxPicks) v = bits_to_range(bits_at(j0, j1, (uint64_t)r), (uint32_t)dim);
-    mine[q] = v;
+    // one Philox evaluation for the wave: the lanes differ in key, element and range, not in code
+    const bool pick = dno < n_picks, col = dno == kMaxPicks;
+    const uint32_t ka = pick ? s0 : j0, kb = pick ? s1 : j1;
+    const uint64_t e = pick ? (uint64_t)r * n_picks + dno : (uint64_t)r;
+    const uint32_t range = pick ? (uint32_t)(n_pop - 1 - dno) : (uint32_t)dim;
+    mine[q] = (pick || col) ? bits_to_range(bits_at(ka, kb, e), range) : 0u;
   }
   const int row_lane0 = (int)(threadIdx.x & 63) - sub;       // first lane of this row in its wave
   // ---- distinct picks (ascending list `taken` starts with the row itself) -------------------
