@@ -48,6 +48,7 @@ _HIP_API = {
     "evox_hip_normal_bf16": (I, [P, P, I64, I64, F, F, P]),
     "evox_hip_randint": (I, [P, P, I64, I64, I64, I64, P]),
     "evox_hip_split": (I, [P, P, I64, I64, P]),
+    "evox_hip_split_nested": (I, [P, P, I, I, I, P]),
     "evox_hip_fold_in": (I, [P, P, I64, I64, P]),
 }
 

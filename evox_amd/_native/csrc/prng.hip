@@ -170,6 +170,31 @@ EVOX_API int evox_hip_split(const int32_t* keys, int32_t* out, int64_t nkeys, in
   return last_launch_status();
 }
 
+// Two levels of splitting in one launch: out[0, n1) = the n1 children of `key`, out[n1, n1 + n2) = the n2 children of
+// child `which` — what split(key, n1) followed by split(children[which], n2) gives.
+namespace {
+__global__ void split_nested_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ out, int n1, int which, int n2) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n1 + n2) return;
+  uint32_t k0 = (uint32_t)key[0], k1 = (uint32_t)key[1];
+  uint64_t i = (uint64_t)t;
+  if (t >= n1) {
+    const u32x4 parent = philox_block(k0, k1, (uint64_t)which, kStreamSplit);
+    k0 = parent.x; k1 = parent.y;
+    i = (uint64_t)(t - n1);
+  }
+  const u32x4 b = philox_block(k0, k1, i, kStreamSplit);
+  out[2 * t] = (int32_t)b.x;
+  out[2 * t + 1] = (int32_t)b.y;
+}
+}  // namespace
+
+EVOX_API int evox_hip_split_nested(const int32_t* key, int32_t* out, int n1, int which, int n2, void* stream) {
+  if (n1 < 1 || n2 < 1 || which < 0 || which >= n1) return (int)hipErrorInvalidValue;
+  split_nested_kernel<<<(n1 + n2 + 63) / 64, 64, 0, (hipStream_t)stream>>>(key, out, n1, which, n2);
+  return last_launch_status();
+}
+
 EVOX_API int evox_hip_split_count(const int32_t* key, int32_t* out, int64_t n, const float* count_in, float* count_out,
                                   void* stream) {
   if (n < 0 || (n == 0 && count_out == nullptr)) return (int)hipErrorInvalidValue;     // n == 0: the counter alone

@@ -160,7 +160,18 @@ class DEBase(Algorithm):
 
         pop, fit = state.population, state.fitness
         dev = pop.device
-        k_sel, k_pb, k_x = rnd.split(key, 3)
+        from ....ops import de as _de
+        static_codes = all(isinstance(v, int) for v in (prim, sec, num_diff, cross))
+        n_picks_early = min(diff_padding_num, 2 * num_diff + 1) if isinstance(num_diff, int) else diff_padding_num
+        fused = _de.supported(pop, prim, sec, num_diff, cross, n_picks_early, replace, code_sets)
+        fused_keys = None
+        if fused and static_codes:
+            # every key of the fused launch in one split: (selection, p-best, crossover) and the crossover key's two children
+            ks = rnd.split_nested(key, 3, 2, 2)
+            k_sel, k_pb, k_x = ks[0], ks[1], ks[2]
+            fused_keys = (ks[0], ks[3], ks[4])
+        else:
+            k_sel, k_pb, k_x = rnd.split(key, 3)
         # Blocked instance: everything below runs over virtual rows (individual, block) -> individual * B + block of
         # the population viewed as (pop_size * B, block_dim); parents are individuals, taken from the row's own block.
         B = self.blocks
@@ -196,12 +207,11 @@ class DEBase(Algorithm):
         def finish(trial_v):
             return torch.clamp(trial_v.reshape(rows_out, self.dim), self.lb, self.ub)
 
-        from ....ops import de as _de
-        if _de.supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets):
+        if fused:
             # GPU: one fused launch (same random elements as the formulation below)
             pbest_rows = pbest_individuals() if (not static_nd or PBEST in (prim, sec)) else None
             return _de.de_trial(key, pop, idx, state.best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks,
-                                self.lb, self.ub, cross, blocks=B).reshape(rows_out, self.dim)
+                                self.lb, self.ub, cross, blocks=B, keys=fused_keys).reshape(rows_out, self.dim)
         if replace:
             picks = rnd.randint(k_sel, (b, n_picks), 0, self.pop_size)
             picks = torch.where(picks == who[:, None], torch.full_like(picks, self.pop_size - 1), picks)

@@ -75,6 +75,20 @@ def split(key: torch.Tensor, num: int = 2) -> torch.Tensor:
     return out
 
 
+def split_nested(key: torch.Tensor, num: int, which: int, sub: int) -> torch.Tensor:
+    """``split(key, num)`` followed by ``split(children[which], sub)``, as one ``(num + sub, 2)`` tensor — on the GPU one
+    launch instead of two (a generation of a small algorithm is a dozen launches, key handling several of them)."""
+    _check_key(key)
+    if key.is_cuda and key.numel() == 2:
+        k = key.contiguous()
+        out = torch.empty((num + sub, 2), dtype=torch.int32, device=k.device)
+        _native.check(_native.hip().evox_hip_split_nested(k.data_ptr(), out.data_ptr(), int(num), int(which), int(sub), _stream(k)),
+                      "split_nested")
+        return out
+    first = split(key, num)
+    return torch.cat([first, split(first[which], sub)], dim=0)
+
+
 def fold_in(key: torch.Tensor, data: int) -> torch.Tensor:
     """Derive a key from ``key`` and an integer (e.g. a generation or rank number)."""
     _check_key(key)

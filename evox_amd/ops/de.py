@@ -40,7 +40,8 @@ def supported(pop, prim, sec, num_diff, cross, n_picks, replace, code_sets=None)
             and n_picks >= 5)
 
 
-def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub, cross=BIN, blocks=1):
+def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, n_picks, lb, ub, cross=BIN, blocks=1,
+             keys=None):
     """Trial vectors for the rows ``idx`` of ``pop``; ``key`` is split exactly as the PyTorch path does
     (selection / pbest / crossover → jrand, mask).  ``prim, sec, num_diff, cross`` are ints, or all four
     per-row integer tensors.
@@ -48,7 +49,8 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
     ``blocks`` > 1: every row of ``pop`` is ``blocks`` independent sub-vectors (stacked members of a container);
     ``idx``, ``F``, ``CR`` and ``pbest_rows`` then run over the virtual rows ``individual * blocks + block``
     (``pbest_rows`` still names individuals), and the result has one row per entry of ``idx``; a ``best_index`` of
-    ``blocks`` entries names the best individual of every block."""
+    ``blocks`` entries names the best individual of every block.  ``keys``: ``(selection, jrand, mask)`` keys already derived
+    from ``key`` by the caller (static strategies), which saves the two split launches here."""
     dev = pop.device
     if best_index.numel() not in (1, blocks):
         raise ValueError("best_index: one individual, or one per block")
@@ -58,14 +60,18 @@ def de_trial(key, pop, idx, best_index, pbest_rows, prim, sec, num_diff, F, CR, 
     if blocks > 1:
         pop = pop.view(n_pop * blocks, pop.shape[1] // blocks)
     b, dim = idx.shape[0], pop.shape[1]
-    k_sel, _k_pb, k_x = rnd.split(key, 3)
     per_row = isinstance(prim, torch.Tensor)
+    if keys is not None and not per_row:
+        k_sel, k_r, k_m = keys                               # derived by the caller (``random.split_nested(key, 3, 2, 2)``)
+    else:
+        k_sel, _k_pb, k_x = rnd.split(key, 3)
+        if per_row:
+            # the tensor formulation gives the binomial crossover the first half of a further split
+            k_x = rnd.split(k_x)[0]
+        k_r, k_m = rnd.split(k_x)
     if per_row:
-        # the tensor formulation gives the binomial crossover the first half of a further split
-        k_x = rnd.split(k_x)[0]
         codes = torch.stack([prim, sec, num_diff, cross], dim=1).to(device=dev, dtype=torch.int32).contiguous()
         prim = sec = num_diff = cross = 0
-    k_r, k_m = rnd.split(k_x)
     f, f_vec = _vec(F, b, dev)
     cr, cr_vec = _vec(CR, b, dev)
     out = torch.empty((b, dim), dtype=torch.float32, device=dev)

@@ -515,6 +515,17 @@ def test_small_mlp_route_follows_the_measurements(cuda):
     assert not route((11, 32, 32, 3), 512) and not route((27, 64, 64, 8), 4096) and not route((244, 1024, 720, 17), 16384)
 
 
+def test_nested_key_split_equals_two_splits(cuda):
+    from evox_amd.core import random as rnd
+
+    key = rnd.PRNGKey(123)
+    for num, which, sub in ((3, 2, 2), (5, 0, 4), (2, 1, 70)):
+        first = rnd.split(key, num)
+        want = torch.cat([first, rnd.split(first[which], sub)], dim=0)
+        assert torch.equal(rnd.split_nested(key, num, which, sub), want)                 # host: by construction
+        assert torch.equal(rnd.split_nested(key.to(cuda), num, which, sub).cpu(), want)   # one launch
+
+
 def test_cmaes_gpu_tracks_cpu(cuda):
     """The GPU tell (gather kernel, fused path kernel, library GEMMs) follows the host formulas."""
     import evox_amd as ex
