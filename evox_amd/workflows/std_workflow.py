@@ -348,7 +348,11 @@ class StdWorkflow(Workflow):
                 name = c if isinstance(c, str) else c[0]  # a name with a "/" is a path below the algorithm's state (containers)
                 path = f"children/algorithm/{name}" if "/" in name else f"children/algorithm/fields/{name}"
                 counters.append(path if isinstance(c, str) else (path, c[1]))
-            graphed = self._graphed[variant] = GraphedStep(self._bare_step, host_counters=counters, mode=self.graph_mode)
+            # an algorithm that asks for new recordings while it runs (the factorisation control of CMA-ES) keeps the
+            # short ring: recording is the expensive part there, and it is paid per recording of the ring
+            rerecords = any(callable(getattr(self.algorithm, h, None)) for h in ("graph_retune", "graph_check"))
+            graphed = self._graphed[variant] = GraphedStep(self._bare_step, host_counters=counters, mode=self.graph_mode,
+                                                           ring=2 if rerecords else None)
         hooks = self.registered_hooks
         for m in hooks["pre_step"]:
             m.pre_step(state)
