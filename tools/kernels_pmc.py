@@ -150,6 +150,8 @@ for _ in range(2):
     A100 = torch.randn(100, 100, device=dev); C100 = A100 @ A100.T / 100 + 0.1 * torch.eye(100, device=dev)
     ev, V = _ls.eigh_small(C100, None, spd=True)                                          # cholesky_lds + eigh_spd_kernel
     ev, V = _ls.eigh_small(C100 * 1.01, V, spd=True)                                      # warm start
+    net_s = MLP([11, 32, 32, 3])
+    a_s = net_s.batched_apply(torch.randn(16384, net_s.n_params, device=dev) * 0.1, torch.randn(16384, 1, 11, device=dev))   # mlp_small_kernel
     for task in ("hopper", "ant"):
         env = make_tensor_env(task)
         est, ob = env.reset(rnd.PRNGKey(5).to(dev), 4096, dev)
