@@ -170,6 +170,21 @@ class SHADE(JaDE):
                              Memory_FCR=memory)
 
 
+def _newest_first(sel, values, depth):
+    """Per column of the mask ``sel`` (rows, columns): the ``values`` of its selected rows, highest row index first, the
+    first ``depth`` of them, NaN-padded — without a sort: a selected row's place is the number of selected rows behind it
+    (a reversed cumulative sum), and the places of a column are distinct, so one scatter writes them (rows that are not
+    selected, or lie deeper than ``depth``, go to a spare row)."""
+    rows, cols = sel.shape
+    st = sel.t().contiguous()                                                    # scans run along the contiguous dimension
+    counts = st.to(torch.int32)
+    behind = (counts.sum(1, keepdim=True) - torch.cumsum(counts, dim=1)).to(torch.int64)     # selected rows with a higher index
+    place = torch.where(st & (behind < depth), behind, torch.full_like(behind, depth))
+    buf = torch.full((cols, depth + 1), float("nan"), dtype=values.dtype, device=values.device)
+    buf.scatter_(1, place, values[None, :].expand(cols, rows))
+    return buf[:, :depth].t()
+
+
 # strategy tables: (primary base, secondary base, #difference vectors, crossover)
 _RAND_1_BIN = (RAND, RAND, 1, BIN)
 _RAND2BEST_2_BIN = (RAND, BEST, 2, BIN)
@@ -242,12 +257,7 @@ class SaDE(DEBase):
         # column of the LP-deep memory — all four columns at once
         B, LP, dev = state.CRs.shape[0], self.LP, state.CRs.device
         sel = ok[:, None] & onehot.bool()                                         # (B, 4)
-        newest_first = torch.argsort(sel.to(torch.int64) * (torch.arange(B, device=dev)[:, None] + 1), dim=0,
-                                     descending=True, stable=True)                # successful rows, highest index first
-        vals = torch.where(torch.gather(sel, 0, newest_first), state.CRs[newest_first],
-                           torch.full((), float("nan"), device=dev))[:LP]          # (min(B, LP), 4)
-        if vals.shape[0] < LP:
-            vals = torch.cat([vals, torch.full((LP - vals.shape[0], 4), float("nan"), device=dev)], dim=0)
+        vals = _newest_first(sel, state.CRs, LP)                                  # (LP, 4), NaN where a column has fewer
         cnt = sel.sum(0).clamp(max=LP)                                            # (4,)
         pos = torch.arange(LP, device=dev)[:, None]
         shifted = torch.gather(state.CR_memory, 0, (pos - cnt).clamp_min(0))

@@ -194,3 +194,22 @@ def test_newton_schulz_plan_picks_the_driver_by_conditioning():
     for stored, want in ((1, (True, False, 2)), (2, (True, True, 2)), (3, (True, True, 3)), (0, (False, False, 2))):
         pl = ns.plan(dict(ctrl, ns_calls=5, ns_sym=stored), True, True, True)
         assert (pl["symmetric"], pl["full"], pl["planes"]) == want
+
+
+def test_sade_memory_push_matches_the_sort_formulation():
+    """The values of a column's selected rows, newest (highest row) first, NaN-padded: the cumulative-sum scatter against
+    the stable-sort formulation it replaced."""
+    from evox_amd.algorithms.so.de_variants.adaptive import _newest_first
+
+    g = torch.Generator().manual_seed(0)
+    for rows, depth in ((100, 50), (30, 50), (1024, 50), (7, 3)):
+        for _ in range(5):
+            sel = torch.rand(rows, 4, generator=g) < torch.rand(1, generator=g)
+            values = torch.rand(rows, generator=g)
+            order = torch.argsort(sel.to(torch.int64) * (torch.arange(rows)[:, None] + 1), dim=0, descending=True, stable=True)
+            want = torch.where(torch.gather(sel, 0, order), values[order], torch.full((), float("nan")))[:depth]
+            if want.shape[0] < depth:
+                want = torch.cat([want, torch.full((depth - want.shape[0], 4), float("nan"))], dim=0)
+            got = _newest_first(sel, values, depth)
+            assert torch.equal(torch.isnan(got), torch.isnan(want))
+            assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
