@@ -143,7 +143,9 @@ def weighted_noise_sum(key, w, dim: int, v=None, row_offset: int = 0):
         # rows are split over blockIdx.y so that narrow problems still fill the chip; partial
         # sums land in a [splits][dim] slab and are added in a fixed order
         col_threads = (dim + 3) // 4
-        splits = max(1, min(64, (256 * 256 * 4) // max(col_threads, 1), n // 64 if n >= 64 else 1))
+        # (a thread regenerates ~200 instructions of noise per row: with few columns the rows must be spread thin — 8 rows
+        # per thread took 75 -> 15 us for 2048 rows of a 1.5 k-parameter policy)
+        splits = max(1, min(512, (256 * 256 * 4) // max(col_threads, 1), n // 8 if n >= 8 else 1))
         slab = torch.empty((2 if v is not None else 1, splits, dim), dtype=torch.float32, device=dev)
         check(hip().evox_hip_noise_wsum(key.contiguous().data_ptr(), w.data_ptr(), vv.data_ptr() if vv is not None else None,
                                         slab[0].data_ptr(), slab[1].data_ptr() if v is not None else None, None,
