@@ -1,17 +1,55 @@
-// Particle-swarm update as two launches:
+// Particle-swarm update as two launches (three for long swarms):
 //   1. pso_best_kernel  – one workgroup scans the swarm: new personal-best fitness, arg-min,
-//                         and whether the global best improves (N is at most a few 1e5, a
-//                         single 1024-thread group streams it in microseconds and needs no
-//                         inter-workgroup hand-off).
+//                         and whether the global best improves.  Beyond 32 768 particles the scan is
+//                         spread over up to 1024 workgroups (pso_best_part_kernel) whose partial minima
+//                         one workgroup merges (pso_best_final_kernel): one workgroup streams 10⁶
+//                         fitness pairs in about a millisecond, as long as the whole move takes.
 //   2. pso_move_kernel  – elementwise over N x D: personal-best rows, velocity and position
 //                         with two Philox uniforms per coordinate generated in registers
-//                         (element e of the logical (2, N, D) draw), clamping to the bounds.
+//                         (element e of the logical (2, N, D) draw), clamping to the bounds.  With a
+//                         dimension divisible by four (and 16-byte aligned operands) a lane moves four
+//                         coordinates of one row with 16-byte loads and stores and one row division.
+#include <algorithm>
+#include <cstdint>
+
 #include "hip_common.h"
 #include "philox.h"
 
 using namespace evox;
 
 namespace {
+
+constexpr int kBestParts = 1024;          // most workgroups of the spread scan; ws holds 2 + 2·kBestParts words
+constexpr int64_t kBestSpread = 32768;    // swarms beyond this size take the spread scan
+
+__device__ inline void best_merge(float& best, int& best_i, float ov, int oi) {
+  if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+}
+
+// The (minimum, lowest index) of a workgroup's lanes, valid in thread 0.
+__device__ inline void best_of_workgroup(float& best, int& best_i, float* s_val, int* s_idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(best_i, o, 64);
+    best_merge(best, best_i, ov, oi);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_i; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x >> 6;
+    for (int w = 1; w < nw; ++w) best_merge(best, best_i, s_val[w], s_idx[w]);
+  }
+}
+
+__device__ inline void best_publish(float best, int best_i, const float* gbest_fit, float* o_gfit, int* ws) {
+  const float g = gbest_fit[0];
+  const int take = (best_i != 0x7fffffff) && (best < g);
+  ws[0] = best_i == 0x7fffffff ? 0 : best_i;
+  ws[1] = take;
+  o_gfit[0] = take ? best : g;
+}
 
 __global__ __launch_bounds__(1024) void pso_best_kernel(const float* __restrict__ fit, const float* __restrict__ pbest_fit,
                                                         const float* __restrict__ gbest_fit, float* __restrict__ o_pfit,
@@ -24,29 +62,47 @@ __global__ __launch_bounds__(1024) void pso_best_kernel(const float* __restrict_
     const float f = fit[i], p = pbest_fit[i];
     const float m = f < p ? f : p;
     o_pfit[i] = m;
-    if (m < best || (m == best && (int)i < best_i)) { best = m; best_i = (int)i; }
+    best_merge(best, best_i, m, (int)i);
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(best_i, o, 64);
-    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+  best_of_workgroup(best, best_i, s_val, s_idx);
+  if (threadIdx.x == 0) best_publish(best, best_i, gbest_fit, o_gfit, ws);
+}
+
+__global__ __launch_bounds__(256) void pso_best_part_kernel(const float* __restrict__ fit, const float* __restrict__ pbest_fit,
+                                                            float* __restrict__ o_pfit, int* __restrict__ ws, int64_t n) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  float best = INFINITY;
+  int best_i = 0x7fffffff;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float f = fit[i], p = pbest_fit[i];
+    const float m = f < p ? f : p;
+    o_pfit[i] = m;
+    best_merge(best, best_i, m, (int)i);
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_i; }
-  __syncthreads();
+  best_of_workgroup(best, best_i, s_val, s_idx);
   if (threadIdx.x == 0) {
-    const int nw = blockDim.x >> 6;
-    for (int w = 1; w < nw; ++w)
-      if (s_val[w] < best || (s_val[w] == best && s_idx[w] < best_i)) { best = s_val[w]; best_i = s_idx[w]; }
-    const float g = gbest_fit[0];
-    const int take = (best_i != 0x7fffffff) && (best < g);
-    ws[0] = best_i == 0x7fffffff ? 0 : best_i;
-    ws[1] = take;
-    o_gfit[0] = take ? best : g;
+    ws[2 + blockIdx.x] = __float_as_int(best);
+    ws[2 + kBestParts + blockIdx.x] = best_i;
   }
 }
 
+__global__ __launch_bounds__(1024) void pso_best_final_kernel(const float* __restrict__ gbest_fit, float* __restrict__ o_gfit,
+                                                              int* __restrict__ ws, int parts) {
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  float best = INFINITY;
+  int best_i = 0x7fffffff;
+  if ((int)threadIdx.x < parts) {
+    best = __int_as_float(ws[2 + threadIdx.x]);
+    best_i = ws[2 + kBestParts + threadIdx.x];
+    if (best_i == 0x7fffffff) best = INFINITY;
+  }
+  best_of_workgroup(best, best_i, s_val, s_idx);
+  if (threadIdx.x == 0) best_publish(best, best_i, gbest_fit, o_gfit, ws);
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void pso_move_kernel(
     const int32_t* __restrict__ key, const float* __restrict__ pop, const float* __restrict__ vel,
     const float* __restrict__ fit, const float* __restrict__ pbest, const float* __restrict__ pbest_fit,
@@ -60,6 +116,39 @@ __global__ __launch_bounds__(256) void pso_move_kernel(
   const bool take = ws[1] != 0;
   const bool best_improved = fit[best_i] < pbest_fit[best_i];
   const float* best_row = (best_improved ? pop : pbest) + (int64_t)best_i * d;
+  if constexpr (VEC) {
+    // d % 4 == 0: the four coordinates of a quad lie in one row, and the second random tensor starts on a block boundary
+    const bool narrow = total < ((int64_t)1 << 31);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e = 4 * q;
+      const int64_t row = narrow ? (int64_t)((uint32_t)e / (uint32_t)d) : e / d;
+      const int col = (int)(e - row * d);
+      const f32x4 rp = unit4(philox_block(k0, k1, (uint64_t)q, kStreamDraw));
+      const f32x4 rg = unit4(philox_block(k0, k1, (uint64_t)(total + e) >> 2, kStreamDraw));
+      const float4 x = *reinterpret_cast<const float4*>(pop + e);
+      const float4 v = *reinterpret_cast<const float4*>(vel + e);
+      const bool better = fit[row] < pbest_fit[row];
+      float4 pb = x;
+      if (!better) pb = *reinterpret_cast<const float4*>(pbest + e);
+      const float4 gcur = *reinterpret_cast<const float4*>((take ? best_row : gbest) + col);
+      const float4 lo = *reinterpret_cast<const float4*>(lb + col);
+      const float4 hi = *reinterpret_cast<const float4*>(ub + col);
+      float4 nv, nx;
+      nv.x = w * v.x + phi_p * lane_of(rp, 0) * (pb.x - x.x) + phi_g * lane_of(rg, 0) * (gcur.x - x.x);
+      nv.y = w * v.y + phi_p * lane_of(rp, 1) * (pb.y - x.y) + phi_g * lane_of(rg, 1) * (gcur.y - x.y);
+      nv.z = w * v.z + phi_p * lane_of(rp, 2) * (pb.z - x.z) + phi_g * lane_of(rg, 2) * (gcur.z - x.z);
+      nv.w = w * v.w + phi_p * lane_of(rp, 3) * (pb.w - x.w) + phi_g * lane_of(rg, 3) * (gcur.w - x.w);
+      nx.x = fminf(fmaxf(x.x + nv.x, lo.x), hi.x);
+      nx.y = fminf(fmaxf(x.y + nv.y, lo.y), hi.y);
+      nx.z = fminf(fmaxf(x.z + nv.z, lo.z), hi.z);
+      nx.w = fminf(fmaxf(x.w + nv.w, lo.w), hi.w);
+      *reinterpret_cast<float4*>(o_pbest + e) = pb;
+      *reinterpret_cast<float4*>(o_vel + e) = nv;
+      *reinterpret_cast<float4*>(o_pop + e) = nx;
+      if (row == 0) *reinterpret_cast<float4*>(o_gbest + col) = gcur;
+    }
+    return;
+  }
   const int shift = (int)(total & 3);
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 rp = unit4(philox_block(k0, k1, (uint64_t)q, kStreamDraw));
@@ -100,10 +189,23 @@ EVOX_API int evox_hip_pso_step(const int32_t* key, const float* pop, const float
                                float* o_pfit, float* o_gbest, float* o_gfit, int* ws, int64_t n, int d, float w,
                                float phi_p, float phi_g, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  pso_best_kernel<<<1, 1024, 0, st>>>(fit, pbest_fit, gbest_fit, o_pfit, o_gfit, ws, n);
+  if (n > kBestSpread) {
+    const int parts = (int)std::min<int64_t>(kBestParts, (n + 1023) / 1024);
+    pso_best_part_kernel<<<parts, 256, 0, st>>>(fit, pbest_fit, o_pfit, ws, n);
+    pso_best_final_kernel<<<1, 1024, 0, st>>>(gbest_fit, o_gfit, ws, parts);
+  } else {
+    pso_best_kernel<<<1, 1024, 0, st>>>(fit, pbest_fit, gbest_fit, o_pfit, o_gfit, ws, n);
+  }
   const int64_t nquad = (n * (int64_t)d + 3) >> 2;
-  pso_move_kernel<<<stream_grid(nquad, 256), 256, 0, st>>>(key, pop, vel, fit, pbest, pbest_fit, gbest, lb, ub, ws, o_pop,
-                                                            o_vel, o_pbest, o_gbest, n, d, w, phi_p, phi_g);
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = d % 4 == 0 && aligned(pop) && aligned(vel) && aligned(pbest) && aligned(gbest) && aligned(lb) &&
+                   aligned(ub) && aligned(o_pop) && aligned(o_vel) && aligned(o_pbest) && aligned(o_gbest);
+  if (vec)
+    pso_move_kernel<true><<<stream_grid(nquad, 256), 256, 0, st>>>(key, pop, vel, fit, pbest, pbest_fit, gbest, lb, ub, ws,
+                                                                  o_pop, o_vel, o_pbest, o_gbest, n, d, w, phi_p, phi_g);
+  else
+    pso_move_kernel<false><<<stream_grid(nquad, 256), 256, 0, st>>>(key, pop, vel, fit, pbest, pbest_fit, gbest, lb, ub, ws,
+                                                                   o_pop, o_vel, o_pbest, o_gbest, n, d, w, phi_p, phi_g);
   return last_launch_status();
 }
 

@@ -40,7 +40,7 @@ def pso_step(key, pop, vel, fit, pbest, pbest_fit, gbest, gbest_fit, lb, ub, w, 
     o_pop, o_vel, o_pbest = torch.empty_like(pop), torch.empty_like(vel), torch.empty_like(pbest)
     o_pfit = torch.empty_like(pbest_fit)
     o_gbest, o_gfit = torch.empty_like(gbest), torch.empty_like(gbest_fit)
-    ws = torch.empty(2, dtype=torch.int32, device=pop.device)
+    ws = torch.empty(2 + 2048, dtype=torch.int32, device=pop.device)   # arg-min, improved flag, the spread scan's partial minima
     check(hip().evox_hip_pso_step(
         key.data_ptr(), pop.data_ptr(), vel.data_ptr(), fit.data_ptr(), pbest.data_ptr(),
         pbest_fit.contiguous().data_ptr(), gbest.contiguous().data_ptr(), gbest_fit.data_ptr(),

@@ -126,6 +126,26 @@ def test_pso_step_matches_reference(cuda):
             assert torch.allclose(g.cpu(), r, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n,d", [(333, 16), (70000, 12), (70000, 7), (1100000, 4)])
+def test_pso_step_long_swarms_and_vector_rows(cuda, n, d):
+    """Swarms beyond 32 768 particles scan their bests with many workgroups, dimensions divisible by four move four
+    coordinates per lane: both must give the step of the tensor formulation, ties of the best going to the lowest index."""
+    key = rnd.PRNGKey(7).to(cuda)
+    g = torch.Generator().manual_seed(n + d)
+    lb, ub = torch.full((d,), -3.0), torch.full((d,), 3.0)
+    pop, vel, pbest = (torch.randn(n, d, generator=g) for _ in range(3))
+    fit, pfit = torch.rand(n, generator=g), torch.rand(n, generator=g)
+    fit[n // 3] = -5.0
+    fit[n - 2] = -5.0                                      # a tie of the swarm's best: the lower index wins
+    gbest, gfit = torch.randn(d, generator=g), torch.tensor([0.5])
+    ref = swarm.pso_step_reference(key.cpu(), pop, vel, fit, pbest, pfit, gbest, gfit, lb, ub, 0.6, 2.5, 0.8)
+    got = swarm.pso_step(key, *(t.to(cuda) for t in (pop, vel, fit, pbest, pfit, gbest, gfit, lb, ub)), 0.6, 2.5, 0.8)
+    for a, r in zip(got, ref):
+        assert torch.allclose(a.cpu(), r, rtol=1e-5, atol=1e-5)
+    assert torch.equal(got[3].cpu(), ref[3]) and torch.equal(got[5].cpu(), ref[5])
+    assert torch.equal(got[4].cpu(), pop[n // 3])
+
+
 def test_newton_schulz_sqrt_on_gpu(cuda):
     n = 300
     a = torch.randn(n, n, device=cuda)
