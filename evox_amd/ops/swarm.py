@@ -10,7 +10,8 @@ from ..core import random as rnd
 from ._util import check, hip, on_gpu, stream_of
 
 _native.register_hip_api({
-    "evox_hip_cso_step": (_native.I, [_native.P] * 6 + [_native.F, _native.P, _native.P, _native.I, _native.I] + [_native.P] * 5),
+    "evox_hip_cso_step": (_native.I, [_native.P] * 6 + [_native.F, _native.P, _native.P, _native.I, _native.I, _native.I]
+                          + [_native.P] * 5),
     "evox_hip_pso_step": (_native.I, [_native.P] * 17 + [_native.I64, _native.I, _native.F, _native.F, _native.F,
                                                         _native.P]),
 })
@@ -57,13 +58,16 @@ def cso_step(key, pop, vel, fit, perm, phi, lb, ub):
     n, d = pop.shape
     half = n // 2
     pop, vel = pop.contiguous(), vel.contiguous()
-    new_pop, new_vel = pop.clone(), vel.clone()
+    # an even swarm: every particle is in a pair and the kernel writes winners' rows too; otherwise the particle left
+    # out keeps its row through the copies
+    write_all = 2 * half == n and perm.numel() == n
+    new_pop, new_vel = (torch.empty_like(pop), torch.empty_like(vel)) if write_all else (pop.clone(), vel.clone())
     cand = torch.empty((half, d), dtype=torch.float32, device=pop.device)
     students = torch.empty(half, dtype=torch.int64, device=pop.device)
     center = pop.mean(0) if phi != 0 else None
     check(hip().evox_hip_cso_step(key.contiguous().data_ptr(), pop.data_ptr(), vel.data_ptr(), fit.contiguous().data_ptr(),
                                   perm.contiguous().data_ptr(), center.data_ptr() if center is not None else None,
-                                  float(phi), lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), half, d,
+                                  float(phi), lb.contiguous().data_ptr(), ub.contiguous().data_ptr(), half, d, int(write_all),
                                   new_pop.data_ptr(), new_vel.data_ptr(), cand.data_ptr(), students.data_ptr(),
                                   stream_of(pop)), "cso_step")
     return cand, new_pop, new_vel, students

@@ -990,7 +990,7 @@ def test_sra_indicators_kernel_matches_matrix_form(cuda, n, m, lower):
     assert torch.allclose(got2.cpu().double(), want2, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("pop,dim,phi", [(1024, 100, 0.0), (101, 7, 0.1), (4, 3, 0.2)])
+@pytest.mark.parametrize("pop,dim,phi", [(1024, 100, 0.0), (101, 7, 0.1), (4, 3, 0.2), (1000, 24, 0.1), (77, 8, 0.1)])
 def test_fused_cso_step_matches_tensor_formulation(cuda, pop, dim, phi, monkeypatch):
     import evox_amd as ex
     from evox_amd import algorithms

@@ -1,7 +1,7 @@
 """Population and dimension scaling of whole generations on ONE GPU: how the time of a generation and the memory held
-grow when the population or the decision vector grows by decades (CMA-ES, OpenES, PSO, NSGA-II).
+grow when the population or the decision vector grows by decades (CMA-ES, OpenES, PSO, CSO, NSGA-II).
 
-    PYTHONPATH=. python3 tools/scaling_sweep.py [--out gpurun_out/scaling_single_gpu.jsonl] [--family cmaes,openes,pso,nsga2]
+    PYTHONPATH=. python3 tools/scaling_sweep.py [--out gpurun_out/scaling_single_gpu.jsonl] [--family cmaes,openes,pso,cso,nsga2]
 
 One JSON line per case: ``ms_per_step``, ``evals_per_sec``, ``peak_mem_gb`` (torch allocator peak over the case) and
 ``bytes_per_eval`` = peak memory / population, the figure that says how many individuals fit next to the 288 GB."""
@@ -52,6 +52,11 @@ def cases(dev):
         algo = algorithms.PSO(lb=torch.full((dim,), -32.0, device=dev), ub=torch.full((dim,), 32.0, device=dev), pop_size=pop)
         return workflows.StdWorkflow(algo, problems.numerical.Ackley()), ex.PRNGKey(3).to(dev)
 
+    def cso(pop, dim):
+        algo = algorithms.CSO(lb=torch.full((dim,), -32.0, device=dev), ub=torch.full((dim,), 32.0, device=dev), pop_size=pop,
+                              phi=0.1)
+        return workflows.StdWorkflow(algo, problems.numerical.Ackley()), ex.PRNGKey(5).to(dev)
+
     def nsga2(pop, dim):
         algo = algorithms.NSGA2(lb=torch.zeros(dim, device=dev), ub=torch.ones(dim, device=dev), n_objs=3, pop_size=pop)
         return workflows.StdWorkflow(algo, problems.numerical.DTLZ2(m=3)), ex.PRNGKey(4).to(dev)
@@ -61,6 +66,7 @@ def cases(dev):
                           (10000, 128), (10000, 512), (10000, 2048), (10000, 4096)]),
         "openes": (openes, [(1024, 10**5), (1024, 10**6), (1024, 10**7), (8192, 10**6), (65536, 10**5)]),
         "pso": (pso, [(10**4, 100), (10**5, 100), (10**6, 100), (10**7, 100), (10**5, 1000), (10**5, 10000)]),
+        "cso": (cso, [(10**4, 100), (10**5, 100), (10**6, 100), (10**5, 1000), (10**4, 10**5)]),
         "nsga2": (nsga2, [(10**3, 12), (10**4, 12), (10**5, 12), (2 * 10**5, 12)]),
     }
     return grid
@@ -69,7 +75,7 @@ def cases(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/scaling_single_gpu.jsonl")
-    ap.add_argument("--family", default="cmaes,openes,pso,nsga2")
+    ap.add_argument("--family", default="cmaes,openes,pso,cso,nsga2")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     grid = cases(dev)
