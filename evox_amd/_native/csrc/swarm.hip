@@ -356,8 +356,73 @@ __device__ __forceinline__ float unit_at(const int32_t* key, uint64_t e) {
   return bits_to_unit(lane_of(blk, (int)(e & 3)));
 }
 
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+__device__ __forceinline__ void store4(float* p, const float (&o)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+// elements e … e + 3 of a key's uniform stream, e a multiple of four: one Philox block
+__device__ __forceinline__ void units4_at(const int32_t* key, uint64_t e, float (&o)[4]) {
+  const f32x4 u = unit4(philox_block((uint32_t)key[0], (uint32_t)key[1], e >> 2, kStreamDraw));
+  o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w;
+}
+
+// VEC: the dimension and every stream offset are multiples of four and all operands 16-byte aligned — a lane moves four
+// coordinates of one row (16-byte accesses, one Philox block per random factor instead of four).
+template <bool VEC>
 __global__ __launch_bounds__(256) void swarm_attract_kernel(Attract a) {
   const int64_t total = a.n * (int64_t)a.dim;
+  if constexpr (VEC) {
+    const int64_t nquad = total >> 2;
+    const bool narrow = total < ((int64_t)1 << 31);
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t e = 4 * q;
+      const int64_t r = narrow ? (int64_t)((uint32_t)e / (uint32_t)a.dim) : e / a.dim;
+      const int c = (int)(e - r * a.dim);
+      float x[4], v[4], nv[4], u[4], lo[4], hi[4];
+      load4(a.x + e, x);
+      load4(a.v + e, v);
+      if (a.inertia_key) {
+        units4_at(a.inertia_key, (uint64_t)(a.inertia_offset + e), u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nv[j] = (a.inertia * u[j]) * v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nv[j] = a.inertia * v[j];
+      }
+#pragma unroll
+      for (int k = 0; k < kMaxAttract; ++k) {
+        if (k < a.nterms) {
+          const AttractTerm& t = a.t[k];
+          const int64_t row = t.mode == 0 ? r : (t.mode == 1 ? t.index[r] : 0);
+          float T[4];
+          load4(t.table + row * a.dim + c, T);
+          if (t.key) {
+            units4_at(t.key, (uint64_t)(t.offset + e), u);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nv[j] = nv[j] + (t.coef * u[j]) * (T[j] - x[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nv[j] = nv[j] + t.coef * (T[j] - x[j]);
+          }
+        }
+      }
+      if (a.row_scale) {
+        const float sc = a.row_scale[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nv[j] = sc * nv[j];
+      }
+      load4(a.lb + c, lo);
+      load4(a.ub + c, hi);
+      store4(a.ov + e, nv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = fminf(fmaxf(x[j] + nv[j], lo[j]), hi[j]);
+      store4(a.ox + e, x);
+    }
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / a.dim;
     const int c = (int)(e - r * a.dim);
@@ -404,7 +469,14 @@ EVOX_API int evox_hip_swarm_attract(const float* x, const float* v, const float*
     a.t[k].mode = modes[k];
     a.t[k].coef = coefs[k];
   }
-  swarm_attract_kernel<<<stream_grid(n * (int64_t)dim, 256), 256, 0, (hipStream_t)stream>>>(a);
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool vec = dim % 4 == 0 && aligned(x) && aligned(v) && aligned(lb) && aligned(ub) && aligned(ox) && aligned(ov) &&
+             (inertia_key == nullptr || inertia_offset % 4 == 0);
+  for (int k = 0; k < nterms; ++k) vec = vec && aligned(tables[k]) && (keys[k] == nullptr || offsets[k] % 4 == 0);
+  if (vec)
+    swarm_attract_kernel<true><<<stream_grid(n * (int64_t)(dim / 4), 256), 256, 0, (hipStream_t)stream>>>(a);
+  else
+    swarm_attract_kernel<false><<<stream_grid(n * (int64_t)dim, 256), 256, 0, (hipStream_t)stream>>>(a);
   return last_launch_status();
 }
 

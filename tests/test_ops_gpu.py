@@ -1275,7 +1275,8 @@ def test_radix_select_matches_sorted_selection(n, k, largest, route, monkeypatch
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["CLPSO", "SLPSOGS", "SLPSOUS", "DMSPSOEL", "FIPS", "FIPS_pbest", "SwmmPSO", "FSPSO"])
-def test_swarm_variant_fused_move_matches_tensor_formulation(name, monkeypatch):
+@pytest.mark.parametrize("d", [37, 40])           # 40: four coordinates per lane
+def test_swarm_variant_fused_move_matches_tensor_formulation(name, d, monkeypatch):
     """The one-launch velocity / position move of the swarm variants (``swarm_attract_kernel``, ``fips_move_kernel``)
     draws the same random factors as the tensor formulation: both tell() from the same state agree, generation after
     generation (DMS-PSO-EL: regrouping generations, plain multi-swarm generations and the final global phase)."""
@@ -1284,7 +1285,7 @@ def test_swarm_variant_fused_move_matches_tensor_formulation(name, monkeypatch):
     from evox_amd.ops import swarm as swarm_ops
 
     dev = torch.device("cuda")
-    d, n = 37, 300
+    n = 300
     lb, ub = torch.full((d,), -10.0, device=dev), torch.full((d,), 10.0, device=dev)
     algo = {"CLPSO": lambda: A.CLPSO(lb, ub, n, 0.5, 1.5, torch.full((n,), 0.2, device=dev)),
             "SLPSOGS": lambda: A.SLPSOGS(lb, ub, n, 0.2, 0.7), "SLPSOUS": lambda: A.SLPSOUS(lb, ub, n, 0.2, 0.7),
