@@ -57,6 +57,19 @@ def cases(dev):
                               phi=0.1)
         return workflows.StdWorkflow(algo, problems.numerical.Ackley()), ex.PRNGKey(5).to(dev)
 
+    def shade(pop, dim):
+        algo = algorithms.SHADE(lb=torch.full((dim,), -32.0, device=dev), ub=torch.full((dim,), 32.0, device=dev), pop_size=pop)
+        return workflows.StdWorkflow(algo, problems.numerical.Ackley()), ex.PRNGKey(6).to(dev)
+
+    def de(pop, dim):
+        algo = algorithms.DE(lb=torch.full((dim,), -32.0, device=dev), ub=torch.full((dim,), 32.0, device=dev), pop_size=pop,
+                             batch_size=pop)
+        return workflows.StdWorkflow(algo, problems.numerical.Ackley()), ex.PRNGKey(7).to(dev)
+
+    def pgpe(pop, dim):
+        algo = algorithms.PGPE(pop_size=pop, center_init=torch.zeros(dim, device=dev), optimizer="adam")
+        return workflows.StdWorkflow(algo, problems.numerical.Sphere()), ex.PRNGKey(8).to(dev)
+
     def nsga2(pop, dim):
         algo = algorithms.NSGA2(lb=torch.zeros(dim, device=dev), ub=torch.ones(dim, device=dev), n_objs=3, pop_size=pop)
         return workflows.StdWorkflow(algo, problems.numerical.DTLZ2(m=3)), ex.PRNGKey(4).to(dev)
@@ -67,6 +80,9 @@ def cases(dev):
         "openes": (openes, [(1024, 10**5), (1024, 10**6), (1024, 10**7), (8192, 10**6), (65536, 10**5)]),
         "pso": (pso, [(10**4, 100), (10**5, 100), (10**6, 100), (10**7, 100), (10**5, 1000), (10**5, 10000)]),
         "cso": (cso, [(10**4, 100), (10**5, 100), (10**6, 100), (10**5, 1000), (10**4, 10**5)]),
+        "shade": (shade, [(10**4, 100), (10**5, 100), (10**6, 100), (10**5, 1000)]),
+        "de": (de, [(10**4, 100), (10**5, 100), (10**6, 100), (10**5, 1000)]),
+        "pgpe": (pgpe, [(1024, 10**5), (1024, 10**6), (16384, 10**5)]),
         "nsga2": (nsga2, [(10**3, 12), (10**4, 12), (10**5, 12), (2 * 10**5, 12)]),
     }
     return grid
