@@ -115,20 +115,16 @@ __global__ __launch_bounds__(256) void de_select_kernel(const float* __restrict_
   }
 }
 
-// mode 0 (SHADE): mem (2×H) → mem_out with the new (M_F, M_CR) in slot 0 and the rest shifted right,
-//                 unchanged when nothing improved or a mean is not finite.
-// mode 1 (JADE):  mem = (F_u, CR_u), H = 1: mean ← (1−c)·mean + c·(Lehmer mean of F | mean of CR).
-__global__ __launch_bounds__(256) void de_finalize_kernel(const float* __restrict__ partials, int nblocks, int mode,
-                                                          float c, const float* __restrict__ mem_f,
-                                                          const float* __restrict__ mem_cr, int H,
-                                                          float* __restrict__ out_f, float* __restrict__ out_cr,
-                                                          int64_t* __restrict__ best_index) {
-  __shared__ float red[4][kPart];
-  __shared__ float tot[kPart];
+// Sum (four weights) and lexicographic minimum (fitness, index) of the records first, first + stride, … < last, by
+// one 256-thread workgroup; the result is valid in thread 0.
+struct DeTotals { float s[4]; float best; int best_i; };
+
+__device__ inline DeTotals de_reduce_records(const float* partials, int64_t first, int64_t last, int64_t stride,
+                                             float (*red)[kPart]) {
   float w = 0.f, wcr = 0.f, wf2 = 0.f, wf = 0.f, best = INFINITY;
   int best_i = 0x7FFFFFFF;
-  for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-    const float* p = partials + (int64_t)b * kPart;
+  for (int64_t b = first + (int64_t)threadIdx.x * stride; b < last; b += (int64_t)blockDim.x * stride) {
+    const float* p = partials + b * kPart;
     w += p[0]; wcr += p[1]; wf2 += p[2]; wf += p[3];
     const float ob = p[4];
     const int oi = __float_as_int(p[5]);
@@ -148,6 +144,7 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(const float* __restric
     red[wave][4] = best; red[wave][5] = __int_as_float(best_i);
   }
   __syncthreads();
+  DeTotals t{};
   if (threadIdx.x == 0) {
     float b = red[0][4];
     int bi = __float_as_int(red[0][5]);
@@ -156,8 +153,43 @@ __global__ __launch_bounds__(256) void de_finalize_kernel(const float* __restric
       const int oi = __float_as_int(red[v][5]);
       if (ob < b || (ob == b && oi < bi)) { b = ob; bi = oi; }
     }
-    for (int k = 0; k < 4; ++k) tot[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
-    best_index[0] = bi == 0x7FFFFFFF ? 0 : bi;
+    for (int k = 0; k < 4; ++k) t.s[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    t.best = b;
+    t.best_i = bi;
+  }
+  return t;
+}
+
+// Long populations leave hundreds of thousands of records: workgroup g folds records [g·chunk, (g+1)·chunk) into the
+// first record of its own chunk (nobody else reads that chunk), and the finalising workgroup then reads every chunk-th
+// record — one workgroup walking 250 000 records alone took as long as the selection pass itself.
+__global__ __launch_bounds__(256) void de_fold_kernel(float* partials, int nblocks, int chunk) {
+  __shared__ float red[4][kPart];
+  const int64_t first = (int64_t)blockIdx.x * chunk;
+  const int64_t last = min((int64_t)nblocks, first + chunk);
+  const DeTotals t = de_reduce_records(partials, first, last, 1, red);
+  if (threadIdx.x == 0) {
+    float* p = partials + first * kPart;
+    p[0] = t.s[0]; p[1] = t.s[1]; p[2] = t.s[2]; p[3] = t.s[3];
+    p[4] = t.best; p[5] = __int_as_float(t.best_i);
+  }
+}
+
+// mode 0 (SHADE): mem (2×H) → mem_out with the new (M_F, M_CR) in slot 0 and the rest shifted right,
+//                 unchanged when nothing improved or a mean is not finite.
+// mode 1 (JADE):  mem = (F_u, CR_u), H = 1: mean ← (1−c)·mean + c·(Lehmer mean of F | mean of CR).
+// The records read are 0, stride, 2·stride, … < nblocks.
+__global__ __launch_bounds__(256) void de_finalize_kernel(const float* __restrict__ partials, int nblocks, int stride,
+                                                          int mode, float c, const float* __restrict__ mem_f,
+                                                          const float* __restrict__ mem_cr, int H,
+                                                          float* __restrict__ out_f, float* __restrict__ out_cr,
+                                                          int64_t* __restrict__ best_index) {
+  __shared__ float red[4][kPart];
+  __shared__ float tot[kPart];
+  const DeTotals t = de_reduce_records(partials, 0, nblocks, stride, red);
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 4; ++k) tot[k] = t.s[k];
+    best_index[0] = t.best_i == 0x7FFFFFFF ? 0 : t.best_i;
   }
   __syncthreads();
   const float sw = tot[0];
@@ -208,11 +240,21 @@ EVOX_API int evox_hip_de_select(const float* pop, const float* trial, const floa
   return last_launch_status();
 }
 
+constexpr int kFoldMin = 4096;       // records beyond which a fold pass precedes the finalising workgroup
+constexpr int kFoldGroups = 256;
+
+// The records beyond kFoldMin are folded in place: partials is written as well as read.
 EVOX_API int evox_hip_de_finalize(const float* partials, int nblocks, int mode, float c, const float* mem_f,
                                   const float* mem_cr, int H, float* out_f, float* out_cr, int64_t* best_index,
                                   void* stream) {
   if (nblocks <= 0 || H < 1 || (mode != 0 && mode != 1)) return (int)hipErrorInvalidValue;
-  de_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, nblocks, mode, c, mem_f, mem_cr, H, out_f, out_cr,
-                                                         best_index);
+  int stride = 1;
+  if (nblocks > kFoldMin) {
+    stride = (nblocks + kFoldGroups - 1) / kFoldGroups;
+    const int groups = (nblocks + stride - 1) / stride;
+    de_fold_kernel<<<groups, 256, 0, (hipStream_t)stream>>>(const_cast<float*>(partials), nblocks, stride);
+  }
+  de_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partials, nblocks, stride, mode, c, mem_f, mem_cr, H, out_f,
+                                                         out_cr, best_index);
   return last_launch_status();
 }
