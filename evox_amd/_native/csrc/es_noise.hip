@@ -113,7 +113,24 @@ __global__ __launch_bounds__(256) void es_perturb_kernel(const int32_t* __restri
 // column-quad kernel above computes each up to four times (two blocks per unaligned quad, and again
 // for the mirrored row), which made it generator-bound at 1.4 TB/s of output.
 // Noise rows [nr0, nr0 + R); out row of noise row nr: nr − nr0 (and nr − nr0 + R when MIRROR).
-template <typename T, bool MIRROR>
+// VEC: dim and pitch are multiples of four and all operands aligned — a block of four normals lies inside one row and
+// is written (and its centre read) with one 16-byte access (8 bytes as bf16) instead of four.
+__device__ __forceinline__ uint32_t bf16_bits(float v) {
+  return (__float_as_uint(v) + 0x7fffu + ((__float_as_uint(v) >> 16) & 1u)) >> 16;
+}
+template <typename T>
+__device__ __forceinline__ void store_quad(T* o, float a, float b, float c, float d) {
+  if constexpr (sizeof(T) == 2) {
+    uint2 w;
+    w.x = bf16_bits(a) | (bf16_bits(b) << 16);
+    w.y = bf16_bits(c) | (bf16_bits(d) << 16);
+    *reinterpret_cast<uint2*>(o) = w;
+  } else {
+    *reinterpret_cast<float4*>(o) = make_float4(a, b, c, d);
+  }
+}
+
+template <typename T, bool MIRROR, bool VEC>
 __global__ __launch_bounds__(256) void es_perturb_flat_kernel(const int32_t* __restrict__ key,
                                                               const float* __restrict__ center,
                                                               const float* __restrict__ scale, int scale_is_vec,
@@ -123,6 +140,23 @@ __global__ __launch_bounds__(256) void es_perturb_flat_kernel(const int32_t* __r
   const uint64_t first = (uint64_t)nr0 * (uint64_t)dim, last = (uint64_t)(nr0 + R) * (uint64_t)dim;   // [first, last)
   const uint64_t b_lo = first >> 2, b_hi = (last + 3) >> 2;
   const float s0 = scale[0];
+  if constexpr (VEC) {
+    const bool narrow = last < ((uint64_t)1 << 32);
+    for (uint64_t b = b_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += (uint64_t)gridDim.x * blockDim.x) {
+      const f32x4 z = normal4(philox_block(k0, k1, b, kStreamDraw));
+      const uint64_t e = b << 2;
+      const int64_t nr = narrow ? (int64_t)((uint32_t)e / (uint32_t)dim) : (int64_t)(e / (uint64_t)dim);
+      const int64_t c = (int64_t)(e - (uint64_t)nr * (uint64_t)dim);
+      const float4 ctr = *reinterpret_cast<const float4*>(center + c);
+      float4 sc = make_float4(s0, s0, s0, s0);
+      if (scale_is_vec) sc = *reinterpret_cast<const float4*>(scale + c);
+      T* o = out + (nr - nr0) * pitch + c;
+      store_quad<T>(o, ctr.x + sc.x * z.x, ctr.y + sc.y * z.y, ctr.z + sc.z * z.z, ctr.w + sc.w * z.w);
+      if (MIRROR)
+        store_quad<T>(o + R * pitch, ctr.x - sc.x * z.x, ctr.y - sc.y * z.y, ctr.z - sc.z * z.z, ctr.w - sc.w * z.w);
+    }
+    return;
+  }
   for (uint64_t b = b_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += (uint64_t)gridDim.x * blockDim.x) {
     const f32x4 z4 = normal4(philox_block(k0, k1, b, kStreamDraw));
     uint64_t e = b << 2;
@@ -166,13 +200,25 @@ EVOX_API int evox_hip_es_perturb(const int32_t* key, const float* center, const 
       const int64_t blocks4 = (R * dim + 3) / 4 + 1;
       const int grid1 = (int)((blocks4 + 255) / 256 < 16384 ? (blocks4 + 255) / 256 : 16384);
       hipStream_t s = (hipStream_t)stream;
-      if (out_dtype == 1) {
-        if (whole_mirror) es_perturb_flat_kernel<uint16_t, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch, row_offset, R, dim);
-        else es_perturb_flat_kernel<uint16_t, false><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch, row_offset, R, dim);
-      } else {
-        if (whole_mirror) es_perturb_flat_kernel<float, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch, row_offset, R, dim);
-        else es_perturb_flat_kernel<float, false><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch, row_offset, R, dim);
-      }
+      auto aligned = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+      const bool vec = dim % 4 == 0 && pitch % 4 == 0 && aligned(center, 16) && (!scale_is_vec || aligned(scale, 16)) &&
+                       aligned(out, out_dtype == 1 ? 8 : 16);
+#define EVOX_FLAT(T, M, V) es_perturb_flat_kernel<T, M, V><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (T*)out, \
+                                                                                pitch, row_offset, R, dim)
+#define EVOX_FLAT_T(T)                          \
+  do {                                          \
+    if (whole_mirror) {                         \
+      if (vec) EVOX_FLAT(T, true, true);        \
+      else EVOX_FLAT(T, true, false);           \
+    } else {                                    \
+      if (vec) EVOX_FLAT(T, false, true);       \
+      else EVOX_FLAT(T, false, false);          \
+    }                                           \
+  } while (0)
+      if (out_dtype == 1) EVOX_FLAT_T(uint16_t);
+      else EVOX_FLAT_T(float);
+#undef EVOX_FLAT_T
+#undef EVOX_FLAT
       return last_launch_status();
     }
   }
@@ -197,12 +243,16 @@ EVOX_API int evox_hip_es_perturb_pairs(const int32_t* key, const float* center, 
   const int64_t blocks4 = (count * dim + 3) / 4 + 1;
   const int grid1 = (int)((blocks4 + 255) / 256 < 16384 ? (blocks4 + 255) / 256 : 16384);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dtype == 1)
-    es_perturb_flat_kernel<uint16_t, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch,
-                                                                 noise_start, count, dim);
-  else
-    es_perturb_flat_kernel<float, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch,
-                                                              noise_start, count, dim);
+  auto aligned = [](const void* p, uintptr_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  const bool vec = dim % 4 == 0 && pitch % 4 == 0 && aligned(center, 16) && (!scale_is_vec || aligned(scale, 16)) &&
+                   aligned(out, out_dtype == 1 ? 8 : 16);
+  if (out_dtype == 1) {
+    if (vec) es_perturb_flat_kernel<uint16_t, true, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch, noise_start, count, dim);
+    else es_perturb_flat_kernel<uint16_t, true, false><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (uint16_t*)out, pitch, noise_start, count, dim);
+  } else {
+    if (vec) es_perturb_flat_kernel<float, true, true><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch, noise_start, count, dim);
+    else es_perturb_flat_kernel<float, true, false><<<grid1, 256, 0, s>>>(key, center, scale, scale_is_vec, (float*)out, pitch, noise_start, count, dim);
+  }
   return last_launch_status();
 }
 

@@ -425,6 +425,26 @@ def test_fused_perturb_matches_host_path(cuda, dim, mirrored):
     torch.testing.assert_close(got16.cpu().float(), want16.float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("dim", [1000, 1002, 37, 4096])
+def test_fused_perturb_whole_mirrored_population_and_pairs(cuda, dim):
+    """The whole mirrored population in one tensor and a share of its pairs (one generator pass writes both signs): a
+    dimension divisible by four takes 16-byte stores (8 bytes as bf16), others the element-wise form — same numbers."""
+    from evox_amd.ops import es
+    key = rnd.PRNGKey(12)
+    center = torch.randn(dim)
+    scale = torch.rand(dim) + 0.1
+    for sc_host in (0.3, scale):
+        sc_dev = sc_host.to(cuda) if isinstance(sc_host, torch.Tensor) else sc_host
+        want = es.perturb(key, center, sc_host, 96, mirrored=True)
+        got = es.perturb(key.to(cuda), center.to(cuda), sc_dev, 96, mirrored=True)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-6, atol=1e-6)
+        pairs = es.perturb_pairs(key.to(cuda), center.to(cuda), sc_dev, 8, 16)          # noise rows 8 … 23
+        torch.testing.assert_close(pairs.cpu(), torch.cat([want[8:24], want[56:72]]), rtol=1e-6, atol=1e-6)
+    got16 = es.perturb(key.to(cuda), center.to(cuda), 0.3, 96, mirrored=True, out_dtype=torch.bfloat16)
+    want16 = es.perturb(key, center, 0.3, 96, mirrored=True).bfloat16()
+    assert torch.equal(got16.cpu(), want16)                 # round-to-nearest-even of the same fp32 values
+
+
 @pytest.mark.parametrize("sizes", [(244, 1024, 720, 17), (27, 64, 8), (5, 130, 3), (12, 256, 256, 6), (11, 16, 3), (17, 48, 48, 6),
                                    (300, 7)])
 @pytest.mark.parametrize("E", [1, 2, 4])
