@@ -157,29 +157,42 @@ __global__ __launch_bounds__(256) void es_perturb_flat_kernel(const int32_t* __r
     }
     return;
   }
-  for (uint64_t b = b_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < b_hi; b += (uint64_t)gridDim.x * blockDim.x) {
-    const f32x4 z4 = normal4(philox_block(k0, k1, b, kStreamDraw));
-    uint64_t e = b << 2;
-    int64_t nr = (int64_t)(e / (uint64_t)dim);
+  // Any dimension: a lane still generates one block of four normals, but the workgroup's 1024 values are turned round in
+  // LDS so that consecutive lanes write consecutive elements (four stores of 256 contiguous bytes per wavefront instead
+  // of four stores that each touch every fourth word of a kilobyte).  Every thread of the workgroup takes part in the
+  // barriers: the loop's trip count depends on the workgroup alone.
+  __shared__ float tile[1024];
+  const bool narrow = last < ((uint64_t)1 << 32);
+  for (uint64_t base = b_lo + (uint64_t)blockIdx.x * 256; base < b_hi; base += (uint64_t)gridDim.x * 256) {
+    const uint64_t b = base + threadIdx.x;
+    f32x4 z4{0.f, 0.f, 0.f, 0.f};
+    if (b < b_hi) z4 = normal4(philox_block(k0, k1, b, kStreamDraw));
+    *reinterpret_cast<float4*>(&tile[4 * threadIdx.x]) = make_float4(z4.x, z4.y, z4.z, z4.w);
+    __syncthreads();
+    uint64_t e = (base << 2) + threadIdx.x;
+    int64_t nr = narrow ? (int64_t)((uint32_t)e / (uint32_t)dim) : (int64_t)(e / (uint64_t)dim);
     int64_t c = (int64_t)(e - (uint64_t)nr * (uint64_t)dim);
 #pragma unroll
-    for (int l = 0; l < 4; ++l, ++e) {
+    for (int j = 0; j < 4; ++j) {
       if (e >= first && e < last) {
-        const float z = lane_of(z4, l);
+        const float z = tile[j * 256 + threadIdx.x];
         const float ctr = center[c], sc = scale_is_vec ? scale[c] : s0;
         const float up = ctr + sc * z;
         T* o = out + (nr - nr0) * pitch + c;
-        if constexpr (sizeof(T) == 2) o[0] = (T)((__float_as_uint(up) + 0x7fffu + ((__float_as_uint(up) >> 16) & 1u)) >> 16);
+        if constexpr (sizeof(T) == 2) o[0] = (T)bf16_bits(up);
         else o[0] = up;
         if (MIRROR) {
           const float dn = ctr - sc * z;
           T* o2 = o + R * pitch;
-          if constexpr (sizeof(T) == 2) o2[0] = (T)((__float_as_uint(dn) + 0x7fffu + ((__float_as_uint(dn) >> 16) & 1u)) >> 16);
+          if constexpr (sizeof(T) == 2) o2[0] = (T)bf16_bits(dn);
           else o2[0] = dn;
         }
       }
-      if (++c == dim) { c = 0; ++nr; }
+      e += 256;
+      c += 256;
+      while (c >= dim) { c -= dim; ++nr; }
     }
+    __syncthreads();
   }
 }
 
