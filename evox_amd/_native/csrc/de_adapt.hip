@@ -54,31 +54,40 @@ __global__ __launch_bounds__(256) void de_select_kernel(const float* __restrict_
                                                         const float* __restrict__ fit,
                                                         const float* __restrict__ trial_fit,
                                                         const float* __restrict__ F, const float* __restrict__ CR,
-                                                        int strict, int weight_by_gain, int n, int d,
+                                                        int strict, int weight_by_gain, int n, int d, int vec,
                                                         float* __restrict__ new_pop, float* __restrict__ new_fit,
                                                         float* __restrict__ partials) {
   constexpr int RPB = 256 / LPR;
   __shared__ float red[4][kPart];
   const int sub = threadIdx.x % LPR;
-  const int r = blockIdx.x * RPB + threadIdx.x / LPR;
   float w = 0.f, wcr = 0.f, wf2 = 0.f, wf = 0.f, best = INFINITY;
   int best_i = 0x7FFFFFFF;
-  if (r < n) {
+  // a workgroup takes the row groups blockIdx.x, blockIdx.x + gridDim.x, …: one group each up to kSelectMaxBlocks groups,
+  // several beyond (a million rows as a quarter of a million workgroups were bound by workgroup launches)
+  const int groups = (n + RPB - 1) / RPB;
+  for (int g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int r = g * RPB + threadIdx.x / LPR;
+    if (r >= n) continue;
     const float pf = fit[r], tf = trial_fit[r];
     const bool ok = strict ? (tf < pf) : (tf <= pf);
     const float* src = (ok ? trial : pop) + (int64_t)r * d;
     float* dst = new_pop + (int64_t)r * d;
-    for (int c = sub; c < d; c += LPR) dst[c] = src[c];
+    if (vec) {
+      for (int c = sub; c < (d >> 2); c += LPR)
+        reinterpret_cast<float4*>(dst)[c] = reinterpret_cast<const float4*>(src)[c];
+    } else {
+      for (int c = sub; c < d; c += LPR) dst[c] = src[c];
+    }
     if (sub == 0) {
       const float nf = ok ? tf : pf;
       new_fit[r] = nf;
-      best = nf == nf ? nf : INFINITY;
-      best_i = r;
+      const float key = nf == nf ? nf : INFINITY;
+      if (key < best || (key == best && r < best_i)) { best = key; best_i = r; }
       if (ok) {
         float gain = weight_by_gain ? pf - tf : 1.f;
         if (!(fabsf(gain) < INFINITY)) gain = 0.f;           // inf − x or NaN: no weight
         const float f = F[r], cr = CR[r];
-        w = gain; wcr = gain * cr; wf2 = gain * f * f; wf = gain * f;
+        w += gain; wcr += gain * cr; wf2 += gain * f * f; wf += gain * f;
       }
     }
   }
@@ -217,10 +226,13 @@ EVOX_API int evox_hip_shade_params(const int32_t* k_slot, const int32_t* k_f, co
   return last_launch_status();
 }
 
+constexpr int kSelectMaxBlocks = 16384;
+
 EVOX_API int evox_hip_de_select_blocks(int n, int d) {
   const int lpr = d >= 48 ? 64 : (d >= 24 ? 32 : (d >= 12 ? 16 : 8));
   const int rpb = 256 / lpr;
-  return (n + rpb - 1) / rpb;
+  const int groups = (n + rpb - 1) / rpb;
+  return groups < kSelectMaxBlocks ? groups : kSelectMaxBlocks;
 }
 
 // partials: evox_hip_de_select_blocks(n, d) × 6 floats
@@ -230,8 +242,10 @@ EVOX_API int evox_hip_de_select(const float* pop, const float* trial, const floa
   if (n <= 0 || d <= 0) return (int)hipErrorInvalidValue;
   const int blocks = evox_hip_de_select_blocks(n, d);
   hipStream_t s = (hipStream_t)stream;
+  auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const int vec = d % 4 == 0 && aligned(pop) && aligned(trial) && aligned(new_pop);
 #define EVOX_SEL(L) de_select_kernel<L><<<blocks, 256, 0, s>>>(pop, trial, fit, trial_fit, F, CR, strict, weight_by_gain, \
-                                                                 n, d, new_pop, new_fit, partials)
+                                                                 n, d, vec, new_pop, new_fit, partials)
   if (d >= 48) EVOX_SEL(64);
   else if (d >= 24) EVOX_SEL(32);
   else if (d >= 12) EVOX_SEL(16);

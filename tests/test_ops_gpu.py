@@ -864,7 +864,7 @@ def test_fused_dtlz_kernel_matches_tensor_formulation(cuda, name, m):
 
 
 @pytest.mark.parametrize("algo_name", ["JaDE", "SHADE"])
-@pytest.mark.parametrize("dim,pop", [(20, 5000), (7, 333), (60, 1000), (60, 20000)])   # the last: folded success records
+@pytest.mark.parametrize("dim,pop", [(20, 5000), (7, 333), (60, 1000), (60, 20000), (60, 70000)])   # folded success records; several row groups per workgroup
 def test_fused_adaptive_de_bookkeeping_matches_tensor_formulation(cuda, algo_name, dim, pop, monkeypatch):
     """Parameter draws, greedy replacement, success statistics and memory update from the fused
     kernels against the tensor formulation, generation by generation from the same state."""
